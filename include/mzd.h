@@ -1,0 +1,271 @@
+/*
+ * mzd.h -- C ABI of the MI355X zstd block-decode hot path ("mzd").
+ *
+ * This is the drop-in boundary underneath KillingSpark/sparkzstd's
+ * FrameReader / FrameDecompressor.  The reference has no FFI of its own (pure
+ * Go); the seam this ABI replaces is the inside of
+ *   (*FrameDecompressor).DecodeNextBlock      decompression/framedecompressor.go:198-244
+ * i.e. the three hot loops
+ *   (*HuffmanDecodingTable).DecodeStream       structure/huffman.go:221-264
+ *   (*SequencesSection).DecodeSequences        structure/sequences.go:126-206
+ *   (*FrameDecompressor).ExecuteSequences      decompression/sequence_execution.go:14-63
+ *     + Ringbuffer.Push / RepeatBeforeIndex    decompression/ringbuffer.go:102,242
+ * and the Raw / RLE block arms                  framedecompressor.go:211-215,229-241.
+ *
+ * Division of labour (BASELINE.json north_star): the HOST keeps frame / block /
+ * section header parsing and FSE / Huffman table construction and describes a
+ * whole batch of independent frames with the flat, pointer-free arrays below;
+ * the DEVICE (hand-written HIP for gfx950) does Huffman literal decode, FSE
+ * sequence decode and sequence execution for every block of every frame.
+ *
+ * Two host-side producers of these descriptors exist:
+ *   - the library's own C++ planner (mzd_plan_*), which mirrors the reference's
+ *     Go host code and is what the tests / bench / Python mirror drive;
+ *   - the Go cgo shim sketched in INTEGRATION.md, which fills the same structs
+ *     from sparkzstd's own parsed Block / FSETable / HuffmanDecodingTable values.
+ *
+ * All structs are plain C, little-endian, naturally aligned, no pointers inside
+ * arrays (cgo-safe).  No torch types anywhere.  Thread-safety: one mzd_ctx per
+ * device, used by one host thread at a time; contexts are independent.
+ */
+#ifndef MZD_H
+#define MZD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZD_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status codes
+ * Per-frame status mirrors the reference's sentinel errors (file:line of the
+ * Go sentinel each replaces). 0 == success. */
+enum {
+    MZD_OK = 0,
+    MZD_ERR_TRUNCATED = 1,        /* io.ErrUnexpectedEOF from the reference's readers */
+    MZD_ERR_MAGIC = 2,            /* framedecompressor.go:128 ErrWrongMagicnumber */
+    MZD_ERR_BLOCK_TYPE = 3,       /* block.go:29 ErrIllegalBlockType */
+    MZD_ERR_BLOCK_SIZE = 4,       /* block.go:30 ErrIllegalBlockSize */
+    MZD_ERR_FSE_TABLE = 5,        /* fse.go:133 ErrDidntReadAllProbabilities (+ build panics :168,:188) */
+    MZD_ERR_HUF_WEIGHTS = 6,      /* huffman.go:109-110 ErrWrongSumOfWeights / ErrCorruptedHuffTree */
+    MZD_ERR_NO_PREV_TABLE = 7,    /* literals.go:206, sequences.go:271-273 */
+    MZD_ERR_BAD_PADDING = 8,      /* huffman.go:218 / fse.go:303 ErrBadPadding */
+    MZD_ERR_HUF_BITS = 9,         /* huffman.go:219 ErrDidntUseAllBitsToDecodeHuffman */
+    MZD_ERR_HUF_LENGTH = 10,      /* literals.go:207 ErrStreamDidntDecodeToRightLength */
+    MZD_ERR_SEQ_BITS = 11,        /* sequences.go:208 ErrNotAllBitsUsed */
+    MZD_ERR_CORRUPT_SIZES = 12,   /* framedecompressor.go:90 ErrCorruptSizes, literals.go:43-44 */
+    MZD_ERR_LITERALS = 13,        /* sequence_execution.go:11 ErrDidntCopyAllLiteralBytes */
+    MZD_ERR_OFFSET = 14,          /* ringbuffer.go:189 ErrCantRepeatBytes (offset beyond produced data / zero) */
+    MZD_ERR_DST_FULL = 15,        /* frame output exceeds out_capacity / content size mismatch */
+    MZD_ERR_UNSUPPORTED = 16,     /* outside the device path's documented limits */
+    MZD_ERR_OUT_OF_BLOCKS = 17,   /* framedecompressor.go:196 ErrOutOfBlocks (host mirror only) */
+    MZD_ERR_DEVICE = 100,         /* HIP runtime error; see mzd_last_error() */
+    MZD_ERR_INVALID_ARG = 101,
+    MZD_ERR_NO_DEVICE = 102       /* no HIP device: the product has NO CPU fallback */
+};
+
+/* ------------------------------------------------------------------ descriptors */
+
+enum { MZD_BLOCK_RAW = 0, MZD_BLOCK_RLE = 1, MZD_BLOCK_COMPRESSED = 2 }; /* block.go:15-20 */
+/* literals.go:22-27; Compressed and Treeless both arrive as MZD_LIT_HUF with the
+ * table already resolved by the host (Treeless = same huf_table index as before) */
+enum { MZD_LIT_RAW = 0, MZD_LIT_RLE = 1, MZD_LIT_HUF = 2 };
+
+#define MZD_NO_TABLE 0xFFFFFFFFu
+#define MZD_UNKNOWN_SIZE 0xFFFFFFFFFFFFFFFFull
+
+/* One frame = one independent unit (tables, offset history {1,4,8} and window
+ * are per frame: framedecompressor.go:42-52, ringbuffer.go:36-49). */
+typedef struct mzd_frame_desc {
+    uint32_t first_block;   /* index into blocks[] */
+    uint32_t n_blocks;
+    uint64_t out_offset;    /* byte offset of this frame's output slab in `out`; multiple of 16 */
+    uint64_t out_capacity;  /* bytes available at out_offset */
+    uint64_t content_size;  /* Frame_Content_Size, or MZD_UNKNOWN_SIZE (frame.go:49-61) */
+    uint64_t window_size;   /* frame.go:28-36 / framedecompressor.go:358-360; informational + limit check */
+} mzd_frame_desc;
+
+/* One block (block.go:22-26 BlockHeader + the slices the reference's section
+ * parsers produce: literals.go:30-41,283-361, sequences.go:371-433). Offsets are
+ * byte offsets into the input blob `in`. */
+typedef struct mzd_block_desc {
+    uint8_t type;            /* MZD_BLOCK_* */
+    uint8_t lit_type;        /* MZD_LIT_* (compressed blocks) */
+    uint8_t lit_streams;     /* 1 or 4 (MZD_LIT_HUF) */
+    uint8_t reserved0;
+    uint32_t size;           /* Raw/RLE: regenerated size (Block_Size). Compressed: Block_Size (informational) */
+    uint64_t src_off;        /* Raw: payload. RLE: the byte to repeat. */
+    uint64_t lit_off;        /* Raw literals: the bytes; RLE literals: the byte; HUF: first stream */
+    uint32_t lit_regen;      /* Regenerated_Size of the literals section */
+    uint32_t lit_stream_size[4]; /* HUF: compressed size of each stream (jump table + computed 4th) */
+    uint32_t huf_table;      /* index into huf_tables[] or MZD_NO_TABLE */
+    uint32_t n_seq;          /* Number_of_Sequences (0: block output == literals) */
+    uint32_t seq_size;       /* bytes of the sequence bitstream */
+    uint64_t seq_off;        /* sequence bitstream */
+    uint32_t ll_table, of_table, ml_table; /* indices into fse_tables[] */
+    uint32_t reserved1;
+} mzd_block_desc;
+
+/* FSE decode table cell == fse.go:10-15 FSETableEntry with the symbol kept
+ * UNtranslated; the device applies predefined.go:5-20,36-50 itself.  An RLE-mode
+ * table (sequences.go:27-62) is a 1-cell table with acc_log 0. */
+typedef struct mzd_fse_entry {
+    uint16_t baseline;  /* fse.go:11 Baseline */
+    uint8_t nbits;      /* fse.go:13 NumberOfBits */
+    uint8_t symbol;     /* literal-length / match-length / offset CODE */
+} mzd_fse_entry;
+
+enum { MZD_FSE_LL = 0, MZD_FSE_OF = 1, MZD_FSE_ML = 2 };
+
+typedef struct mzd_fse_table_desc {
+    uint32_t entries_off;  /* first cell in fse_entries[] */
+    uint8_t acc_log;       /* table has 1<<acc_log cells; 0 == RLE mode */
+    uint8_t kind;          /* MZD_FSE_* */
+    uint16_t reserved;
+} mzd_fse_table_desc;
+
+/* Huffman decode table cell == huffman.go:30-37 (Symbols[j], NumberOfBits[j]),
+ * flat table of 1<<max_bits cells in the reference's fill order (huffman.go:163-187). */
+typedef struct mzd_huf_entry {
+    uint8_t symbol;
+    uint8_t nbits;
+} mzd_huf_entry;
+
+typedef struct mzd_huf_table_desc {
+    uint32_t entries_off;  /* first cell in huf_entries[]; even */
+    uint32_t max_bits;     /* 1..11 */
+} mzd_huf_table_desc;
+
+#define MZD_IN_PAD 64 /* readable slack required before and after `in` when it is a device pointer */
+
+enum {
+    MZD_BATCH_IN_ON_DEVICE = 1u << 0,  /* `in` is a device pointer (with MZD_IN_PAD slack both sides) */
+    MZD_BATCH_OUT_ON_DEVICE = 1u << 1  /* `out` is a device pointer */
+};
+
+/* A batch of independent frames. Descriptor arrays are always HOST memory. */
+typedef struct mzd_batch {
+    uint32_t abi_version;  /* MZD_ABI_VERSION */
+    uint32_t flags;        /* MZD_BATCH_* */
+    const uint8_t *in;     /* concatenated compressed payloads (whole frames or just the sections) */
+    uint64_t in_size;
+    uint8_t *out;          /* output blob; may be NULL for upload (library allocates on device) */
+    uint64_t out_size;
+    const mzd_frame_desc *frames;
+    uint32_t n_frames;
+    const mzd_block_desc *blocks;
+    uint32_t n_blocks;
+    const mzd_fse_table_desc *fse_tables;
+    uint32_t n_fse_tables;
+    const mzd_fse_entry *fse_entries;
+    uint32_t n_fse_entries;
+    const mzd_huf_table_desc *huf_tables;
+    uint32_t n_huf_tables;
+    const mzd_huf_entry *huf_entries;
+    uint32_t n_huf_entries;
+} mzd_batch;
+
+/* ------------------------------------------------------------------ library */
+
+typedef struct mzd_ctx mzd_ctx;       /* one per device */
+typedef struct mzd_dbatch mzd_dbatch; /* a batch resident in HBM */
+typedef struct mzd_plan mzd_plan;     /* host planner state */
+
+int mzd_abi_version(void);
+/* "hip-gfx950". There is no CPU backend. */
+const char *mzd_backend(void);
+const char *mzd_strerror(int code);
+/* number of HIP devices, 0 if none / runtime unavailable */
+int mzd_device_count(void);
+
+/* Tuning knobs (0 == default). */
+typedef struct mzd_options {
+    uint32_t seq_variant;     /* sequence-decode kernel variant, see DESIGN.md */
+    uint32_t exec_threads;    /* threads per frame in the execution kernel (multiple of 64) */
+    uint32_t reserved[6];
+} mzd_options;
+
+mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);
+void mzd_destroy(mzd_ctx *ctx);
+const char *mzd_last_error(mzd_ctx *ctx);
+
+/* Make a batch resident: copies (or adopts, per flags) the input blob, uploads
+ * descriptors and tables, derives the per-kernel work lists, allocates scratch
+ * (literal buffer, sequence records) and, if batch->out is NULL or host memory, the
+ * device output blob.  Replaces nothing in the reference (which has no device). */
+int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *batch, mzd_dbatch **out);
+/* The hot path: launches the kernels for every frame of the batch on `stream`
+ * (a hipStream_t, or NULL for the context's stream). Asynchronous.
+ * Replaces huffman.go:221, sequences.go:126, sequence_execution.go:14 and the
+ * Raw/RLE arms of framedecompressor.go:198-244 for all frames at once. */
+int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream);
+/* Blocks until the context's work is done (the cgo call returns after this). */
+int mzd_sync(mzd_ctx *ctx);
+/* Copies results back. Any pointer may be NULL. `out_host` receives the whole
+ * output blob (out_size bytes). status/out_len have n_frames entries. */
+int mzd_batch_download(mzd_ctx *ctx, mzd_dbatch *db, uint8_t *out_host, int32_t *status,
+                       uint64_t *out_len);
+/* Device pointers of the resident batch (for callers that keep results in HBM). */
+void *mzd_batch_device_out(mzd_dbatch *db);
+void *mzd_batch_device_status(mzd_dbatch *db);
+void *mzd_batch_device_out_len(mzd_dbatch *db);
+void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db);
+
+/* upload + run + sync + download + free: the single synchronous call a
+ * FrameDecompressor.DecodeNextBlock-level shim makes. Returns 0 or the first
+ * non-zero frame status. */
+int mzd_decode_batch(mzd_ctx *ctx, const mzd_batch *batch, int32_t *status, uint64_t *out_len);
+
+/* Per-kernel timing of the last mzd_batch_run (HIP events recorded on the launch
+ * stream). Call after mzd_sync. names/ms arrays of capacity `cap`; returns the
+ * number of kernels. */
+int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap);
+/* Byte counts of the resident batch for roofline accounting. */
+typedef struct mzd_batch_stats {
+    uint64_t compressed_bytes;    /* sum over blocks of the bytes the kernels must read (C) */
+    uint64_t table_bytes;         /* FSE + Huffman table cells shipped to the device */
+    uint64_t scratch_bytes;       /* literal buffer + sequence records (implementation traffic) */
+    uint64_t out_capacity_bytes;
+    uint64_t n_sequences;
+    uint64_t n_huf_streams;
+    uint64_t n_blocks[3];         /* raw, rle, compressed */
+} mzd_batch_stats;
+int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st);
+
+/* ------------------------------------------------------------------ host planner
+ * C++ restatement of the reference's host side, exposed in C so that tests, the
+ * bench and the Python mirror can drive the device without Go:
+ *   frame header        structure/frame.go:23-127, framedecompressor.go:130-150,306-374
+ *   block header        structure/block.go:33-55
+ *   literals header     structure/literals.go:67-289 (+ jump table :46-62)
+ *   huffman tree        structure/huffman.go:40-190 (+ fse.go:307-390 for the weights)
+ *   sequences header    structure/sequences.go:228-450
+ *   FSE tables          fse/fse.go:28-230, fse/predefined.go
+ *   table carry-over    framedecompressor.go:283-294 (Repeat / Treeless) */
+mzd_plan *mzd_plan_create(void);
+void mzd_plan_destroy(mzd_plan *p);
+void mzd_plan_reset(mzd_plan *p);
+/* Parses one frame starting at `frame` (magic number first) and appends it to the
+ * plan.  The frame's bytes are copied into the plan's input blob.  *consumed =
+ * bytes used up to and including the last block (the 4-byte content checksum is
+ * never read: SURVEY quirk 4).  Returns MZD_OK or the parse error; a failed frame
+ * is still appended (zero blocks) so that indices stay aligned, with the error as
+ * its planning status. */
+int mzd_plan_add_frame(mzd_plan *p, const uint8_t *frame, uint64_t len, uint64_t *consumed);
+/* Many frames, parsed on `n_threads` host threads (0 = hardware concurrency). */
+int mzd_plan_add_frames(mzd_plan *p, const uint8_t *blob, const uint64_t *frame_off,
+                        const uint64_t *frame_len, uint32_t n_frames, uint32_t n_threads);
+/* Lays out the output slabs (content size when known, else n_blocks * 128 KiB),
+ * finalises the batch view.  The returned pointer stays valid until the plan is
+ * modified or destroyed. */
+const mzd_batch *mzd_plan_finalize(mzd_plan *p);
+/* planning status of frame i (MZD_OK if it parsed) */
+int mzd_plan_frame_status(const mzd_plan *p, uint32_t i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

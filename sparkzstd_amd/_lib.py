@@ -1,0 +1,133 @@
+"""ctypes loader for libmzd.so (the C-ABI of include/mzd.h).  Fails loudly: there is no
+Python or CPU fallback for the hot path."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmzd.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+
+MZD_ABI_VERSION = 1
+MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
+MZD_IN_PAD = 64
+MZD_BATCH_IN_ON_DEVICE = 1
+MZD_BATCH_OUT_ON_DEVICE = 2
+
+# every symbol include/mzd.h declares (tests/test_abi.py checks the export list against the header)
+EXPORTS = [
+    "mzd_abi_version", "mzd_backend", "mzd_strerror", "mzd_device_count", "mzd_create", "mzd_destroy",
+    "mzd_last_error", "mzd_batch_upload", "mzd_batch_run", "mzd_sync", "mzd_batch_download",
+    "mzd_batch_device_out", "mzd_batch_device_status", "mzd_batch_device_out_len", "mzd_batch_free",
+    "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_batch_get_stats", "mzd_plan_create",
+    "mzd_plan_destroy", "mzd_plan_reset", "mzd_plan_add_frame", "mzd_plan_add_frames",
+    "mzd_plan_finalize", "mzd_plan_frame_status",
+]
+
+
+class FrameDesc(ctypes.Structure):
+    _fields_ = [("first_block", ctypes.c_uint32), ("n_blocks", ctypes.c_uint32),
+                ("out_offset", ctypes.c_uint64), ("out_capacity", ctypes.c_uint64),
+                ("content_size", ctypes.c_uint64), ("window_size", ctypes.c_uint64)]
+
+
+class BlockDesc(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_uint8), ("lit_type", ctypes.c_uint8), ("lit_streams", ctypes.c_uint8),
+                ("reserved0", ctypes.c_uint8), ("size", ctypes.c_uint32), ("src_off", ctypes.c_uint64),
+                ("lit_off", ctypes.c_uint64), ("lit_regen", ctypes.c_uint32),
+                ("lit_stream_size", ctypes.c_uint32 * 4), ("huf_table", ctypes.c_uint32),
+                ("n_seq", ctypes.c_uint32), ("seq_size", ctypes.c_uint32), ("seq_off", ctypes.c_uint64),
+                ("ll_table", ctypes.c_uint32), ("of_table", ctypes.c_uint32), ("ml_table", ctypes.c_uint32),
+                ("reserved1", ctypes.c_uint32)]
+
+
+class FseEntry(ctypes.Structure):
+    _fields_ = [("baseline", ctypes.c_uint16), ("nbits", ctypes.c_uint8), ("symbol", ctypes.c_uint8)]
+
+
+class FseTableDesc(ctypes.Structure):
+    _fields_ = [("entries_off", ctypes.c_uint32), ("acc_log", ctypes.c_uint8), ("kind", ctypes.c_uint8),
+                ("reserved", ctypes.c_uint16)]
+
+
+class HufEntry(ctypes.Structure):
+    _fields_ = [("symbol", ctypes.c_uint8), ("nbits", ctypes.c_uint8)]
+
+
+class HufTableDesc(ctypes.Structure):
+    _fields_ = [("entries_off", ctypes.c_uint32), ("max_bits", ctypes.c_uint32)]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("in_", ctypes.c_void_p), ("in_size", ctypes.c_uint64),
+                ("out", ctypes.c_void_p), ("out_size", ctypes.c_uint64),
+                ("frames", ctypes.POINTER(FrameDesc)), ("n_frames", ctypes.c_uint32),
+                ("blocks", ctypes.POINTER(BlockDesc)), ("n_blocks", ctypes.c_uint32),
+                ("fse_tables", ctypes.POINTER(FseTableDesc)), ("n_fse_tables", ctypes.c_uint32),
+                ("fse_entries", ctypes.POINTER(FseEntry)), ("n_fse_entries", ctypes.c_uint32),
+                ("huf_tables", ctypes.POINTER(HufTableDesc)), ("n_huf_tables", ctypes.c_uint32),
+                ("huf_entries", ctypes.POINTER(HufEntry)), ("n_huf_entries", ctypes.c_uint32)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("seq_variant", ctypes.c_uint32), ("exec_threads", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 6)]
+
+
+class BatchStats(ctypes.Structure):
+    _fields_ = [("compressed_bytes", ctypes.c_uint64), ("table_bytes", ctypes.c_uint64),
+                ("scratch_bytes", ctypes.c_uint64), ("out_capacity_bytes", ctypes.c_uint64),
+                ("n_sequences", ctypes.c_uint64), ("n_huf_streams", ctypes.c_uint64),
+                ("n_blocks", ctypes.c_uint64 * 3)]
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if libmzd.so is missing (build it: python -c
+    'import __graft_entry__ as g; g.build()' or make -C sparkzstd_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: the sparkzstd_amd hot path is HIP only, "
+                          "there is no fallback. Run `make -C sparkzstd_amd/csrc`.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, u32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+    sig = {
+        "mzd_abi_version": (i32, []),
+        "mzd_backend": (ctypes.c_char_p, []),
+        "mzd_strerror": (ctypes.c_char_p, [i32]),
+        "mzd_device_count": (i32, []),
+        "mzd_create": (vp, [i32, ctypes.POINTER(Options), ctypes.POINTER(i32)]),
+        "mzd_destroy": (None, [vp]),
+        "mzd_last_error": (ctypes.c_char_p, [vp]),
+        "mzd_batch_upload": (i32, [vp, ctypes.POINTER(Batch), ctypes.POINTER(vp)]),
+        "mzd_batch_run": (i32, [vp, vp, vp]),
+        "mzd_sync": (i32, [vp]),
+        "mzd_batch_download": (i32, [vp, vp, vp, vp, vp]),
+        "mzd_batch_device_out": (vp, [vp]),
+        "mzd_batch_device_status": (vp, [vp]),
+        "mzd_batch_device_out_len": (vp, [vp]),
+        "mzd_batch_free": (None, [vp, vp]),
+        "mzd_decode_batch": (i32, [vp, ctypes.POINTER(Batch), vp, vp]),
+        "mzd_last_run_kernel_ms": (i32, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]),
+        "mzd_batch_get_stats": (i32, [vp, ctypes.POINTER(BatchStats)]),
+        "mzd_plan_create": (vp, []),
+        "mzd_plan_destroy": (None, [vp]),
+        "mzd_plan_reset": (None, [vp]),
+        "mzd_plan_add_frame": (i32, [vp, vp, u64, ctypes.POINTER(u64)]),
+        "mzd_plan_add_frames": (i32, [vp, vp, vp, vp, u32, u32]),
+        "mzd_plan_finalize": (ctypes.POINTER(Batch), [vp]),
+        "mzd_plan_frame_status": (i32, [vp, u32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.mzd_abi_version() != MZD_ABI_VERSION:
+        raise ImportError("libmzd.so ABI version mismatch")
+    _lib = L
+    return L

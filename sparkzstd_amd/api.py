@@ -1,0 +1,215 @@
+"""Batch-level host API over the C-ABI: Plan (host planner), Context (one per GPU),
+ResidentBatch (a batch in HBM), decode_frames()."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Batch, BatchStats, Options
+
+
+class MzdError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = _lib.load().mzd_strerror(code).decode()
+        super().__init__(f"{where}: {msg} (code {code})" if where else f"{msg} (code {code})")
+
+
+def strerror(code: int) -> str:
+    return _lib.load().mzd_strerror(code).decode()
+
+
+class Plan:
+    """Host planner: parses frames, builds FSE/Huffman tables, emits the descriptors of mzd.h.
+    Mirrors what sparkzstd's Go host code keeps doing (frame.go, block.go, literals.go:67-289,
+    sequences.go:228-450, huffman.go:40-190, fse.go:28-230)."""
+
+    def __init__(self):
+        self._L = _lib.load()
+        self._p = self._L.mzd_plan_create()
+        self._keep = []
+        self._batch = None
+
+    def close(self):
+        if self._p:
+            self._L.mzd_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()
+
+    def add_frame(self, frame: bytes):
+        """-> (status, consumed)"""
+        consumed = ctypes.c_uint64()
+        buf = (ctypes.c_uint8 * len(frame)).from_buffer_copy(frame) if len(frame) else (ctypes.c_uint8 * 1)()
+        rc = self._L.mzd_plan_add_frame(self._p, ctypes.addressof(buf), len(frame), ctypes.byref(consumed))
+        self._batch = None
+        return rc, consumed.value
+
+    def add_frames(self, blob: np.ndarray, offs: np.ndarray, lens: np.ndarray, threads: int = 0):
+        """Adopts `blob` (uint8 array, kept alive) and parses frames [offs[i], offs[i]+lens[i])."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        self._keep += [blob, offs, lens]
+        self._batch = None
+        return self._L.mzd_plan_add_frames(self._p, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                           len(offs), threads)
+
+    def finalize(self) -> Batch:
+        bp = self._L.mzd_plan_finalize(self._p)
+        self._batch = bp.contents
+        return self._batch
+
+    def frame_status(self, i: int) -> int:
+        return self._L.mzd_plan_frame_status(self._p, i)
+
+
+class ResidentBatch:
+    def __init__(self, ctx, handle, batch: Batch):
+        self.ctx = ctx
+        self._h = handle
+        self.n_frames = batch.n_frames
+        self.out_size = batch.out_size
+        self.frame_out_offset = np.array([batch.frames[i].out_offset for i in range(batch.n_frames)], dtype=np.uint64) \
+            if batch.n_frames <= 4096 else None
+        self._batch = batch
+
+    def run(self, stream=None):
+        rc = self.ctx._L.mzd_batch_run(self.ctx._c, self._h, stream)
+        if rc:
+            raise MzdError(rc, "mzd_batch_run: " + self.ctx.last_error())
+
+    def download(self, want_out=True):
+        """-> (out blob as np.uint8 array or None, status int32[n], out_len uint64[n])"""
+        out = np.empty(self.out_size, dtype=np.uint8) if want_out else None
+        status = np.empty(self.n_frames, dtype=np.int32)
+        out_len = np.empty(self.n_frames, dtype=np.uint64)
+        rc = self.ctx._L.mzd_batch_download(self.ctx._c, self._h, out.ctypes.data if want_out and self.out_size else None,
+                                            status.ctypes.data if self.n_frames else None,
+                                            out_len.ctypes.data if self.n_frames else None)
+        if rc:
+            raise MzdError(rc, "mzd_batch_download: " + self.ctx.last_error())
+        return out, status, out_len
+
+    def device_out_ptr(self):
+        return self.ctx._L.mzd_batch_device_out(self._h)
+
+    def device_status_ptr(self):
+        return self.ctx._L.mzd_batch_device_status(self._h)
+
+    def device_out_len_ptr(self):
+        return self.ctx._L.mzd_batch_device_out_len(self._h)
+
+    def stats(self) -> BatchStats:
+        st = BatchStats()
+        self.ctx._L.mzd_batch_get_stats(self._h, ctypes.byref(st))
+        return st
+
+    def free(self):
+        if self._h:
+            self.ctx._L.mzd_batch_free(self.ctx._c, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU (mzd_ctx). Raises if no HIP device: there is no CPU path."""
+
+    def __init__(self, device: int = 0, seq_variant: int = 0, exec_threads: int = 0):
+        self._L = _lib.load()
+        opt = Options()
+        opt.seq_variant = seq_variant
+        opt.exec_threads = exec_threads
+        err = ctypes.c_int()
+        self._c = self._L.mzd_create(device, ctypes.byref(opt), ctypes.byref(err))
+        if not self._c:
+            raise MzdError(err.value, "mzd_create")
+
+    def last_error(self) -> str:
+        return self._L.mzd_last_error(self._c).decode()
+
+    def upload(self, batch: Batch, device_in_ptr=None, device_out_ptr=None) -> ResidentBatch:
+        """device_in_ptr / device_out_ptr: raw device addresses (e.g. torch tensor .data_ptr())
+        that replace batch.in / batch.out; the input must carry MZD_IN_PAD bytes of slack."""
+        b = Batch()
+        ctypes.memmove(ctypes.byref(b), ctypes.byref(batch), ctypes.sizeof(Batch))
+        if device_in_ptr is not None:
+            b.in_ = device_in_ptr
+            b.flags |= _lib.MZD_BATCH_IN_ON_DEVICE
+        if device_out_ptr is not None:
+            b.out = device_out_ptr
+            b.flags |= _lib.MZD_BATCH_OUT_ON_DEVICE
+        h = ctypes.c_void_p()
+        rc = self._L.mzd_batch_upload(self._c, ctypes.byref(b), ctypes.byref(h))
+        if rc:
+            raise MzdError(rc, "mzd_batch_upload: " + self.last_error())
+        return ResidentBatch(self, h, batch)
+
+    def sync(self):
+        rc = self._L.mzd_sync(self._c)
+        if rc:
+            raise MzdError(rc, "mzd_sync: " + self.last_error())
+
+    def kernel_ms(self):
+        names = (ctypes.c_char_p * 8)()
+        ms = (ctypes.c_float * 8)()
+        n = self._L.mzd_last_run_kernel_ms(self._c, names, ms, 8)
+        return {names[i].decode(): ms[i] for i in range(n)}
+
+    def close(self):
+        if self._c:
+            self._L.mzd_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def decode_frames(frames, ctx: Context = None):
+    """Decodes independent zstd frames (list of bytes) in ONE device batch.
+    -> (outputs: list of bytes-or-None, statuses: list of int).  The batched analogue of calling
+    sparkzstd's FrameDecompressor.Decompress() (framedecompressor.go:153) once per frame."""
+    ctx = ctx or default_context()
+    plan = Plan()
+    try:
+        plan_status = []
+        for f in frames:
+            rc, _ = plan.add_frame(bytes(f))
+            plan_status.append(rc)
+        batch = plan.finalize()
+        rb = ctx.upload(batch)
+        try:
+            rb.run()
+            out, status, out_len = rb.download()
+        finally:
+            rb.free()
+        outs, sts = [], []
+        for i in range(len(frames)):
+            st = plan_status[i] or int(status[i])
+            sts.append(st)
+            if st == 0:
+                o = int(batch.frames[i].out_offset)
+                outs.append(out[o:o + int(out_len[i])].tobytes())
+            else:
+                outs.append(None)
+        return outs, sts
+    finally:
+        plan.close()

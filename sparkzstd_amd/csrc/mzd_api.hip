@@ -1,0 +1,534 @@
+// mzd_api.hip -- C-ABI implementation (include/mzd.h): context, batch residency, kernel
+// launches, result download.  Host code; compiled with hipcc together with the kernels.
+//
+// There is NO CPU fallback: without a HIP device mzd_create fails with MZD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mzd.h"
+#include "mzd_device.h"
+
+// unity build: the kernels live in their own file but are compiled in this translation unit
+#include "mzd_kernels.hip"
+
+using namespace mzd;
+
+struct mzd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mzd_options opt{};
+    std::string last_error;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    bool attr_set = false;
+};
+
+struct mzd_dbatch {
+    // device memory
+    uint8_t *d_in_alloc = nullptr;  // owned input allocation (with padding) or null when adopted
+    const uint8_t *d_in = nullptr;
+    uint8_t *d_out = nullptr;
+    bool own_out = false;
+    DFrame *d_frames = nullptr;
+    DBlock *d_blocks = nullptr;
+    BlockSum *d_sums = nullptr;
+    HufTask *d_huf_tasks = nullptr;
+    SeqTask *d_seq_tasks = nullptr;
+    uint32_t *d_fse_entries = nullptr;
+    uint16_t *d_huf_entries = nullptr;
+    uint64_t *d_recs = nullptr;
+    TileBase *d_tiles = nullptr;
+    uint8_t *d_litbuf = nullptr;
+    int32_t *d_status = nullptr;
+    uint64_t *d_out_len = nullptr;
+    // geometry
+    uint32_t n_frames = 0, n_blocks = 0, n_huf_tasks = 0, n_seq_tasks = 0;
+    uint32_t huf_slot_cells = 2;
+    uint64_t out_size = 0;
+    mzd_batch_stats stats{};
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            char buf_[256];                                                                   \
+            snprintf(buf_, sizeof buf_, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+            (ctx)->last_error = buf_;                                                         \
+            return MZD_ERR_DEVICE;                                                            \
+        }                                                                                     \
+    } while (0)
+
+template <class T>
+int upload_vec(mzd_ctx *ctx, const std::vector<T> &v, T **dptr)
+{
+    *dptr = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc((void **)dptr, bytes));
+    if (!v.empty()) HIP_TRY(ctx, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MZD_OK;
+}
+
+const int kMaxSym[3] = {35, 31, 52};  // LL, OF, ML (predefined.go table lengths - 1)
+const int kMaxLog[3] = {9, 8, 9};
+
+}  // namespace
+
+extern "C" {
+
+int mzd_abi_version(void) { return MZD_ABI_VERSION; }
+const char *mzd_backend(void) { return "hip-gfx950"; }
+
+const char *mzd_strerror(int code)
+{
+    switch (code) {
+    case MZD_OK: return "ok";
+    case MZD_ERR_TRUNCATED: return "unexpected end of input";
+    case MZD_ERR_MAGIC: return "Magicnum is not correct";
+    case MZD_ERR_BLOCK_TYPE: return "Illegal BlockType. Must be smaller than 3.";
+    case MZD_ERR_BLOCK_SIZE: return "Illegal block-size. Must be lower than 128kb";
+    case MZD_ERR_FSE_TABLE: return "The probabilities didnt add up to the expected total sum";
+    case MZD_ERR_HUF_WEIGHTS: return "The weights didnt leave a power of two for the last weight";
+    case MZD_ERR_NO_PREV_TABLE: return "No previous table available to carry over";
+    case MZD_ERR_BAD_PADDING: return "The padding at the end of the stream was more than a byte";
+    case MZD_ERR_HUF_BITS: return "Didnt read all bits to decode huffman stream";
+    case MZD_ERR_HUF_LENGTH: return "Huffstream did not decode to the correct length";
+    case MZD_ERR_SEQ_BITS: return "Did not read all bits to decode sequences";
+    case MZD_ERR_CORRUPT_SIZES: return "The sizes of literal and sequence section did not add up to blocksize";
+    case MZD_ERR_LITERALS: return "Not enough bytes read to execute literals copy";
+    case MZD_ERR_OFFSET: return "You cant repeat bytes from before the first one";
+    case MZD_ERR_DST_FULL: return "frame output does not fit its slab / content size mismatch";
+    case MZD_ERR_UNSUPPORTED: return "outside the device path's limits";
+    case MZD_ERR_OUT_OF_BLOCKS: return "No blocks left in frame";
+    case MZD_ERR_DEVICE: return "HIP runtime error";
+    case MZD_ERR_INVALID_ARG: return "invalid argument";
+    case MZD_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    default: return "unknown error";
+    }
+}
+
+int mzd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err)
+{
+    int n = mzd_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        if (err) *err = n <= 0 ? MZD_ERR_NO_DEVICE : MZD_ERR_INVALID_ARG;
+        return nullptr;
+    }
+    mzd_ctx *c = new mzd_ctx();
+    c->device = device;
+    if (opt) c->opt = *opt;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        if (err) *err = MZD_ERR_DEVICE;
+        delete c;
+        return nullptr;
+    }
+    for (auto &e : c->ev) (void)hipEventCreate(&e);
+    if (err) *err = MZD_OK;
+    return c;
+}
+
+void mzd_destroy(mzd_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mzd_last_error(mzd_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
+{
+    if (!db) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipFree(db->d_in_alloc);
+    if (db->own_out) (void)hipFree(db->d_out);
+    (void)hipFree(db->d_frames);
+    (void)hipFree(db->d_blocks);
+    (void)hipFree(db->d_sums);
+    (void)hipFree(db->d_huf_tasks);
+    (void)hipFree(db->d_seq_tasks);
+    (void)hipFree(db->d_fse_entries);
+    (void)hipFree(db->d_huf_entries);
+    (void)hipFree(db->d_recs);
+    (void)hipFree(db->d_tiles);
+    (void)hipFree(db->d_litbuf);
+    (void)hipFree(db->d_status);
+    (void)hipFree(db->d_out_len);
+    delete db;
+}
+
+int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
+{
+    if (!ctx || !b || !out) return MZD_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (b->abi_version != MZD_ABI_VERSION) {
+        ctx->last_error = "abi_version mismatch";
+        return MZD_ERR_INVALID_ARG;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- validate tables once per table
+    std::vector<uint8_t> fse_ok(b->n_fse_tables, 1), huf_ok(b->n_huf_tables, 1);
+    for (uint32_t i = 0; i < b->n_fse_tables; i++) {
+        const mzd_fse_table_desc &d = b->fse_tables[i];
+        const uint64_t n = 1ull << d.acc_log;
+        if (d.kind > 2 || d.acc_log > kMaxLog[d.kind] || (uint64_t)d.entries_off + n > b->n_fse_entries) {
+            fse_ok[i] = 0;
+            continue;
+        }
+        for (uint64_t j = 0; j < n; j++) {
+            const mzd_fse_entry &e = b->fse_entries[d.entries_off + j];
+            if (e.symbol > kMaxSym[d.kind] || e.nbits > d.acc_log || (uint32_t)e.baseline + (1u << e.nbits) > n) {
+                fse_ok[i] = 0;
+                break;
+            }
+        }
+    }
+    uint32_t max_huf_bits = 1;
+    for (uint32_t i = 0; i < b->n_huf_tables; i++) {
+        const mzd_huf_table_desc &d = b->huf_tables[i];
+        if (d.max_bits < 1 || d.max_bits > 11 || (d.entries_off & 1) ||
+            (uint64_t)d.entries_off + (1ull << d.max_bits) > b->n_huf_entries) {
+            huf_ok[i] = 0;
+            continue;
+        }
+        const uint32_t n = 1u << d.max_bits;
+        for (uint32_t j = 0; j < n; j++) {
+            const mzd_huf_entry &e = b->huf_entries[d.entries_off + j];
+            if (e.nbits < 1 || e.nbits > d.max_bits) {
+                huf_ok[i] = 0;
+                break;
+            }
+        }
+        if (huf_ok[i]) max_huf_bits = std::max(max_huf_bits, d.max_bits);
+    }
+
+    // ---- derive the device work lists
+    std::vector<DFrame> frames(b->n_frames);
+    std::vector<DBlock> blocks(b->n_blocks);
+    std::vector<HufTask> huf_tasks;
+    std::vector<SeqTask> seq_tasks;
+    uint64_t rec_total = 0, tile_total = 0, lit_total = 0;
+    mzd_batch_stats st{};
+    auto in_range = [&](uint64_t off, uint64_t n) { return off <= b->in_size && n <= b->in_size - off; };
+    for (uint32_t f = 0; f < b->n_frames; f++) {
+        const mzd_frame_desc &fd = b->frames[f];
+        DFrame &df = frames[f];
+        df.out_offset = fd.out_offset;
+        df.out_capacity = fd.out_capacity;
+        df.content_size = fd.content_size;
+        df.first_block = fd.first_block;
+        df.n_blocks = fd.n_blocks;
+        df.plan_status = MZD_OK;
+        df.pad = 0;
+        if ((uint64_t)fd.first_block + fd.n_blocks > b->n_blocks || (fd.out_offset & 15) ||
+            fd.out_offset > b->out_size || fd.out_capacity > b->out_size - fd.out_offset) {
+            df.plan_status = MZD_ERR_INVALID_ARG;
+            df.n_blocks = 0;
+            continue;
+        }
+        st.out_capacity_bytes += fd.out_capacity;
+        bool seen_seq = false;
+        for (uint32_t k = 0; k < fd.n_blocks && df.plan_status == MZD_OK; k++) {
+            const uint32_t bi = fd.first_block + k;
+            const mzd_block_desc &bd = b->blocks[bi];
+            DBlock &d = blocks[bi];
+            memset(&d, 0, sizeof d);
+            d.type = bd.type;
+            d.size = bd.size;
+            if (bd.type == MZD_BLOCK_RAW || bd.type == MZD_BLOCK_RLE) {
+                const uint64_t need = bd.type == MZD_BLOCK_RAW ? bd.size : 1;
+                if (bd.size > kBlockMax || !in_range(bd.src_off, need)) { df.plan_status = MZD_ERR_TRUNCATED; break; }
+                d.src_off = bd.src_off;
+                st.compressed_bytes += need;
+                st.n_blocks[bd.type]++;
+                continue;
+            }
+            if (bd.type != MZD_BLOCK_COMPRESSED) { df.plan_status = MZD_ERR_BLOCK_TYPE; break; }
+            st.n_blocks[2]++;
+            d.lit_type = bd.lit_type;
+            d.lit_regen = bd.lit_regen;
+            if (bd.lit_regen > kBlockMax) { df.plan_status = MZD_ERR_CORRUPT_SIZES; break; }
+            if (bd.lit_type == MZD_LIT_RAW) {
+                if (!in_range(bd.lit_off, bd.lit_regen)) { df.plan_status = MZD_ERR_TRUNCATED; break; }
+                d.lit_src = bd.lit_off;
+                st.compressed_bytes += bd.lit_regen;
+            } else if (bd.lit_type == MZD_LIT_RLE) {
+                if (!in_range(bd.lit_off, 1)) { df.plan_status = MZD_ERR_TRUNCATED; break; }
+                d.lit_src = bd.lit_off;
+                st.compressed_bytes += 1;
+            } else if (bd.lit_type == MZD_LIT_HUF) {
+                if (bd.huf_table >= b->n_huf_tables) { df.plan_status = MZD_ERR_NO_PREV_TABLE; break; }
+                if (!huf_ok[bd.huf_table]) { df.plan_status = MZD_ERR_HUF_WEIGHTS; break; }
+                const mzd_huf_table_desc &ht = b->huf_tables[bd.huf_table];
+                const int ns = bd.lit_streams == 4 ? 4 : 1;
+                uint64_t csum = 0;
+                for (int s = 0; s < ns; s++) csum += bd.lit_stream_size[s];
+                if (!in_range(bd.lit_off, csum)) { df.plan_status = MZD_ERR_TRUNCATED; break; }
+                const uint32_t normal = ns == 4 ? (bd.lit_regen + 3) / 4 : bd.lit_regen;  // literals.go:306-307
+                if (ns == 4 && 3ull * normal > bd.lit_regen) { df.plan_status = MZD_ERR_HUF_LENGTH; break; }
+                d.lit_src = lit_total;
+                uint64_t ioff = bd.lit_off;
+                for (int s = 0; s < 4; s++) {
+                    HufTask t{};
+                    if (s < ns) {
+                        t.in_off = ioff;
+                        t.in_size = bd.lit_stream_size[s];
+                        t.out_off = lit_total + (uint64_t)s * normal;
+                        t.out_size = ns == 4 ? (s < 3 ? normal : bd.lit_regen - 3 * normal) : bd.lit_regen;
+                        ioff += t.in_size;
+                        st.n_huf_streams++;
+                    }
+                    t.table_off = ht.entries_off;
+                    t.max_bits = ht.max_bits;
+                    t.block = bi;
+                    huf_tasks.push_back(t);
+                }
+                lit_total += ((uint64_t)bd.lit_regen + 15) & ~15ull;
+                st.compressed_bytes += csum;
+            } else {
+                df.plan_status = MZD_ERR_INVALID_ARG;
+                break;
+            }
+            d.n_seq = bd.n_seq;
+            if (bd.n_seq > 0) {
+                const uint32_t ti[3] = {bd.ll_table, bd.of_table, bd.ml_table};
+                bool ok = true;
+                for (int kd = 0; kd < 3; kd++)
+                    ok = ok && ti[kd] < b->n_fse_tables && fse_ok[ti[kd]] && b->fse_tables[ti[kd]].kind == kd;
+                if (!ok) { df.plan_status = MZD_ERR_FSE_TABLE; break; }
+                if (bd.seq_size == 0 || bd.seq_size > kBlockMax || !in_range(bd.seq_off, bd.seq_size)) {
+                    df.plan_status = MZD_ERR_TRUNCATED;
+                    break;
+                }
+                SeqTask t{};
+                t.in_off = bd.seq_off;
+                t.in_size = bd.seq_size;
+                t.n_seq = bd.n_seq;
+                t.rec_off = rec_total;
+                t.tile_off = (uint32_t)tile_total;
+                t.block = bi;
+                t.ll_off = b->fse_tables[bd.ll_table].entries_off;
+                t.of_off = b->fse_tables[bd.of_table].entries_off;
+                t.ml_off = b->fse_tables[bd.ml_table].entries_off;
+                t.ll_log = b->fse_tables[bd.ll_table].acc_log;
+                t.of_log = b->fse_tables[bd.of_table].acc_log;
+                t.ml_log = b->fse_tables[bd.ml_table].acc_log;
+                t.hist_known = seen_seq ? 0 : 1;
+                seen_seq = true;
+                seq_tasks.push_back(t);
+                d.rec_off = rec_total;
+                d.tile_off = (uint32_t)tile_total;
+                rec_total += bd.n_seq;
+                tile_total += (bd.n_seq + 63) / 64;
+                if (tile_total > 0xFFFFFFFFull) { df.plan_status = MZD_ERR_UNSUPPORTED; break; }
+                st.compressed_bytes += bd.seq_size;
+                st.n_sequences += bd.n_seq;
+            }
+        }
+        if (df.plan_status != MZD_OK) df.n_blocks = 0;
+    }
+    st.table_bytes = (uint64_t)b->n_fse_entries * 4 + (uint64_t)b->n_huf_entries * 2;
+    st.scratch_bytes = rec_total * 8 + tile_total * 8 + lit_total;
+
+    // ---- device memory
+    mzd_dbatch *db = new mzd_dbatch();
+    db->n_frames = b->n_frames;
+    db->n_blocks = b->n_blocks;
+    db->n_huf_tasks = (uint32_t)huf_tasks.size();
+    db->n_seq_tasks = (uint32_t)seq_tasks.size();
+    db->huf_slot_cells = 1u << max_huf_bits;
+    db->out_size = b->out_size;
+    db->stats = st;
+    int rc = MZD_OK;
+    auto fail = [&](int code) {
+        mzd_batch_free(ctx, db);
+        return code;
+    };
+#define TRY_OR_FAIL(expr)                 \
+    do {                                  \
+        rc = (expr);                      \
+        if (rc != MZD_OK) return fail(rc); \
+    } while (0)
+#define HIP_OR_FAIL(expr)                                                                 \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ctx->last_error = std::string(#expr " failed: ") + hipGetErrorString(e_);     \
+            return fail(MZD_ERR_DEVICE);                                                  \
+        }                                                                                 \
+    } while (0)
+
+    if (b->flags & MZD_BATCH_IN_ON_DEVICE) {
+        db->d_in = b->in;
+    } else {
+        HIP_OR_FAIL(hipMalloc((void **)&db->d_in_alloc, b->in_size + 2 * MZD_IN_PAD));
+        HIP_OR_FAIL(hipMemset(db->d_in_alloc, 0, MZD_IN_PAD));
+        HIP_OR_FAIL(hipMemset(db->d_in_alloc + MZD_IN_PAD + b->in_size, 0, MZD_IN_PAD));
+        if (b->in_size) HIP_OR_FAIL(hipMemcpy(db->d_in_alloc + MZD_IN_PAD, b->in, b->in_size, hipMemcpyHostToDevice));
+        db->d_in = db->d_in_alloc + MZD_IN_PAD;
+    }
+    if ((b->flags & MZD_BATCH_OUT_ON_DEVICE) && b->out) {
+        db->d_out = b->out;
+    } else {
+        HIP_OR_FAIL(hipMalloc((void **)&db->d_out, std::max<uint64_t>(b->out_size, 16)));
+        db->own_out = true;
+    }
+    TRY_OR_FAIL(upload_vec(ctx, frames, &db->d_frames));
+    TRY_OR_FAIL(upload_vec(ctx, blocks, &db->d_blocks));
+    TRY_OR_FAIL(upload_vec(ctx, huf_tasks, &db->d_huf_tasks));
+    TRY_OR_FAIL(upload_vec(ctx, seq_tasks, &db->d_seq_tasks));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_sums, std::max<size_t>(b->n_blocks, 1) * sizeof(BlockSum)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_fse_entries, std::max<size_t>(b->n_fse_entries, 1) * 4));
+    if (b->n_fse_entries)
+        HIP_OR_FAIL(hipMemcpy(db->d_fse_entries, b->fse_entries, (size_t)b->n_fse_entries * 4, hipMemcpyHostToDevice));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_entries, std::max<size_t>(b->n_huf_entries, 2) * 2 + 8));
+    if (b->n_huf_entries)
+        HIP_OR_FAIL(hipMemcpy(db->d_huf_entries, b->huf_entries, (size_t)b->n_huf_entries * 2, hipMemcpyHostToDevice));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_recs, std::max<uint64_t>(rec_total, 1) * 8));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_tiles, std::max<uint64_t>(tile_total, 1) * sizeof(TileBase)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_status, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_out_len, std::max<size_t>(b->n_frames, 1) * sizeof(uint64_t)));
+    HIP_OR_FAIL(hipMemset(db->d_status, 0xFF, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
+    HIP_OR_FAIL(hipMemset(db->d_out_len, 0, std::max<size_t>(b->n_frames, 1) * sizeof(uint64_t)));
+#undef TRY_OR_FAIL
+#undef HIP_OR_FAIL
+    *out = db;
+    return MZD_OK;
+}
+
+int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
+{
+    if (!ctx || !db) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    const bool cell16 = ctx->opt.seq_variant != 1;  // default: 2-byte LDS cells (63 chains per CU)
+    const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 1024;
+    if (exec_threads % 64 || exec_threads > 1024) return MZD_ERR_INVALID_ARG;
+    const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + 512
+                                  : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + 512;
+    const size_t exec_lds = kBlockMax + 32 + 16;
+    const size_t huf_lds = (size_t)kHufQuads * db->huf_slot_cells * 2;
+    if (!ctx->attr_set) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + 512)));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((size_t)kSeqChains32 * kSeqCellsPerChain * 4 + 512)));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)exec_lds));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
+        ctx->attr_set = true;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (db->n_huf_tasks)
+        k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
+                                                             db->d_litbuf, db->d_sums, db->huf_slot_cells);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (db->n_seq_tasks) {
+        if (cell16)
+            k_seq<true><<<(db->n_seq_tasks + kSeqChains16 - 1) / kSeqChains16, 64, seq_lds, s>>>(
+                db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+        else
+            k_seq<false><<<(db->n_seq_tasks + kSeqChains32 - 1) / kSeqChains32, 64, seq_lds, s>>>(
+                db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    if (db->n_frames)
+        k_exec<<<db->n_frames, exec_threads, exec_lds, s>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
+                                                           db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
+                                                           db->d_out_len);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->timed = true;
+    return MZD_OK;
+}
+
+int mzd_sync(mzd_ctx *ctx)
+{
+    if (!ctx) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return MZD_OK;
+}
+
+int mzd_batch_download(mzd_ctx *ctx, mzd_dbatch *db, uint8_t *out_host, int32_t *status, uint64_t *out_len)
+{
+    if (!ctx || !db) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (out_host && db->out_size) HIP_TRY(ctx, hipMemcpy(out_host, db->d_out, db->out_size, hipMemcpyDeviceToHost));
+    if (status && db->n_frames)
+        HIP_TRY(ctx, hipMemcpy(status, db->d_status, db->n_frames * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_len && db->n_frames)
+        HIP_TRY(ctx, hipMemcpy(out_len, db->d_out_len, db->n_frames * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MZD_OK;
+}
+
+void *mzd_batch_device_out(mzd_dbatch *db) { return db ? db->d_out : nullptr; }
+void *mzd_batch_device_status(mzd_dbatch *db) { return db ? db->d_status : nullptr; }
+void *mzd_batch_device_out_len(mzd_dbatch *db) { return db ? db->d_out_len : nullptr; }
+
+int mzd_decode_batch(mzd_ctx *ctx, const mzd_batch *batch, int32_t *status, uint64_t *out_len)
+{
+    if (!ctx || !batch) return MZD_ERR_INVALID_ARG;
+    mzd_dbatch *db = nullptr;
+    int rc = mzd_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    rc = mzd_batch_run(ctx, db, nullptr);
+    std::vector<int32_t> st(batch->n_frames);
+    if (rc == MZD_OK) {
+        uint8_t *host_out = (batch->flags & MZD_BATCH_OUT_ON_DEVICE) ? nullptr : batch->out;
+        rc = mzd_batch_download(ctx, db, host_out, st.data(), out_len);
+    }
+    mzd_batch_free(ctx, db);
+    if (rc) return rc;
+    int first = MZD_OK;
+    for (uint32_t i = 0; i < batch->n_frames; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] && !first) first = st[i];
+    }
+    return first;
+}
+
+int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
+{
+    static const char *kNames[4] = {"k_init", "k_huf", "k_seq", "k_exec"};
+    if (!ctx || !ctx->timed) return 0;
+    int n = 0;
+    for (int i = 0; i < 4 && n < cap; i++, n++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]) != hipSuccess) t = -1;
+        if (names) names[n] = kNames[i];
+        if (ms) ms[n] = t;
+    }
+    return n;
+}
+
+int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
+{
+    if (!db || !st) return MZD_ERR_INVALID_ARG;
+    *st = db->stats;
+    return MZD_OK;
+}
+
+}  // extern "C"

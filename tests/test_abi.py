@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/mzd.h declares (CPU, no compute)."""
+import ctypes
+import os
+import re
+
+import sparkzstd_amd as z
+from sparkzstd_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "mzd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mzd_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/mzd.h but not exported by libmzd.so"
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_struct_layouts_match_header():
+    # sizes the header implies (natural alignment, little endian)
+    assert ctypes.sizeof(_lib.FrameDesc) == 40
+    assert ctypes.sizeof(_lib.BlockDesc) == 80
+    assert ctypes.sizeof(_lib.FseEntry) == 4
+    assert ctypes.sizeof(_lib.FseTableDesc) == 8
+    assert ctypes.sizeof(_lib.HufEntry) == 2
+    assert ctypes.sizeof(_lib.HufTableDesc) == 8
+
+
+def test_identity_and_errors():
+    L = _lib.load()
+    assert L.mzd_abi_version() == 1
+    assert L.mzd_backend() == b"hip-gfx950"
+    assert b"Magicnum" in L.mzd_strerror(2)
+    assert L.mzd_device_count() >= 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a HIP device the product refuses to run (no oracle / CPU route)."""
+    L = _lib.load()
+    if L.mzd_device_count() > 0:
+        return
+    try:
+        z.Context(0)
+    except z.MzdError as e:
+        assert e.code == 102
+    else:
+        raise AssertionError("Context() must fail without a GPU")
+
+
+def test_product_does_not_link_oracle():
+    so = open(_lib.LIB_PATH, "rb").read()
+    assert b"orc_decode_frame" not in so and b"sparkzstd_oracle" not in so

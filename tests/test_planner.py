@@ -1,0 +1,105 @@
+"""Host planner (sparkzstd_amd/csrc/planner.cpp) on CPU: descriptors produced for the golden
+corpus, executed by the test-only descriptor interpreter, must regenerate the originals.  Also
+error behaviour of the header parsers.  No GPU, no oracle involvement in the product path."""
+import ctypes
+
+import pytest
+
+import sparkzstd_amd as z
+from sparkzstd_amd import _lib
+from tests.conftest import check_expected
+from tests.desc_interp import run_batch
+
+
+def _blob_of(batch):
+    return bytes((ctypes.c_uint8 * batch.in_size).from_address(batch.in_)) if batch.in_size else b""
+
+
+def test_planner_parses_whole_corpus(corpus):
+    p = z.Plan()
+    for name, comp, length, sha, exp in corpus:
+        rc, consumed = p.add_frame(comp)
+        assert rc == 0, name
+        assert consumed == len(comp) - 4  # checksum never read
+    b = p.finalize()
+    assert b.n_frames == 100
+    # SURVEY 4 corpus census: 3651 blocks = 746 raw / 447 rle / 2458 compressed
+    types = [b.blocks[i].type for i in range(b.n_blocks)]
+    assert (types.count(0), types.count(1), types.count(2)) == (746, 447, 2458)
+    nseq = sum(b.blocks[i].n_seq for i in range(b.n_blocks))
+    assert nseq == 1031936
+    # frames with a content size get an exact slab
+    for i, (name, comp, length, sha, exp) in enumerate(corpus):
+        fd = b.frames[i]
+        if fd.content_size != _lib.MZD_UNKNOWN_SIZE:
+            assert fd.content_size == length and fd.out_capacity == length
+        else:
+            assert fd.out_capacity >= length
+        assert fd.out_offset % 16 == 0
+    p.close()
+
+
+def test_descriptors_regenerate_small_corpus_frames(corpus):
+    """The descriptor contract carries everything: interpreting it reproduces the originals."""
+    small = [c for c in corpus if c[2] <= 40000][:24]
+    assert len(small) >= 10
+    p = z.Plan()
+    for name, comp, *_ in small:
+        assert p.add_frame(comp)[0] == 0
+    b = p.finalize()
+    outs = run_batch(b, _blob_of(b))
+    for (name, comp, length, sha, exp), got in zip(small, outs):
+        check_expected(name, got, length, sha, exp)
+    p.close()
+
+
+def test_predefined_tables_are_shared_and_match_kat(kat, corpus):
+    """fse/fse_test.go:8-41 through the planner: baseline / nbits / code of the predefined LL table."""
+    LL_BASE = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64,
+               0x80, 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000]
+    LL_EXTRA = [0] * 16 + [1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+    p = z.Plan()
+    for name, comp, *_ in corpus:
+        p.add_frame(comp)
+    b = p.finalize()
+    found = [i for i in range(b.n_fse_tables) if b.fse_tables[i].kind == 0 and b.fse_tables[i].acc_log == 6]
+    ok = 0
+    for ti in found:
+        td = b.fse_tables[ti]
+        cells = [b.fse_entries[td.entries_off + i] for i in range(64)]
+        got = [[c.baseline, LL_EXTRA[c.symbol], c.nbits, LL_BASE[c.symbol]] for c in cells]
+        ok += got == kat["ll_predefined_table"]
+    assert ok >= 1
+    p.close()
+
+
+@pytest.mark.parametrize("frame,code", [
+    (b"\x28\xb5\x2f\xfc\x20\x00\x01\x00\x00", 2),            # wrong magic
+    (b"\x28\xb5\x2f\xfd\x20\x00\x07\x00\x00", 3),            # reserved block type 3
+    (b"\x28\xb5\x2f\xfd\x20\x00\x01\x00", 1),                # truncated block header
+    (b"\x28\xb5\x2f\xfd\x20\x00\x09\x00\x10\x00", 4),        # block size 131073 > 128 KiB
+    (b"\x28\xb5\x2f\xfd", 1),
+])
+def test_planner_header_errors(frame, code):
+    p = z.Plan()
+    rc, _ = p.add_frame(frame)
+    assert rc == code
+    b = p.finalize()
+    assert b.n_frames == 1 and b.frames[0].n_blocks == 0 and p.frame_status(0) == code
+    p.close()
+
+
+def test_handmade_raw_and_rle_frames():
+    """config-2 style frames: single-segment, 4-byte FCS, one raw or rle block."""
+    payload = bytes(range(200)) * 3
+    n = len(payload)
+    raw = b"\x28\xb5\x2f\xfd" + bytes([0xA0]) + n.to_bytes(4, "little") + ((n << 3) | 1).to_bytes(3, "little") + payload
+    rle = b"\x28\xb5\x2f\xfd" + bytes([0xA0]) + (1000).to_bytes(4, "little") + ((1000 << 3) | 3).to_bytes(3, "little") + b"\x5a"
+    p = z.Plan()
+    assert p.add_frame(raw) == (0, len(raw))
+    assert p.add_frame(rle) == (0, len(rle))
+    b = p.finalize()
+    outs = run_batch(b, _blob_of(b))
+    assert outs[0] == payload and outs[1] == b"\x5a" * 1000
+    assert b.frames[0].content_size == n and b.frames[0].window_size == n
+    p.close()
