@@ -389,18 +389,20 @@ __global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, cons
         const uint32_t LL = (cl & 0xFFFFFF) + llx;
 
         // ---- repeat-offset resolution (sequence_execution.go:65-114) on concrete-or-symbolic history
-        int off;
+        int off, n0, n1 = h1, n2 = h2;
         if (ofv > 3) {
             off = (int)(ofv - 3);
             if (ofv - 3 >= kRecOffSymbolic && act) status = MZD_ERR_UNSUPPORTED;  // offset >= 2^28
-            h2 = h1; h1 = h0; h0 = off;
+            n2 = h1; n1 = h0;
         } else {
             const int idx = (int)ofv - 1 + (LL == 0 ? 1 : 0);
             off = idx == 0 ? h0 : (idx == 1 ? h1 : (idx == 2 ? h2 : hist_dec(h0)));
             if (off == 0 && act) status = MZD_ERR_OFFSET;
-            if (idx >= 2) h2 = h1;
-            if (idx >= 1) { h1 = h0; h0 = off; }
+            if (idx >= 2) n2 = h1;
+            if (idx >= 1) n1 = h0;
         }
+        n0 = off;
+        if (act) { h0 = n0; h1 = n1; h2 = n2; }  // finished lanes keep their final history
         if (act && status == MZD_OK) {
             const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
             myrec[i] = (uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)offfield << kRecOffShift);
