@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- decompressed MB/s of the zstd block-decode hot path on MI355X.
+
+One "step" = one pass of the whole hot path (Huffman literal decode -> FSE sequence decode ->
+sequence execution) over one resident batch of synthetic frames.  Default workload = BASELINE.json
+configs[3]: 65536 independent single-block 128 KiB text-like frames per GPU,
+generated deterministically by tools/synth (own zstd-format encoder).  Inputs, descriptors and
+tables are resident in HBM before the timed region; outputs stay in HBM.
+
+Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
+time).  Frames are independent, so ranks simply take disjoint frame ranges: no data-path collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=4, help="SURVEY 8d config: 2 raw/rle, 3 huffman only, 4 full")
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="default: 65536 (config 4) / 4096 (configs 2, 3)")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
+    ap.add_argument("--seq-variant", type=int, default=0)
+    ap.add_argument("--exec-threads", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
+    """Oracle ("port" of the reference algorithm, plain C) on the host cores, bounded sample of the
+    SAME frames.  Reported next to the GPU number; never the thing measured as `value`."""
+    from tests.oracle_binding import load_oracle
+    orc = load_oracle()
+    cores = os.cpu_count() or 1
+    n_total = len(off)
+
+    def run(first, count, nthreads):
+        per = (count + nthreads - 1) // nthreads
+        outs = []
+        ths = []
+        t0 = time.perf_counter()
+        for t in range(nthreads):
+            a, b = first + t * per, min(first + count, first + (t + 1) * per)
+            if a >= b:
+                continue
+            n = b - a
+            dst = np.empty(n * frame_bytes, dtype=np.uint8)
+            doff = (np.arange(n, dtype=np.uint64) * np.uint64(frame_bytes))
+            dcap = np.full(n, frame_bytes, dtype=np.uint64)
+            olen = np.empty(n, dtype=np.uint64)
+            st = np.empty(n, dtype=np.int32)
+            o = np.ascontiguousarray(off[a:b])
+            l = np.ascontiguousarray(ln[a:b])
+            outs.append((dst, olen, st, o, l, doff, dcap))
+            th = threading.Thread(target=orc.lib.orc_decode_frames,
+                                  args=(blob.ctypes.data, o.ctypes.data, l.ctypes.data, n, dst.ctypes.data,
+                                        doff.ctypes.data, dcap.ctypes.data, olen.ctypes.data, st.ctypes.data))
+            th.start()
+            ths.append(th)
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        ok = all(int(x[2].max()) == 0 for x in outs)
+        return dt, ok
+
+    calib = min(n_total, 4 * cores)
+    dt, ok = run(0, calib, cores)
+    rate = calib / max(dt, 1e-6)  # frames/s on all cores
+    sample = int(max(calib, min(n_total, rate * budget_s)))
+    dt, ok2 = run(0, sample, cores)
+    return {"value": round(sample * frame_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} frames of the same batch, oracle (C restatement of the reference "
+                      f"algorithm) on {cores} host threads, {dt:.1f}s", "ok": bool(ok and ok2)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1 and a.gpus == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sparkzstd_amd as z
+    from tools import synth_binding as sb
+
+    frame_bytes = 131072
+    base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
+    if a.strong:
+        per = base // world
+        first, scaling = rank * per, "strong"
+    else:
+        per = base
+        first, scaling = rank * per, "weak"
+
+    # ---- synthetic batch (host), planning (host), upload: all outside the timed region
+    t0 = time.perf_counter()
+    gen_threads = a.gen_threads or max(1, (os.cpu_count() or 1) // max(1, world))
+    blob, off, ln, cks, nseq = sb.make_batch(a.config, first, per, frame_bytes, threads=gen_threads)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    plan = z.Plan()
+    rc = plan.add_frames(blob, off, ln, threads=gen_threads)
+    assert rc == 0, f"planner failed: {rc}"
+    batch = plan.finalize()
+    t_plan = time.perf_counter() - t0
+    assert batch.n_frames == per and batch.out_size == per * frame_bytes
+
+    t0 = time.perf_counter()
+    pad = 64
+    d_in = torch.zeros(blob.size + 2 * pad, dtype=torch.uint8, device="cuda")
+    d_in[pad:pad + blob.size].copy_(torch.from_numpy(blob))
+    d_out = torch.zeros(batch.out_size, dtype=torch.uint8, device="cuda")
+    ctx = z.Context(local_rank, seq_variant=a.seq_variant, exec_threads=a.exec_threads)
+    rb = ctx.upload(batch, device_in_ptr=d_in.data_ptr() + pad, device_out_ptr=d_out.data_ptr())
+    torch.cuda.synchronize()
+    t_upload = time.perf_counter() - t0
+    stats = rb.stats()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup
+    for _ in range(a.warmup):
+        rb.run(stream)
+    torch.cuda.synchronize()
+    ctx.timing_reset(True)
+
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rb.run(stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = ctx.kernel_ms()  # HIP events on the launch stream, averaged over the K timed steps
+
+    # ---- verification (outside the timed region): status, lengths, checksum of every frame
+    ok = True
+    if not a.no_verify:
+        _, status, out_len = rb.download(want_out=False)
+        ok = bool((status == 0).all() and (out_len == frame_bytes).all())
+        exp = torch.from_numpy(cks.view(np.int64)).cuda()
+        words = frame_bytes // 8
+        wts = (2 * torch.arange(words, dtype=torch.int64, device="cuda") + 1)
+        o64 = d_out.view(torch.int64).view(per, words)
+        chunk = 4096
+        for c in range(0, per, chunk):
+            got = (o64[c:c + chunk] * wts).sum(dim=1)
+            ok = ok and bool((got == exp[c:c + chunk]).all())
+    if world > 1:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+
+    if rank == 0:
+        total_frames = per * world
+        d_bytes = total_frames * frame_bytes
+        ms_per_step = elapsed / a.steps * 1e3
+        value = d_bytes / (elapsed / a.steps) / 1e6
+        # roofline of the dominant kernel set: algorithmic bytes = compressed bytes read once +
+        # decompressed bytes written once, per launch (= one pass over this rank's batch)
+        c_bytes = int(stats.compressed_bytes)
+        alg = c_bytes + per * frame_bytes
+        path_ms = sum(v for k, v in kms.items() if v > 0)
+        dom = max(kms, key=lambda k: kms[k]) if kms else None
+        achieved = alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                "traffic": None,
+                "kernel": f"hot path = k_huf + k_seq + k_exec in sequence; dominant {dom}",
+                "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+                "algorithmic_bytes_per_launch": alg,
+                "dominant_kernel_alone_GBs": round(alg / (kms[dom] * 1e-3) / 1e9, 1) if dom else None}
+        cpu = None
+        if a.cpu_seconds > 0:
+            cpu = cpu_baseline(blob, off, ln, frame_bytes, a.cpu_seconds)
+        names = {2: "config2 raw/rle single-block 128KiB frames", 3: "config3 4-stream huffman literals, 0 sequences",
+                 4: "config4 text-like 128KiB frames: huffman literals + FSE sequences + match copy"}
+        line = {
+            "metric": "decompressed MB/s + %HBM-peak, 64k-frame batch, 1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": names.get(a.config, str(a.config)), "frames_per_gpu": per,
+                       "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes,
+                       "sequences_per_frame": round(float(nseq.mean()), 1),
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 1024},
+            "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok,
+            "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
+            "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 2), "upload": round(t_upload, 2)},
+        }
+        print(json.dumps(line), flush=True)
+        if not ok:
+            sys.exit(3)
+    rb.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

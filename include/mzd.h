@@ -219,10 +219,13 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db);
  * non-zero frame status. */
 int mzd_decode_batch(mzd_ctx *ctx, const mzd_batch *batch, int32_t *status, uint64_t *out_len);
 
-/* Per-kernel timing of the last mzd_batch_run (HIP events recorded on the launch
- * stream). Call after mzd_sync. names/ms arrays of capacity `cap`; returns the
- * number of kernels. */
+/* Per-kernel durations, averaged over every mzd_batch_run since the last
+ * mzd_timing_reset (HIP events recorded on the launch stream around each kernel).
+ * Call after mzd_sync. names/ms arrays of capacity `cap`; returns the number of
+ * kernels. */
 int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap);
+/* Forget accumulated timings; enable != 0 keeps recording events on later runs. */
+void mzd_timing_reset(mzd_ctx *ctx, int enable);
 /* Byte counts of the resident batch for roofline accounting. */
 typedef struct mzd_batch_stats {
     uint64_t compressed_bytes;    /* sum over blocks of the bytes the kernels must read (C) */

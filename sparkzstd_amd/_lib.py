@@ -19,7 +19,7 @@ EXPORTS = [
     "mzd_abi_version", "mzd_backend", "mzd_strerror", "mzd_device_count", "mzd_create", "mzd_destroy",
     "mzd_last_error", "mzd_batch_upload", "mzd_batch_run", "mzd_sync", "mzd_batch_download",
     "mzd_batch_device_out", "mzd_batch_device_status", "mzd_batch_device_out_len", "mzd_batch_free",
-    "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_batch_get_stats", "mzd_plan_create",
+    "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_timing_reset", "mzd_batch_get_stats", "mzd_plan_create",
     "mzd_plan_destroy", "mzd_plan_reset", "mzd_plan_add_frame", "mzd_plan_add_frames",
     "mzd_plan_finalize", "mzd_plan_frame_status",
 ]
@@ -114,6 +114,7 @@ def load():
         "mzd_batch_free": (None, [vp, vp]),
         "mzd_decode_batch": (i32, [vp, ctypes.POINTER(Batch), vp, vp]),
         "mzd_last_run_kernel_ms": (i32, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]),
+        "mzd_timing_reset": (None, [vp, i32]),
         "mzd_batch_get_stats": (i32, [vp, ctypes.POINTER(BatchStats)]),
         "mzd_plan_create": (vp, []),
         "mzd_plan_destroy": (None, [vp]),

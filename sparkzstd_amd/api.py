@@ -156,7 +156,11 @@ class Context:
         if rc:
             raise MzdError(rc, "mzd_sync: " + self.last_error())
 
+    def timing_reset(self, enable=True):
+        self._L.mzd_timing_reset(self._c, 1 if enable else 0)
+
     def kernel_ms(self):
+        """average ms per kernel over the runs since timing_reset() (call after sync())"""
         names = (ctypes.c_char_p * 8)()
         ms = (ctypes.c_float * 8)()
         n = self._L.mzd_last_run_kernel_ms(self._c, names, ms, 8)

@@ -22,8 +22,10 @@ struct mzd_ctx {
     hipStream_t stream = nullptr;
     mzd_options opt{};
     std::string last_error;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool timed = false;
+    // HIP events around every kernel of every mzd_batch_run since the last mzd_timing_reset
+    std::vector<hipEvent_t> ev;  // 5 per run
+    size_t runs = 0;
+    bool timing = true;
     bool attr_set = false;
 };
 
@@ -137,7 +139,6 @@ mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err)
         delete c;
         return nullptr;
     }
-    for (auto &e : c->ev) (void)hipEventCreate(&e);
     if (err) *err = MZD_OK;
     return c;
 }
@@ -146,8 +147,7 @@ void mzd_destroy(mzd_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto &e : ctx->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -437,13 +437,23 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
         ctx->attr_set = true;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    hipEvent_t *ev = nullptr;
+    if (ctx->timing) {
+        if (ctx->runs >= 4096) ctx->runs = 0;  // bounded ring
+        while (ctx->ev.size() < (ctx->runs + 1) * 5) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        ev = ctx->ev.data() + ctx->runs * 5;
+    }
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     if (db->n_huf_tasks)
         k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                              db->d_litbuf, db->d_sums, db->huf_slot_cells);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s));
     if (db->n_seq_tasks) {
         if (cell16)
             k_seq<true><<<(db->n_seq_tasks + kSeqChains16 - 1) / kSeqChains16, 64, seq_lds, s>>>(
@@ -452,14 +462,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             k_seq<false><<<(db->n_seq_tasks + kSeqChains32 - 1) / kSeqChains32, 64, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
     if (db->n_frames)
         k_exec<<<db->n_frames, exec_threads, exec_lds, s>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
                                                            db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
                                                            db->d_out_len);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    if (ev) {
+        HIP_TRY(ctx, hipEventRecord(ev[4], s));
+        ctx->runs++;
+    }
     HIP_TRY(ctx, hipGetLastError());
-    ctx->timed = true;
     return MZD_OK;
 }
 
@@ -513,15 +525,29 @@ int mzd_decode_batch(mzd_ctx *ctx, const mzd_batch *batch, int32_t *status, uint
 int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
 {
     static const char *kNames[4] = {"k_init", "k_huf", "k_seq", "k_exec"};
-    if (!ctx || !ctx->timed) return 0;
+    if (!ctx || ctx->runs == 0) return 0;
     int n = 0;
     for (int i = 0; i < 4 && n < cap; i++, n++) {
-        float t = 0;
-        if (hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]) != hipSuccess) t = -1;
+        double acc = 0;
+        size_t cnt = 0;
+        for (size_t r = 0; r < ctx->runs; r++) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ctx->ev[r * 5 + i], ctx->ev[r * 5 + i + 1]) == hipSuccess) {
+                acc += t;
+                cnt++;
+            }
+        }
         if (names) names[n] = kNames[i];
-        if (ms) ms[n] = t;
+        if (ms) ms[n] = cnt ? (float)(acc / cnt) : -1.0f;
     }
     return n;
+}
+
+void mzd_timing_reset(mzd_ctx *ctx, int enable)
+{
+    if (!ctx) return;
+    ctx->runs = 0;
+    ctx->timing = enable != 0;
 }
 
 int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
