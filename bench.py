@@ -224,11 +224,15 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 2), "upload": round(t_upload, 2)},
         }
         print(json.dumps(line), flush=True)
-        if not ok:
-            sys.exit(3)
     rb.free()
+    ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    # leave without interpreter teardown: under rocprofv3 the HIP/torch atexit handlers can hang
+    os._exit(0 if ok else 3)
 
 
 if __name__ == "__main__":

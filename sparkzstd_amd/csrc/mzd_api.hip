@@ -426,7 +426,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (exec_threads % 64 || exec_threads > 1024) return MZD_ERR_INVALID_ARG;
     const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + 512
                                   : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + 512;
-    const size_t exec_lds = kBlockMax + 32 + 16;
+    const size_t exec_lds = kExecLdsBytes;
     const size_t huf_lds = (size_t)kHufQuads * db->huf_slot_cells * 2;
     if (!ctx->attr_set) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

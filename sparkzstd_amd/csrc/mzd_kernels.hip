@@ -424,15 +424,28 @@ __global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// k_exec: sequence execution + Raw/RLE blocks.  One workgroup per frame.
+// k_exec: sequence execution + Raw/RLE blocks.  One workgroup (16 wavefronts) per frame.
+//
+// LDS layout:  [ block buffer 128 KiB + 32 ][ validity bitmap 16 KiB ][ control ]
+//   * the block being regenerated lives in LDS, shifted by `mis` so that LDS and HBM agree on
+//     16-byte alignment; matches into EARLIER blocks of the frame read HBM (already flushed);
+//   * validity bitmap: bit p set <=> output byte p of the block has been written.  Sequence
+//     execution is a DATAFLOW: a match copy runs as soon as exactly its source bytes are valid,
+//     so 64-sequence tiles execute on 16 wavefronts with no ordering between tiles and no false
+//     dependencies (the reference's serial loop sequence_execution.go:16-53 is the degenerate
+//     schedule of the same dataflow graph).  Progress: the earliest unexecuted match of a block
+//     always has all its sources valid, and every wavefront walks its tiles in increasing order.
+//   * byte-misaligned LDS dword READS are replayed 64x on gfx950 (tools/ubench), misaligned dword
+//     WRITES are not: copies read aligned dwords, funnel-shift with v_alignbyte, write misaligned.
 
 struct ExecShared {
-    int committed_tile;      // tiles [0, committed_tile) of the current block are final in LDS
-    uint32_t committed_pos;  // block-relative output position up to which everything is final
     int error;
+    uint32_t pad[3];
 };
 
-constexpr uint32_t kNoPos = 0xFFFFFFFFu;
+constexpr uint32_t kExecBufBytes = kBlockMax + 32;
+constexpr uint32_t kExecMapWords = kBlockMax / 32 + 4;  // one bit per output byte (+ slack for the w+1 probe)
+constexpr uint32_t kExecLdsBytes = kExecBufBytes + kExecMapWords * 4 + 16;
 
 __device__ __forceinline__ int sel3(uint32_t k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
 __device__ __forceinline__ int resolve_hist(int v, int H0, int H1, int H2)
@@ -442,6 +455,41 @@ __device__ __forceinline__ int resolve_hist(int v, int H0, int H1, int H2)
     return sel3(u & 3, H0, H1, H2) - (int)(u >> 2);
 }
 
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_shr(uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// wave64 inclusive scan on the DPP path (row_shr 1/2/4/8, row_bcast 15/31): ~100 cycles
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+    v += dpp_shr<0x111, 0xf, 0xf>(v);
+    v += dpp_shr<0x112, 0xf, 0xf>(v);
+    v += dpp_shr<0x114, 0xf, 0xe>(v);
+    v += dpp_shr<0x118, 0xf, 0xc>(v);
+    v += dpp_shr<0x142, 0xa, 0xf>(v);
+    v += dpp_shr<0x143, 0xc, 0xf>(v);
+    return v;
+}
+
+// bit mask helpers for the validity bitmap: bits [bit, bit+n) of a 64-bit window, n <= 32
+__device__ __forceinline__ uint64_t span_mask(uint32_t bit, uint32_t n)
+{
+    return ((n >= 32 ? 0xFFFFFFFFull : ((1ull << n) - 1))) << bit;
+}
+__device__ __forceinline__ void publish(uint32_t *vmap, uint32_t pos, uint32_t n)  // n <= 32
+{
+    // data bytes were stored by this wavefront BEFORE this point; DS operations of a wavefront execute
+    // in order, so only the compiler has to be kept from sinking those stores below the OR
+    asm volatile("" ::: "memory");
+    const uint64_t m = span_mask(pos & 31, n);
+    const uint32_t w = pos >> 5;
+    atomicOr(&vmap[w], (uint32_t)m);
+    if ((uint32_t)(m >> 32)) atomicOr(&vmap[w + 1], (uint32_t)(m >> 32));
+}
+__device__ __forceinline__ uint32_t ld32u_g(const uint8_t *p) { return ((const U32U *)p)->v; }
+__device__ __forceinline__ void st32u_l(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
+
 __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
@@ -449,8 +497,9 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
                                                int32_t *frame_status, uint64_t *frame_out_len)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *buf = smem;  // kBlockMax + 32 bytes: the block being regenerated, shifted by `mis`
-    ExecShared *sh = (ExecShared *)(smem + kBlockMax + 32);
+    uint8_t *buf = smem;
+    uint32_t *vmap = (uint32_t *)(smem + kExecBufBytes);
+    ExecShared *sh = (ExecShared *)(smem + kExecBufBytes + kExecMapWords * 4);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
     const DFrame fr = frames[blockIdx.x];
@@ -458,8 +507,8 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
 
     if (tid == 0) sh->error = fr.plan_status;
     __syncthreads();
-    uint64_t outPos = 0;  // bytes of this frame produced so far
-    int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
+    uint64_t outPos = 0;              // bytes of this frame produced so far
+    int H0 = 1, H1 = 4, H2 = 8;       // framedecompressor.go:48,59
 
     for (uint32_t bi = 0; bi < fr.n_blocks && sh->error == MZD_OK; bi++) {
         const DBlock b = blocks[fr.first_block + bi];
@@ -504,20 +553,38 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
         const uint8_t *lits = (b.lit_type == MZD_LIT_HUF ? litbuf : in) + b.lit_src;
         const bool litRle = b.lit_type == MZD_LIT_RLE;
         const uint32_t rleWord = litRle ? lits[0] * 0x01010101u : 0;
-        if (tid == 0) {
-            sh->committed_tile = 0;
-            sh->committed_pos = 0;
+        const uint32_t ntiles = (b.n_seq + 63) >> 6;
+        if (ntiles) {
+            // clear the validity bits the sequences of this block will set
+            const uint32_t words = (seqOut + 31) >> 5;
+            for (uint32_t i = tid; i < words; i += nthr) vmap[i] = 0;
         }
         __syncthreads();
 
-        const uint32_t ntiles = (b.n_seq + 63) >> 6;
         const uint64_t *brec = recs + b.rec_off;
         const TileBase *btile = tiles + b.tile_off;
 
-        for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
+        // software pipeline: records / tile bases of the NEXT tile are loaded while the current one runs
+        uint32_t tile = wave;
+        uint64_t rec_n = 0;
+        TileBase tb_n{0, 0};
+        if (tile < ntiles) {
             const uint32_t si = tile * 64 + lane;
-            const bool valid = si < b.n_seq;
-            const uint64_t rec = valid ? brec[si] : 0ull;
+            rec_n = si < b.n_seq ? brec[si] : 0ull;
+            tb_n = btile[tile];
+        }
+        for (; tile < ntiles; tile += nwaves) {
+            const uint64_t rec = rec_n;
+            const TileBase tb = tb_n;
+            {
+                const uint32_t nt = tile + nwaves;
+                if (nt < ntiles) {
+                    const uint32_t si = nt * 64 + lane;
+                    rec_n = si < b.n_seq ? brec[si] : 0ull;
+                    tb_n = btile[nt];
+                }
+            }
+            const bool valid = tile * 64 + lane < b.n_seq;
             const uint32_t LL = (uint32_t)rec & kRecLlMask;
             const uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;
             const uint32_t offf = (uint32_t)(rec >> kRecOffShift) & kRecOffMask;
@@ -526,14 +593,10 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
                 uint32_t u = offf & (kRecOffSymbolic - 1);
                 off = sel3(u & 3, H0, H1, H2) - (int)(u >> 2);
             }
-            const TileBase tb = btile[tile];
-            const uint32_t litEnd = tb.lit_pos + wave_incl_scan_u32(LL, lane);
-            const uint32_t outEnd = tb.out_pos + wave_incl_scan_u32(LL + ML, lane);
+            const uint32_t litEnd = tb.lit_pos + wave_incl_scan_dpp(LL);
+            const uint32_t outEnd = tb.out_pos + wave_incl_scan_dpp(LL + ML);
             const uint32_t dstM = outEnd - ML, dstL = dstM - LL, srcL = litEnd - LL;
-            const uint32_t tileStart = tb.out_pos;
-            const uint32_t tileEnd = (uint32_t)__shfl((int)outEnd, 63, 64);
-            bool bad = false;
-            if (valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstM)) bad = true;  // ringbuffer.go:206-214
+            const bool bad = valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstM);  // ringbuffer.go:206-214
             if (__any(bad)) {
                 if (lane == 0) atomicMax(&sh->error, MZD_ERR_OFFSET);
             }
@@ -541,18 +604,26 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
 
             // ---- literals (sequence_execution.go:19-34): they depend on nothing
             {
-                const uint32_t shortLL = (valid && LL <= 16) ? LL : 0;
-                const uint32_t maxShort = wave_max_u32(shortLL);
-                if (maxShort > 0) {
-                    uint32_t w[4];
-                    if (litRle) { w[0] = w[1] = w[2] = w[3] = rleWord; }
-                    else if (shortLL) { U128U v = *(const U128U *)(lits + srcL); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-                    else { w[0] = w[1] = w[2] = w[3] = 0; }
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        if (j >= (int)maxShort) break;
-                        if (j < (int)shortLL) lbuf[dstL + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+                const uint32_t sLL = (valid && LL <= 16) ? LL : 0;
+                if (__any(sLL != 0)) {
+                    uint32_t w0 = rleWord, w1 = rleWord, w2 = rleWord, w3 = rleWord, wt = rleWord;
+                    if (!litRle && sLL) {
+                        const U128U v = *(const U128U *)(lits + srcL);
+                        w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+                        if (sLL >= 4) wt = ld32u_g(lits + srcL + sLL - 4);
                     }
+                    uint8_t *d = lbuf + dstL;
+                    if (sLL >= 4) st32u_l(d, w0);
+                    if (sLL >= 8) st32u_l(d + 4, w1);
+                    if (sLL >= 12) st32u_l(d + 8, w2);
+                    if (sLL >= 16) st32u_l(d + 12, w3);
+                    if (sLL >= 4 && (sLL & 3)) st32u_l(d + sLL - 4, wt);  // overlapped tail dword
+                    if (sLL > 0 && sLL < 4) {
+                        d[0] = (uint8_t)w0;
+                        if (sLL > 1) d[1] = (uint8_t)(w0 >> 8);
+                        if (sLL > 2) d[2] = (uint8_t)(w0 >> 16);
+                    }
+                    if (sLL) publish(vmap, dstL, sLL);
                 }
                 uint64_t longs = __ballot(valid && LL > 16);
                 while (longs) {
@@ -563,80 +634,154 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
                     const uint32_t s = (uint32_t)__shfl((int)srcL, src, 64);
                     if (litRle) for (uint32_t j = lane; j < n; j += 64) lbuf[d + j] = (uint8_t)rleWord;
                     else for (uint32_t j = lane; j < n; j += 64) lbuf[d + j] = lits[s + j];
+                    // publish: lane k owns bytes [32k, 32k+32) of the run per round of 2 KiB
+                    for (uint32_t j = lane * 32; j < n; j += 64 * 32) publish(vmap, d + j, min(32u, n - j));
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes done before matches read them
 
-            // ---- matches (sequence_execution.go:43-49, ringbuffer.go:242-277)
+            // ---- matches (sequence_execution.go:43-49, ringbuffer.go:242-277) as dataflow
             bool pending = valid && ML > 0 && !bad;
-            const uint32_t srcSpan = min(ML, (uint32_t)max(off, 1));  // bytes that are true sources
-            const int srcEnd = srcM + (int)srcSpan;
-            // part of the source range that belongs to EARLIER tiles of this block
-            const uint32_t needPrev = (srcM < (int)tileStart && srcEnd > 0) ? (uint32_t)min(srcEnd, (int)tileStart) : 0;
+            const uint32_t span = min(ML, (uint32_t)max(off, 1));  // bytes that are true sources
+            const bool isShort = ML <= 32;
+            const bool overlap = (uint32_t)off < ML;
+            uint32_t spins = 0;
             while (__any(pending)) {
-                const uint32_t firstDst = wave_min_u32(pending ? dstM : kNoPos);
-                const uint32_t committed = __hip_atomic_load(&sh->committed_pos, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const bool ready = pending && (srcEnd <= (int)firstDst || dstM == firstDst) && needPrev <= committed;
-                if (!__any(ready)) {
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                // short matches: one lane each, byte loop to the longest ready short match
-                const uint32_t shortML = (ready && ML <= 32) ? ML : 0;
-                const uint32_t maxShort = wave_max_u32(shortML);
-                for (uint32_t j = 0; j < maxShort; j++) {
-                    if (j < shortML) {
-                        const int q = srcM + (int)j;
-                        const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
-                        lbuf[dstM + j] = v;
+                // readiness of short matches: all source bytes at positions >= 0 must be valid
+                bool ready = false;
+                if (pending && isShort) {
+                    const int s0 = max(srcM, 0), s1 = srcM + (int)span;  // [s0, s1) inside this block
+                    if (s1 <= s0) ready = true;
+                    else {
+                        const uint64_t m = span_mask((uint32_t)s0 & 31, (uint32_t)(s1 - s0));
+                        const uint32_t w = (uint32_t)s0 >> 5;
+                        const uint32_t v0 = __hip_atomic_load(&vmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t v1 = __hip_atomic_load(&vmap[w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint64_t v = (uint64_t)v0 | ((uint64_t)v1 << 32);
+                        ready = (v & m) == m;
                     }
                 }
-                // long matches: whole wavefront per match
-                uint64_t longs = __ballot(ready && ML > 32);
-                while (longs) {
+                asm volatile("" ::: "memory");  // data reads below stay below the validity reads
+                bool progressed = false;
+                // (1) short non-overlapping matches entirely inside this block: dword path
+                const bool fast = ready && !overlap && srcM >= 0;
+                if (__any(fast)) {
+                    progressed = true;
+                    uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    uint32_t t0 = 0, t1 = 0;
+                    // aligned dwords covering the source bytes [sbyte, sbyte + ML) of the LDS buffer
+                    const uint32_t sbyte = fast ? (mis + (uint32_t)srcM) : 0;
+                    const uint32_t sa = sbyte & 3;
+                    const uint32_t *base = (const uint32_t *)(buf + (sbyte & ~3u));
+                    const uint32_t ndw = fast ? ((sa + ML + 3) >> 2) : 0;
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        if ((uint32_t)j < ndw) w[j] = base[j];
+                    const uint32_t tb_byte = sbyte + ML - 4;  // tail dword = source bytes [ML-4, ML)
+                    if (fast && ML >= 4 && (ML & 3)) {
+                        const uint32_t *tp = (const uint32_t *)(buf + (tb_byte & ~3u));
+                        t0 = tp[0];
+                        t1 = tp[1];
+                    }
+                    if (fast) {
+                        uint8_t *d = lbuf + dstM;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if ((uint32_t)(4 * j + 4) <= ML) st32u_l(d + 4 * j, __builtin_amdgcn_alignbyte(w[j + 1], w[j], sa));
+                        }
+                        if (ML >= 4 && (ML & 3)) st32u_l(d + ML - 4, __builtin_amdgcn_alignbyte(t1, t0, tb_byte & 3));
+                        if (ML < 4) {  // ML == 3 (or less on odd streams)
+                            const uint32_t x = __builtin_amdgcn_alignbyte(w[1], w[0], sa);
+                            if (ML > 0) d[0] = (uint8_t)x;
+                            if (ML > 1) d[1] = (uint8_t)(x >> 8);
+                            if (ML > 2) d[2] = (uint8_t)(x >> 16);
+                        }
+                        publish(vmap, dstM, ML);
+                    }
+                }
+                // (2) short matches that overlap themselves or reach into earlier blocks: byte loop
+                const bool slowb = ready && !fast;
+                if (__any(slowb)) {
+                    progressed = true;
+                    const uint32_t n = slowb ? ML : 0;
+                    const uint32_t nmax = wave_max_u32(n);
+                    for (uint32_t j = 0; j < nmax; j++) {
+                        if (j < n) {
+                            const int q = srcM + (int)j;
+                            const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
+                            lbuf[dstM + j] = v;
+                        }
+                    }
+                    if (slowb) publish(vmap, dstM, ML);
+                }
+                pending = pending && !ready;
+                // (3) at most one long match per iteration, whole wavefront, non-blocking readiness test
+                uint64_t longs = __ballot(pending && !isShort);
+                if (longs) {
                     const int src = __builtin_ctzll(longs);
-                    longs &= longs - 1;
                     const uint32_t n = (uint32_t)__shfl((int)ML, src, 64);
                     const uint32_t d = (uint32_t)__shfl((int)dstM, src, 64);
                     const int s = __shfl(srcM, src, 64);
                     const uint32_t o = (uint32_t)__shfl(off, src, 64);
-                    if (o >= 64) {
-                        // each 64-byte step only reads bytes written by earlier steps (in-order LDS)
-                        for (uint32_t j = lane; j < n; j += 64) {
-                            const int q = s + (int)j;
-                            const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
-                            lbuf[d + j] = v;
-                        }
-                    } else {
-                        // overlapping: periodic fill from the (final) pattern [s, s+o)
-                        uint32_t r = (uint32_t)lane % o;
-                        const uint32_t stepr = 64 % o;
-                        for (uint32_t j = lane; j < n; j += 64) {
-                            const int q = s + (int)r;
-                            const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
-                            lbuf[d + j] = v;
-                            r += stepr;
-                            if (r >= o) r -= o;
+                    const uint32_t sp2 = (uint32_t)__shfl((int)span, src, 64);
+                    // readiness: every valid-map word overlapping [max(s,0), s+sp2) must be complete there
+                    bool ok = true;
+                    const int s0 = max(s, 0), s1 = s + (int)sp2;
+                    if (s1 > s0) {
+                        const uint32_t wf = (uint32_t)s0 >> 5, wl = (uint32_t)(s1 - 1) >> 5;
+                        for (uint32_t wi = wf + lane; wi <= wl; wi += 64) {
+                            uint32_t need = 0xFFFFFFFFu;
+                            if (wi == wf) need &= 0xFFFFFFFFu << ((uint32_t)s0 & 31);
+                            if (wi == wl) need &= 0xFFFFFFFFu >> (31 - ((uint32_t)(s1 - 1) & 31));
+                            const uint32_t v = __hip_atomic_load(&vmap[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            ok = ok && ((v & need) == need);
                         }
                     }
+                    asm volatile("" ::: "memory");
+                    if (__all(ok)) {
+                        progressed = true;
+                        if (o >= 64) {
+                            // each 64-byte step only reads bytes written by earlier steps (in-order LDS)
+                            for (uint32_t j = lane; j < n; j += 64) {
+                                const int q = s + (int)j;
+                                const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
+                                lbuf[d + j] = v;
+                            }
+                        } else {
+                            // overlapping: periodic fill from the (final) pattern [s, s+o)
+                            uint32_t r = (uint32_t)lane % o;
+                            const uint32_t stepr = 64 % o;
+                            for (uint32_t j = lane; j < n; j += 64) {
+                                const int q = s + (int)r;
+                                const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
+                                lbuf[d + j] = v;
+                                r += stepr;
+                                if (r >= o) r -= o;
+                            }
+                        }
+                        for (uint32_t j = lane * 32; j < n; j += 64 * 32) publish(vmap, d + j, min(32u, n - j));
+                        if (lane == src) pending = false;
+                    }
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                pending = pending && !ready;
-            }
-
-            // ---- in-order commit
-            while (__hip_atomic_load(&sh->committed_tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tile)
-                __builtin_amdgcn_s_sleep(1);
-            if (lane == 0) {
-                __hip_atomic_store(&sh->committed_pos, tileEnd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&sh->committed_tile, (int)tile + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!progressed) {
+                    if ((++spins & 15) == 0 &&
+                        __hip_atomic_load(&sh->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != MZD_OK)
+                        break;  // corrupt input: a skipped match would never validate its bytes
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
         }
         // ---- literals after the last sequence (sequence_execution.go:55-59)
         {
             const uint32_t rest = b.lit_regen - litTotal;
-            if (litRle) for (uint32_t j = tid; j < rest; j += nthr) lbuf[seqOut + j] = (uint8_t)rleWord;
-            else for (uint32_t j = tid; j < rest; j += nthr) lbuf[seqOut + j] = lits[litTotal + j];
+            uint8_t *d = lbuf + seqOut;
+            if (litRle) {
+                for (uint32_t j = tid; j < rest; j += nthr) d[j] = (uint8_t)rleWord;
+            } else {
+                const uint8_t *s = lits + litTotal;
+                const uint32_t n4 = rest >> 2;
+                for (uint32_t j = tid; j < n4; j += nthr) st32u_l(d + 4 * j, ld32u_g(s + 4 * j));
+                for (uint32_t j = (n4 << 2) + tid; j < rest; j += nthr) d[j] = s[j];
+            }
         }
         __syncthreads();
         // ---- the block leaves for HBM: head bytes, aligned 16-byte body, tail bytes

@@ -1,0 +1,95 @@
+"""The synthetic workload generator (tools/synth: own zstd-format encoder) emits frames that the
+reference algorithm (oracle) regenerates exactly, that the host planner accepts, and whose
+descriptors interpret back to the original.  CPU only."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import sparkzstd_amd as z
+from tests.desc_interp import run_batch
+from tools import synth_binding as sb
+
+
+def _libzstd():
+    for p in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1"):
+        try:
+            L = ctypes.CDLL(p)
+            L.ZSTD_decompress.restype = ctypes.c_size_t
+            L.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+            L.ZSTD_isError.argtypes = [ctypes.c_size_t]
+            return L
+        except OSError:
+            continue
+    return None
+
+
+CASES = [(sb.TEXT, sb.MODE_FULL, 131072), (sb.TEXT, sb.MODE_LITERALS, 20000), (sb.EXP, sb.MODE_LITERALS, 131072),
+         (sb.EXP, sb.MODE_FULL, 50000), (sb.RANDOM, sb.MODE_FULL, 4096), (sb.ZERO, sb.MODE_FULL, 131072),
+         (sb.TEXT, sb.MODE_FULL, 300000), (sb.TEXT, sb.MODE_FULL, 63), (sb.TEXT, sb.MODE_FULL, 0),
+         (sb.RANDOM, sb.MODE_RAW, 1000), (sb.ZERO, sb.MODE_RLE, 1000)]
+
+
+@pytest.mark.parametrize("kind,mode,n", CASES)
+def test_synth_frames_decode_with_oracle_and_libzstd(oracle, kind, mode, n):
+    data = sb.generate(kind, 1234 + n, n)
+    frame, nseq = sb.compress(data, mode)
+    rc, out, consumed, _ = oracle.decode_frame(frame, cap=n + 64)
+    assert rc == 0 and out == data and consumed == len(frame)
+    L = _libzstd()
+    if L is not None:  # independent cross-check where libzstd exists (not required on the GPU box)
+        dst = ctypes.create_string_buffer(n + 64)
+        r = L.ZSTD_decompress(dst, n + 64, frame, len(frame))
+        assert not L.ZSTD_isError(r) and dst.raw[:r] == data
+
+
+def test_config_batches_have_the_surveyed_shape(oracle):
+    """config 4 ~ 12.5k sequences / ~43 KB per frame (zstd -3 shape), config 3 has 0
+    sequences and MaxBits 11, config 2 alternates raw / rle."""
+    blob, off, ln, ck, ns = sb.make_batch(4, 0, 8, threads=2)
+    assert 11000 < ns.mean() < 15000 and 40000 < ln.mean() < 50000
+    for i in range(8):
+        fr = blob[int(off[i]):int(off[i] + ln[i])].tobytes()
+        rc, out, _, tr = oracle.decode_frame(fr, cap=131072 + 64, want_trace=True)
+        assert rc == 0 and len(out) == 131072 and sb.checksum64(out) == int(ck[i])
+        b = tr["blocks"][0]
+        assert (b["lit_type"], b["lit_streams"], b["ll_mode"], b["of_mode"], b["ml_mode"]) == (2, 4, 2, 2, 2)
+    blob, off, ln, ck, ns = sb.make_batch(3, 0, 4, threads=2)
+    for i in range(4):
+        fr = blob[int(off[i]):int(off[i] + ln[i])].tobytes()
+        rc, out, _, tr = oracle.decode_frame(fr, cap=131072 + 64, want_trace=True)
+        b = tr["blocks"][0]
+        assert rc == 0 and b["n_seq"] == 0 and b["huf_max_bits"] == 11 and b["lit_regen"] == 131072
+        assert sb.checksum64(out) == int(ck[i])
+    blob, off, ln, ck, ns = sb.make_batch(2, 0, 4, threads=1)
+    assert [int(x) for x in ln] == [131072 + 12, 13, 131072 + 12, 13]
+
+
+def test_planner_and_descriptors_on_synth_frames():
+    frames, datas = [], []
+    for kind, mode, n in [(sb.TEXT, sb.MODE_FULL, 6000), (sb.EXP, sb.MODE_LITERALS, 3000), (sb.ZERO, sb.MODE_FULL, 5000),
+                          (sb.TEXT, sb.MODE_FULL, 140000)]:
+        d = sb.generate(kind, n, n)
+        frames.append(sb.compress(d, mode)[0])
+        datas.append(d)
+    p = z.Plan()
+    for f in frames:
+        assert p.add_frame(f) == (0, len(f))
+    b = p.finalize()
+    blob = bytes((ctypes.c_uint8 * b.in_size).from_address(b.in_))
+    assert run_batch(b, blob) == datas
+    p.close()
+
+
+def test_add_frames_adopts_blob_and_is_thread_safe():
+    blob, off, ln, ck, ns = sb.make_batch(4, 100, 96, frame_bytes=8192, threads=4)
+    p1, p2 = z.Plan(), z.Plan()
+    assert p1.add_frames(blob, off, ln, threads=1) == 0
+    assert p2.add_frames(blob, off, ln, threads=8) == 0
+    b1, b2 = p1.finalize(), p2.finalize()
+    assert (b1.n_frames, b1.n_blocks, b1.n_fse_entries, b1.n_huf_entries) == (b2.n_frames, b2.n_blocks, b2.n_fse_entries, b2.n_huf_entries)
+    assert b1.in_ == blob.ctypes.data  # adopted, not copied
+    for i in range(b1.n_blocks):
+        assert bytes(b1.blocks[i]) == bytes(b2.blocks[i])
+    p1.close(); p2.close()
