@@ -153,7 +153,7 @@ typedef struct mzd_batch {
     const uint8_t *in;     /* concatenated compressed payloads (whole frames or just the sections) */
     uint64_t in_size;
     uint8_t *out;          /* output blob; may be NULL for upload (library allocates on device) */
-    uint64_t out_size;
+    uint64_t out_size;     /* must leave >= 64 readable bytes after the last frame's slab (the planner adds 256) */
     const mzd_frame_desc *frames;
     uint32_t n_frames;
     const mzd_block_desc *blocks;
@@ -185,7 +185,8 @@ int mzd_device_count(void);
 typedef struct mzd_options {
     uint32_t seq_variant;     /* sequence-decode kernel variant, see DESIGN.md */
     uint32_t exec_threads;    /* threads per frame in the execution kernel (multiple of 64) */
-    uint32_t reserved[6];
+    uint32_t exec_chunk;      /* LDS window chunk of the execution kernel in bytes (multiple of 1024) */
+    uint32_t reserved[5];
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

@@ -72,7 +72,7 @@ class Batch(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("seq_variant", ctypes.c_uint32), ("exec_threads", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 6)]
+                ("exec_chunk", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5)]
 
 
 class BatchStats(ctypes.Structure):

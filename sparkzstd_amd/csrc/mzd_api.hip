@@ -422,18 +422,22 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
     const bool cell16 = ctx->opt.seq_variant != 1;  // default: 2-byte LDS cells (63 chains per CU)
-    const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 1024;
+    const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 256;
     if (exec_threads % 64 || exec_threads > 1024) return MZD_ERR_INVALID_ARG;
-    const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + 512
-                                  : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + 512;
-    const size_t exec_lds = kExecLdsBytes;
+    // LDS chunk of the execution kernel: default 32 KiB (4 workgroups per CU); multiple of 1024
+    uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 32768;
+    exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
+    const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16
+                                  : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32;
+    const size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
     const size_t huf_lds = (size_t)kHufQuads * db->huf_slot_cells * 2;
     if (!ctx->attr_set) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + 512)));
+                                         (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)((size_t)kSeqChains32 * kSeqCellsPerChain * 4 + 512)));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)exec_lds));
+                                         (int)((size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32)));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
         ctx->attr_set = true;
     }
@@ -456,17 +460,17 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s));
     if (db->n_seq_tasks) {
         if (cell16)
-            k_seq<true><<<(db->n_seq_tasks + kSeqChains16 - 1) / kSeqChains16, 64, seq_lds, s>>>(
+            k_seq<true><<<(db->n_seq_tasks + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
         else
-            k_seq<false><<<(db->n_seq_tasks + kSeqChains32 - 1) / kSeqChains32, 64, seq_lds, s>>>(
+            k_seq<false><<<(db->n_seq_tasks + kSeqChains32 - 1) / kSeqChains32, 128, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
     }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
     if (db->n_frames)
         k_exec<<<db->n_frames, exec_threads, exec_lds, s>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
                                                            db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
-                                                           db->d_out_len);
+                                                           db->d_out_len, exec_cap);
     if (ev) {
         HIP_TRY(ctx, hipEventRecord(ev[4], s));
         ctx->runs++;

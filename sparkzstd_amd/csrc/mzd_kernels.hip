@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/mzd.h"
 #include "mzd_device.h"
 
@@ -240,17 +242,68 @@ __constant__ uint8_t c_ml_extra[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 
 __device__ __forceinline__ int hist_dec(int x) { return x > 0 ? x - 1 : x - 4; }
 
+// Unmasked variant of the register bit window for k_seq: a valid sequence bitstream is consumed
+// exactly to bit 0, so bytes below the stream start are never interpreted (over-reads are
+// detected through the bit budget `rem`); the input blob carries MZD_IN_PAD bytes of slack.
+struct SeqBits {
+    const uint8_t *pd;  // address of D's bytes == stream + ptr - 8
+    uint64_t C, D;
+    int k;
+    __device__ __forceinline__ int init(const uint8_t *start, int len)
+    {
+        BackBits b;
+        const int r = b.init(start, len);  // masked loads once, for streams shorter than 16 bytes
+        C = b.C; D = b.D; k = b.k;
+        pd = start + (len - 16);
+        return r;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        const int nb = k >> 3;
+        const int sh = nb * 8;
+        C = (C << sh) | ((D >> 1) >> (63 - sh));
+        pd -= nb;
+        k &= 7;
+        // ordering point: the old D must be dead before the new D is requested, otherwise the
+        // compiler keeps both alive, copies at the loop back edge and waits vmcnt(0) for the copy
+        asm volatile("" ::"v"((uint32_t)C), "v"((uint32_t)(C >> 32)) : "memory");
+        D = ld64u(pd);
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(((C << k) >> 1) >> (63 - n)); }
+};
+
+// top n (0..31) bits of the 64-bit left-justified window T; n == 0 -> 0 (v_bfe_u32 width 0)
+__device__ __forceinline__ uint32_t top_bits(uint64_t T, uint32_t n)
+{
+    return __builtin_amdgcn_ubfe((uint32_t)(T >> 32), 32u - n, n);
+}
+
+// LDS after the cell slots and the constant table.  The decode wavefront hands every decoded
+// sequence to the helper wavefront through `queue` (all chains of a wavefront are at the same step
+// index, so one head / tail pair serves the whole wavefront).
+template <int DEPTH>
+struct SeqShared {
+    uint32_t progress[64];  // bytes of each chain's bitstream still unread (published every 32 steps)
+    uint32_t head;          // steps produced by the decode wavefront
+    uint32_t tail;          // steps consumed by the helper wavefront
+    uint32_t pad[2];
+    uint64_t queue[DEPTH][64];  // LL:17 | ML:18 | offset value:28 | valid:1
+};
+
 template <bool CELL16>
-__global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
-                                            uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
-                                            uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
-                                            BlockSum *sums)
+__global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
+                                             uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
+                                             uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
+                                             BlockSum *sums)
 {
     constexpr int NCH = CELL16 ? kSeqChains16 : kSeqChains32;
     constexpr int CELL_BYTES = CELL16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *CT = (uint32_t *)(smem + (size_t)NCH * kSeqCellsPerChain * CELL_BYTES);  // [2][64]
-    const int lane = threadIdx.x;
+    constexpr int kSeqQueueDepth = CELL16 ? kSeqQueue16 : kSeqQueue32;
+    SeqShared<kSeqQueueDepth> *shs = (SeqShared<kSeqQueueDepth> *)(CT + 128);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const uint32_t tid = blockIdx.x * NCH + lane;
     const bool has = lane < NCH && tid < n_tasks;
     SeqTask t;
@@ -259,11 +312,13 @@ __global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, cons
         t.n_seq = 0; t.in_size = 0; t.ll_off = t.of_off = t.ml_off = 0; t.ll_log = t.of_log = t.ml_log = 0;
         t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
     }
-    // constant tables
-    CT[lane] = lane < 36 ? (c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24)) : 0u;
-    CT[64 + lane] = lane < 53 ? (c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24)) : 0u;
-
-    // stage the three tables of every chain of this wavefront
+    if (wave == 0) {
+        CT[lane] = lane < 36 ? (c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24)) : 0u;
+        CT[64 + lane] = lane < 53 ? (c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24)) : 0u;
+        shs->progress[lane] = t.in_size;
+        if (lane == 0) { shs->head = 0; shs->tail = 0; }
+    }
+    // stage the three tables of every chain of this workgroup (both wavefronts copy)
     for (int ch = 0; ch < NCH; ch++) {
         if (blockIdx.x * NCH + ch >= n_tasks) break;
         uint32_t off[3], lg[3];
@@ -277,7 +332,7 @@ __global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, cons
         for (int kind = 0; kind < 3; kind++) {
             const uint32_t n = 1u << lg[kind];
             const uint32_t base = (uint32_t)ch * kSeqCellsPerChain + (uint32_t)kind * 512;
-            for (uint32_t i = lane; i < n; i += 64) {
+            for (uint32_t i = threadIdx.x; i < n; i += 128) {
                 uint32_t e = fse_entries[off[kind] + i];  // baseline(16) | nbits(8) | symbol(8)
                 uint32_t baseline = e & 0xFFFF, nb = (e >> 16) & 0xFF, sym = e >> 24;
                 if (CELL16) {
@@ -285,16 +340,94 @@ __global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, cons
                     ((uint16_t *)smem)[base + i] = (uint16_t)(next | (sym << 10));
                 } else {
                     uint32_t extra = kind == 0 ? c_ll_extra[min(sym, 35u)] : (kind == 1 ? c_ml_extra[min(sym, 52u)] : sym);
-                    ((uint32_t *)smem)[base + i] = baseline | (nb << 10) | (extra << 14) | (sym << 19);
+                    ((uint32_t *)smem)[base + i] = baseline | (nb << 10) | (extra << 14) | ((sym & 63) << 19);
                 }
             }
         }
     }
     __syncthreads();
 
+    // wave-uniform trip count in an SGPR; both wavefronts compute the same value
+    const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(has ? t.n_seq : 0u));
+
+    if (wave == 1) {
+        // ---- helper wavefront.  (1) It drains the sequence queue: repeat-offset resolution
+        // (sequence_execution.go:65-114) on a concrete-or-symbolic history, record packing, running
+        // sums, tile bases and ALL global stores -- so the decode wavefront never has a store in
+        // flight when it waits for its prefetched bits.  (2) It walks ahead of every chain's read
+        // cursor and touches the bitstream lines so that the decode wavefront's refills hit L2
+        // instead of stalling 64 lanes on one lane's HBM miss.
+        const uint8_t *sbase = in + t.in_off;
+        int low = (int)t.in_size;  // everything at or above `low` has been requested
+        uint32_t sink = 0;
+        constexpr int kAhead = 1024, kLine = 128;
+        int h0, h1, h2;
+        if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
+        else { h0 = -1; h1 = -2; h2 = -3; }
+        uint32_t litPos = 0, outPos = 0;
+        int status = MZD_OK;
+        uint64_t *myrec = recs + t.rec_off;
+        TileBase *mytile = tiles + t.tile_off;
+        uint32_t head_seen = 0;  // the counterpart's counter is only re-read when the cached value runs out
+        for (uint32_t j = 0; j < nmax; j++) {
+            if ((j & 31) == 0) {
+                const int cur = (int)__hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int target = max(cur - kAhead, 0);
+                int guard = 0;
+                while (has && low > target && guard < 16) {
+                    low = max(low - kLine, 0);
+                    sink ^= *(const volatile uint32_t *)(sbase + (low & ~3));
+                    guard++;
+                }
+            }
+            while (head_seen <= j) {
+                head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head_seen <= j) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            const uint64_t q = shs->queue[j % kSeqQueueDepth][lane];
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&shs->tail, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool act = (q >> 63) != 0 && status == MZD_OK;
+            const uint32_t LL = (uint32_t)q & kRecLlMask;
+            const uint32_t ML = (uint32_t)(q >> kRecMlShift) & kRecMlMask;
+            const uint32_t ofv = (uint32_t)(q >> kRecOffShift) & (kRecOffSymbolic - 1);
+            if ((j & 63) == 0 && act) mytile[j >> 6] = TileBase{litPos, outPos};
+            const bool isnew = ofv > 3;
+            const int idx = isnew ? 4 : (int)ofv - 1 + (LL == 0 ? 1 : 0);  // 0..3 repeat cases, 4 = new offset
+            int off = idx == 0 ? h0 : (idx == 1 ? h1 : (idx == 2 ? h2 : hist_dec(h0)));
+            if (isnew) off = (int)(ofv - 3);
+            if (act) {
+                if (off == 0) status = MZD_ERR_OFFSET;
+                if (idx >= 2) h2 = h1;
+                if (idx >= 1) { h1 = h0; h0 = off; }
+            }
+            if (act && status == MZD_OK) {
+                const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
+                myrec[j] = (uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)offfield << kRecOffShift);
+                litPos += LL;
+                outPos += LL + ML;
+                if (outPos > kBlockMax) status = MZD_ERR_CORRUPT_SIZES;  // a block regenerates <= 128 KiB
+            }
+        }
+        if (has && t.n_seq > 0) {
+            BlockSum *bs = &sums[t.block];
+            bs->lit_total = litPos;
+            bs->out_total = outPos;
+            bs->hist[0] = h0;
+            bs->hist[1] = h1;
+            bs->hist[2] = h2;
+            if (status != MZD_OK) atomicCAS(&bs->status, MZD_OK, status);
+        }
+        if (sink == 0x9E3779B9u && lane == 77) sums[0].pad[0] = sink;  // keeps the touches alive; never true
+        return;
+    }
+
+    // ---- decode wavefront: table lookups, bit fields, state updates -- and nothing else
     const uint32_t slot = (uint32_t)lane * kSeqCellsPerChain;
     const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
-    BackBits br;
+    SeqBits br;
     int rem = 0;
     int status = MZD_OK;
     uint32_t sL = 0, sM = 0, sO = 0;
@@ -313,139 +446,168 @@ __global__ __launch_bounds__(64) void k_seq(const uint8_t *__restrict__ in, cons
             if (rem < 0) status = MZD_ERR_SEQ_BITS;
         }
     } else {
-        br.s = in; br.C = br.D = 0; br.ptr = 0; br.k = 0;
+        br.pd = in; br.C = br.D = 0; br.k = 0;
     }
-    int h0, h1, h2;
-    if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
-    else { h0 = -1; h1 = -2; h2 = -3; }
-    uint32_t litPos = 0, outPos = 0;
-    uint64_t *myrec = recs + t.rec_off;
-    TileBase *mytile = tiles + t.tile_off;
+    const uint32_t sizeL = 1u << alL, sizeM = 1u << alM, sizeO = 1u << alO;
+    const int nbL0 = alL - 31, nbM0 = alM - 31, nbO0 = alO - 31;  // nbits = acc_log - 31 + clz(next)
 
-    const uint32_t nmax = wave_max_u32((has && status == MZD_OK) ? t.n_seq : 0u);
-    for (uint32_t i = 0; i < nmax; i++) {
-        const bool act = i < t.n_seq && status == MZD_OK;
+    // One sequence step.  SLOW == false is the hot variant: all six bit fields are cut from one
+    // 64-bit window; a lane that needs more than 64 - k bits (very long offsets / lengths) does
+    // NOT advance in that iteration ("stalls": every update is predicated off) and is reported
+    // through the return value.  The hot loop then leaves at its normal bottom, the stalled lanes
+    // run one SLOW step (refills between fields) outside it, and the loop resumes.  This keeps a
+    // single definition of every loop-carried register in the hot loop.
+    // Returns (stall, packed queue entry).
+    auto step = [&](auto slow_tag, uint32_t i, bool only, uint64_t &entry) -> bool {
+        constexpr bool SLOW = decltype(slow_tag)::value;
+        const bool base_act = only && i < t.n_seq && status == MZD_OK;
         const bool lastseq = (i + 1 == t.n_seq);
-        if (act && (i & 63) == 0) mytile[i >> 6] = TileBase{litPos, outPos};
-
         // ---- table cells for the three current states
         uint32_t symL, symM, symO, nbL, nbM, nbO, baseL, baseM, baseO, exL, exM;
+        uint32_t cl, cm;
         if (CELL16) {
             const uint16_t *c = (const uint16_t *)smem + slot;
-            uint32_t xl = c[sL], xm = c[512 + sM], xo = c[1024 + sO];
+            const uint32_t xl = c[sL], xm = c[512 + sM], xo = c[1024 + sO];
             symL = xl >> 10; symM = xm >> 10; symO = xo >> 10;
-            uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
-            nbL = (uint32_t)alL - (31 - __builtin_clz(nl | 1));
-            nbM = (uint32_t)alM - (31 - __builtin_clz(nm | 1));
-            nbO = (uint32_t)alO - (31 - __builtin_clz(no | 1));
-            baseL = (nl << nbL) - (1u << alL);
-            baseM = (nm << nbM) - (1u << alM);
-            baseO = (no << nbO) - (1u << alO);
+            cl = CT[symL]; cm = CT[64 + symM];
+            const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
+            nbL = (uint32_t)(nbL0 + __builtin_clz(nl | 1));
+            nbM = (uint32_t)(nbM0 + __builtin_clz(nm | 1));
+            nbO = (uint32_t)(nbO0 + __builtin_clz(no | 1));
+            baseL = (nl << nbL) - sizeL;
+            baseM = (nm << nbM) - sizeM;
+            baseO = (no << nbO) - sizeO;
+            exL = cl >> 24; exM = cm >> 24;
         } else {
             const uint32_t *c = (const uint32_t *)smem + slot;
-            uint32_t el = c[sL], em = c[512 + sM], eo = c[1024 + sO];
+            const uint32_t el = c[sL], em = c[512 + sM], eo = c[1024 + sO];
             baseL = el & 1023; nbL = (el >> 10) & 15; exL = (el >> 14) & 31; symL = el >> 19;
             baseM = em & 1023; nbM = (em >> 10) & 15; exM = (em >> 14) & 31; symM = em >> 19;
             baseO = eo & 1023; nbO = (eo >> 10) & 15; symO = eo >> 19;
+            cl = CT[symL]; cm = CT[64 + symM];
         }
-        const uint32_t cl = CT[symL], cm = CT[64 + symM];
-        if (CELL16) { exL = cl >> 24; exM = cm >> 24; }
         const uint32_t exO = symO;
         if (lastseq) { nbL = 0; nbM = 0; nbO = 0; }  // no state update after the last sequence (sequences.go:178)
-        const int total = (int)(exO + exM + exL + nbL + nbM + nbO);
+        // cumulative bit offsets in stream order: OF extra, ML extra, LL extra, LL state, ML state, OF state
+        const uint32_t o2 = exO + exM, o3 = o2 + exL, o4 = o3 + nbL, o5 = o4 + nbM;
+        const int total = (int)(o5 + nbO);
 
-        // ---- bits, in stream order: OF extra, ML extra, LL extra, LL state, ML state, OF state
-        br.refill();
         uint32_t ofx, mlx, llx, aL, aM, aO;
-        const bool slow = act && (br.k + total > 64);
-        if (__any(slow)) {  // rare: very long offsets/lengths; refill between fields
-            ofx = br.peek((int)exO); br.k += (int)exO; br.refill();
-            mlx = br.peek((int)exM); br.k += (int)exM;
-            llx = br.peek((int)exL); br.k += (int)exL; br.refill();
-            aL = br.peek((int)nbL); br.k += (int)nbL;
-            aM = br.peek((int)nbM); br.k += (int)nbM;
-            aO = br.peek((int)nbO); br.k += (int)nbO;
+        bool act, stall = false;
+        if (!SLOW) {
+            stall = base_act && (br.k + total > 64);
+            act = base_act && !stall;
+            const uint64_t T = br.C << br.k;
+            ofx = top_bits(T, exO);
+            mlx = top_bits(T << exO, exM);
+            llx = top_bits(T << o2, exL);
+            aL = top_bits(T << o3, nbL);
+            aM = top_bits(T << o4, nbM);
+            aO = top_bits(T << o5, nbO);
+            // idle, finished, failed and stalled lanes must not advance: the refill pointer is unclamped
+            br.k += act ? total : 0;
         } else {
-            uint64_t T = br.C << br.k;
-            ofx = (uint32_t)((T >> 1) >> (63 - exO)); T <<= exO;
-            mlx = (uint32_t)((T >> 1) >> (63 - exM)); T <<= exM;
-            llx = (uint32_t)((T >> 1) >> (63 - exL)); T <<= exL;
-            aL = (uint32_t)((T >> 1) >> (63 - nbL)); T <<= nbL;
-            aM = (uint32_t)((T >> 1) >> (63 - nbM)); T <<= nbM;
-            aO = (uint32_t)((T >> 1) >> (63 - nbO));
-            br.k += total;
+            act = base_act;
+            const uint32_t m = act ? 0xFFFFFFFFu : 0u;
+            const int wO = (int)(exO & m), wM = (int)(exM & m), wL = (int)(exL & m);
+            const int vL = (int)(nbL & m), vM = (int)(nbM & m), vO = (int)(nbO & m);
+            ofx = br.peek(wO); br.k += wO; br.refill();
+            mlx = br.peek(wM); br.k += wM;
+            llx = br.peek(wL); br.k += wL; br.refill();
+            aL = br.peek(vL); br.k += vL;
+            aM = br.peek(vM); br.k += vM;
+            aO = br.peek(vO); br.k += vO;
         }
-        if (act) {
-            rem -= total;
-            if (rem < 0) status = MZD_ERR_SEQ_BITS;  // over-read (cursor would pass -1)
-        }
-        // next states: state = Baseline + Read(NumberOfBits) (fse.go:282-290), order LL, ML, OF
-        // (masks are no-ops for valid tables; they keep idle / failed lanes inside their LDS slot)
-        sL = (baseL + aL) & 511; sM = (baseM + aM) & 511; sO = (baseO + aO) & 255;
-
         // ---- values (sequences.go:99-120)
         const uint32_t ofv = (1u << exO) + ofx;
         const uint32_t ML = (cm & 0xFFFFFF) + mlx;
         const uint32_t LL = (cl & 0xFFFFFF) + llx;
-
-        // ---- repeat-offset resolution (sequence_execution.go:65-114) on concrete-or-symbolic history
-        int off, n0, n1 = h1, n2 = h2;
-        if (ofv > 3) {
-            off = (int)(ofv - 3);
-            if (ofv - 3 >= kRecOffSymbolic && act) status = MZD_ERR_UNSUPPORTED;  // offset >= 2^28
-            n2 = h1; n1 = h0;
-        } else {
-            const int idx = (int)ofv - 1 + (LL == 0 ? 1 : 0);
-            off = idx == 0 ? h0 : (idx == 1 ? h1 : (idx == 2 ? h2 : hist_dec(h0)));
-            if (off == 0 && act) status = MZD_ERR_OFFSET;
-            if (idx >= 2) n2 = h1;
-            if (idx >= 1) n1 = h0;
+        if (act) {
+            rem -= total;
+            if (rem < 0) status = MZD_ERR_SEQ_BITS;  // over-read (cursor would pass -1)
+            if (ofv >= kRecOffSymbolic) status = MZD_ERR_UNSUPPORTED;  // offset value >= 2^28
+            // next states: state = Baseline + Read(NumberOfBits) (fse.go:282-290), order LL, ML, OF
+            // (the masks are no-ops for valid tables; they keep a failing lane inside its LDS slot)
+            sL = (baseL + aL) & 511; sM = (baseM + aM) & 511; sO = (baseO + aO) & 255;
         }
-        n0 = off;
-        if (act) { h0 = n0; h1 = n1; h2 = n2; }  // finished lanes keep their final history
-        if (act && status == MZD_OK) {
-            const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
-            myrec[i] = (uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)offfield << kRecOffShift);
-            litPos += LL;
-            outPos += LL + ML;
-            if (outPos > kBlockMax) status = MZD_ERR_CORRUPT_SIZES;  // a block regenerates <= 128 KiB
+        const bool emit = act && status == MZD_OK;
+        entry = emit ? ((uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)ofv << kRecOffShift) | (1ull << 63)) : 0ull;
+        return stall;
+    };
+
+    uint32_t i = 0;
+    uint32_t tail_seen = 0;
+    auto wait_space = [&](uint32_t at) {  // queue slot of step `at` is free once at - tail < depth
+        while (at - tail_seen >= (uint32_t)kSeqQueueDepth) {
+            tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)__hip_atomic_load(&shs->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (at - tail_seen >= (uint32_t)kSeqQueueDepth) __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    while (i < nmax) {
+        bool stalled = false;
+        bool any_stall = false;
+        uint64_t entry = 0;
+        do {
+            if ((i & 31) == 0 && has)  // bytes not yet requested by the refills (for the helper wavefront)
+                shs->progress[lane] = (uint32_t)max((int)(br.pd - (in + t.in_off)), 0);
+            br.refill();
+            stalled = step(std::false_type{}, i, true, entry);
+            any_stall = __any(stalled) != 0;
+            if (!any_stall) {
+                // hand the step to the helper wavefront (space in the queue: i - tail < depth)
+                wait_space(i);
+                shs->queue[i % kSeqQueueDepth][lane] = entry;
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&shs->head, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            i++;
+        } while (i < nmax && !any_stall);
+        if (any_stall) {
+            // lanes that advanced keep their entry; stalled lanes produce theirs now
+            uint64_t e2 = 0;
+            step(std::true_type{}, i - 1, stalled, e2);
+            if (stalled) entry = e2;
+            wait_space(i - 1);
+            shs->queue[(i - 1) % kSeqQueueDepth][lane] = entry;
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&shs->head, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     if (has && t.n_seq > 0) {
         if (status == MZD_OK && rem != 0) status = MZD_ERR_SEQ_BITS;  // sequences.go:197-204
-        BlockSum *bs = &sums[t.block];
-        bs->lit_total = litPos;
-        bs->out_total = outPos;
-        bs->hist[0] = h0;
-        bs->hist[1] = h1;
-        bs->hist[2] = h2;
-        if (status != MZD_OK) atomicCAS(&bs->status, MZD_OK, status);
+        if (status != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, status);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_exec: sequence execution + Raw/RLE blocks.  One workgroup (16 wavefronts) per frame.
+// k_exec: sequence execution + Raw/RLE blocks.  One workgroup per frame, several per CU.
 //
-// LDS layout:  [ block buffer 128 KiB + 32 ][ validity bitmap 16 KiB ][ control ]
-//   * the block being regenerated lives in LDS, shifted by `mis` so that LDS and HBM agree on
-//     16-byte alignment; matches into EARLIER blocks of the frame read HBM (already flushed);
-//   * validity bitmap: bit p set <=> output byte p of the block has been written.  Sequence
-//     execution is a DATAFLOW: a match copy runs as soon as exactly its source bytes are valid,
-//     so 64-sequence tiles execute on 16 wavefronts with no ordering between tiles and no false
+// The window (ringbuffer.go) is split in two: the CHUNK of the block currently being regenerated
+// lives in LDS (cap bytes, chunk boundaries fall on 64-sequence tile boundaries), everything older
+// is final and already in the frame's HBM slab.  LDS layout:
+//      [ chunk buffer cap + 32 ][ validity bitmap cap / 8 + 16 ][ control ]
+//   * a match whose source lies entirely before the chunk reads HBM/L2 with plain unaligned
+//     16-byte loads: nothing to wait for;
+//   * inside the chunk, execution is a DATAFLOW: bit p of the bitmap says "output byte p of the
+//     chunk is written"; a match copy runs as soon as exactly its source bytes are valid, so
+//     64-sequence tiles execute on all wavefronts with no ordering between tiles and no false
 //     dependencies (the reference's serial loop sequence_execution.go:16-53 is the degenerate
-//     schedule of the same dataflow graph).  Progress: the earliest unexecuted match of a block
-//     always has all its sources valid, and every wavefront walks its tiles in increasing order.
+//     schedule of the same graph).  Progress: the earliest unexecuted match of a chunk always has
+//     all its sources valid and every wavefront walks its tiles in increasing order;
+//   * a small LDS footprint keeps several frames resident per CU, which is what hides the
+//     dependency-chain latency of each one;
 //   * byte-misaligned LDS dword READS are replayed 64x on gfx950 (tools/ubench), misaligned dword
-//     WRITES are not: copies read aligned dwords, funnel-shift with v_alignbyte, write misaligned.
+//     WRITES are not: copies read aligned dwords, funnel-shift with v_alignbyte, write misaligned;
+//   * a tile that regenerates more than a chunk (one very long sequence) is executed in order
+//     straight in HBM by one wavefront.
 
 struct ExecShared {
     int error;
-    uint32_t pad[3];
+    uint32_t next_tile;  // first tile of the next chunk (written by thread 0)
+    uint32_t chunk_end;  // block-relative output position where the current chunk ends
+    uint32_t pad;
 };
-
-constexpr uint32_t kExecBufBytes = kBlockMax + 32;
-constexpr uint32_t kExecMapWords = kBlockMax / 32 + 4;  // one bit per output byte (+ slack for the w+1 probe)
-constexpr uint32_t kExecLdsBytes = kExecBufBytes + kExecMapWords * 4 + 16;
 
 __device__ __forceinline__ int sel3(uint32_t k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
 __device__ __forceinline__ int resolve_hist(int v, int H0, int H1, int H2)
@@ -472,7 +634,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
     return v;
 }
 
-// bit mask helpers for the validity bitmap: bits [bit, bit+n) of a 64-bit window, n <= 32
+// bits [bit, bit+n) of a 64-bit window, n <= 32
 __device__ __forceinline__ uint64_t span_mask(uint32_t bit, uint32_t n)
 {
     return ((n >= 32 ? 0xFFFFFFFFull : ((1ull << n) - 1))) << bit;
@@ -490,16 +652,74 @@ __device__ __forceinline__ void publish(uint32_t *vmap, uint32_t pos, uint32_t n
 __device__ __forceinline__ uint32_t ld32u_g(const uint8_t *p) { return ((const U32U *)p)->v; }
 __device__ __forceinline__ void st32u_l(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
 
+// stores n (1..16) bytes held in w0..w3 (+ wt = bytes [n-4, n) when n >= 4) to LDS at d
+__device__ __forceinline__ void lds_store_upto16(uint8_t *d, uint32_t n, uint32_t w0, uint32_t w1, uint32_t w2,
+                                                 uint32_t w3, uint32_t wt)
+{
+    if (n >= 4) st32u_l(d, w0);
+    if (n >= 8) st32u_l(d + 4, w1);
+    if (n >= 12) st32u_l(d + 8, w2);
+    if (n >= 16) st32u_l(d + 12, w3);
+    if (n >= 4 && (n & 3)) st32u_l(d + n - 4, wt);  // overlapped tail dword
+    if (n > 0 && n < 4) {
+        d[0] = (uint8_t)w0;
+        if (n > 1) d[1] = (uint8_t)(w0 >> 8);
+        if (n > 2) d[2] = (uint8_t)(w0 >> 16);
+    }
+}
+
+// In-order execution of one tile straight in HBM by one wavefront (tiles that regenerate more
+// than a chunk).  Every copy is wavefront-cooperative; writes are made visible before the next
+// copy reads them (same CU: s_waitcnt is enough at workgroup scope).
+__device__ void exec_tile_in_hbm(uint8_t *out, uint64_t outPos, const uint8_t *lits, bool litRle, uint32_t rleWord,
+                                 uint32_t LL, uint32_t ML, int off, uint32_t dstL, uint32_t dstM, uint32_t srcL,
+                                 bool valid, int lane)
+{
+    for (int sIdx = 0; sIdx < 64; sIdx++) {
+        const uint32_t v = (uint32_t)__shfl((int)valid, sIdx, 64);
+        if (!v) break;
+        const uint32_t ll = (uint32_t)__shfl((int)LL, sIdx, 64), ml = (uint32_t)__shfl((int)ML, sIdx, 64);
+        const uint32_t dl = (uint32_t)__shfl((int)dstL, sIdx, 64), dm = (uint32_t)__shfl((int)dstM, sIdx, 64);
+        const uint32_t sl = (uint32_t)__shfl((int)srcL, sIdx, 64);
+        const uint32_t o = (uint32_t)__shfl(off, sIdx, 64);
+        uint8_t *d = out + outPos + dl;
+        if (litRle) for (uint32_t j = lane; j < ll; j += 64) d[j] = (uint8_t)rleWord;
+        else for (uint32_t j = lane; j < ll; j += 64) d[j] = lits[sl + j];
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): literal bytes are in memory before a match may read them
+        if (ml == 0 || o == 0) continue;
+        uint8_t *dmP = out + outPos + dm;
+        const uint8_t *sp = dmP - o;
+        if (o >= 64) {
+            for (uint32_t base = 0; base < ml; base += 64) {  // each 64-byte step reads only finished bytes
+                const uint32_t j = base + lane;
+                uint8_t b = 0;
+                if (j < ml) b = sp[j];
+                if (j < ml) dmP[j] = b;
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+        } else {
+            uint32_t r = (uint32_t)lane % o;  // periodic fill from the final pattern [sp, sp+o)
+            const uint32_t stepr = 64 % o;
+            for (uint32_t j = lane; j < ml; j += 64) {
+                dmP[j] = sp[r];
+                r += stepr;
+                if (r >= o) r -= o;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
                                                const TileBase *__restrict__ tiles, const uint8_t *__restrict__ litbuf,
-                                               int32_t *frame_status, uint64_t *frame_out_len)
+                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *buf = smem;
-    uint32_t *vmap = (uint32_t *)(smem + kExecBufBytes);
-    ExecShared *sh = (ExecShared *)(smem + kExecBufBytes + kExecMapWords * 4);
+    uint8_t *buf = smem;                                        // cap + 32 bytes
+    uint32_t *vmap = (uint32_t *)(smem + cap + 32);             // cap / 32 + 4 words
+    ExecShared *sh = (ExecShared *)(smem + cap + 32 + (cap / 32 + 4) * 4);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
     const DFrame fr = frames[blockIdx.x];
@@ -548,252 +768,317 @@ __global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, u
             __syncthreads();
             break;
         }
-        const uint32_t mis = (uint32_t)((uintptr_t)(out + outPos) & 15);
-        uint8_t *lbuf = buf + mis;  // lbuf[p] = block-relative output byte p
         const uint8_t *lits = (b.lit_type == MZD_LIT_HUF ? litbuf : in) + b.lit_src;
         const bool litRle = b.lit_type == MZD_LIT_RLE;
         const uint32_t rleWord = litRle ? lits[0] * 0x01010101u : 0;
         const uint32_t ntiles = (b.n_seq + 63) >> 6;
-        if (ntiles) {
-            // clear the validity bits the sequences of this block will set
-            const uint32_t words = (seqOut + 31) >> 5;
-            for (uint32_t i = tid; i < words; i += nthr) vmap[i] = 0;
-        }
-        __syncthreads();
-
         const uint64_t *brec = recs + b.rec_off;
         const TileBase *btile = tiles + b.tile_off;
+        uint8_t *bout = out + outPos;  // HBM address of block-relative position 0
 
-        // software pipeline: records / tile bases of the NEXT tile are loaded while the current one runs
-        uint32_t tile = wave;
-        uint64_t rec_n = 0;
-        TileBase tb_n{0, 0};
-        if (tile < ntiles) {
-            const uint32_t si = tile * 64 + lane;
-            rec_n = si < b.n_seq ? brec[si] : 0ull;
-            tb_n = btile[tile];
-        }
-        for (; tile < ntiles; tile += nwaves) {
-            const uint64_t rec = rec_n;
-            const TileBase tb = tb_n;
-            {
-                const uint32_t nt = tile + nwaves;
-                if (nt < ntiles) {
-                    const uint32_t si = nt * 64 + lane;
-                    rec_n = si < b.n_seq ? brec[si] : 0ull;
-                    tb_n = btile[nt];
+        uint32_t t0 = 0;  // first tile of the current chunk
+        while (t0 < ntiles && sh->error == MZD_OK) {
+            // ---- chunk = maximal run of tiles [t0, t1) regenerating at most `cap` bytes
+            const uint32_t chunkStart = btile[t0].out_pos;
+            if (tid == 0) {
+                uint32_t lo = t0 + 1, hi = ntiles;  // largest t1 with out(t1) - chunkStart <= cap (out(ntiles) = seqOut)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    const uint32_t e = mid == ntiles ? seqOut : btile[mid].out_pos;
+                    if (e - chunkStart <= cap) lo = mid;
+                    else hi = mid - 1;
                 }
+                const uint32_t e = lo == ntiles ? seqOut : btile[lo].out_pos;
+                sh->next_tile = lo;
+                sh->chunk_end = e;
             }
-            const bool valid = tile * 64 + lane < b.n_seq;
-            const uint32_t LL = (uint32_t)rec & kRecLlMask;
-            const uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;
-            const uint32_t offf = (uint32_t)(rec >> kRecOffShift) & kRecOffMask;
-            int off = (int)offf;
-            if (offf & kRecOffSymbolic) {
-                uint32_t u = offf & (kRecOffSymbolic - 1);
-                off = sel3(u & 3, H0, H1, H2) - (int)(u >> 2);
+            __syncthreads();
+            const uint32_t t1 = sh->next_tile;
+            const uint32_t chunkEnd = sh->chunk_end;
+            const uint32_t chunkLen = chunkEnd - chunkStart;
+            if (chunkLen > cap) {
+                // ---- oversized tile: in-order execution in HBM by wavefront 0
+                if (wave == 0) {
+                    const uint32_t si = t0 * 64 + lane;
+                    const bool valid = si < b.n_seq;
+                    const uint64_t rec = valid ? brec[si] : 0ull;
+                    const uint32_t LL = (uint32_t)rec & kRecLlMask;
+                    const uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;
+                    const uint32_t offf = (uint32_t)(rec >> kRecOffShift) & kRecOffMask;
+                    int off = (int)offf;
+                    if (offf & kRecOffSymbolic) {
+                        uint32_t u = offf & (kRecOffSymbolic - 1);
+                        off = sel3(u & 3, H0, H1, H2) - (int)(u >> 2);
+                    }
+                    const TileBase tb = btile[t0];
+                    const uint32_t litEnd = tb.lit_pos + wave_incl_scan_dpp(LL);
+                    const uint32_t outEnd = tb.out_pos + wave_incl_scan_dpp(LL + ML);
+                    const uint32_t dstM = outEnd - ML, dstL = dstM - LL, srcL = litEnd - LL;
+                    const bool bad = valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstM);
+                    if (__any(bad)) {
+                        if (lane == 0) atomicMax(&sh->error, MZD_ERR_OFFSET);
+                    } else {
+                        exec_tile_in_hbm(out, outPos, lits, litRle, rleWord, LL, ML, off, dstL, dstM, srcL, valid, lane);
+                    }
+                }
+                __syncthreads();
+                t0 = t1;
+                continue;
             }
-            const uint32_t litEnd = tb.lit_pos + wave_incl_scan_dpp(LL);
-            const uint32_t outEnd = tb.out_pos + wave_incl_scan_dpp(LL + ML);
-            const uint32_t dstM = outEnd - ML, dstL = dstM - LL, srcL = litEnd - LL;
-            const bool bad = valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstM);  // ringbuffer.go:206-214
-            if (__any(bad)) {
-                if (lane == 0) atomicMax(&sh->error, MZD_ERR_OFFSET);
-            }
-            const int srcM = (int)dstM - off;  // block-relative; negative = earlier blocks (HBM)
+            const uint32_t mis = (uint32_t)((uintptr_t)(bout + chunkStart) & 15);
+            uint8_t *lbuf = buf + mis;  // lbuf[q] = chunk-relative output byte q
+            for (uint32_t i = tid; i < ((chunkLen + 31) >> 5) + 1; i += nthr) vmap[i] = 0;
+            __syncthreads();
 
-            // ---- literals (sequence_execution.go:19-34): they depend on nothing
-            {
-                const uint32_t sLL = (valid && LL <= 16) ? LL : 0;
-                if (__any(sLL != 0)) {
-                    uint32_t w0 = rleWord, w1 = rleWord, w2 = rleWord, w3 = rleWord, wt = rleWord;
-                    if (!litRle && sLL) {
-                        const U128U v = *(const U128U *)(lits + srcL);
-                        w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
-                        if (sLL >= 4) wt = ld32u_g(lits + srcL + sLL - 4);
-                    }
-                    uint8_t *d = lbuf + dstL;
-                    if (sLL >= 4) st32u_l(d, w0);
-                    if (sLL >= 8) st32u_l(d + 4, w1);
-                    if (sLL >= 12) st32u_l(d + 8, w2);
-                    if (sLL >= 16) st32u_l(d + 12, w3);
-                    if (sLL >= 4 && (sLL & 3)) st32u_l(d + sLL - 4, wt);  // overlapped tail dword
-                    if (sLL > 0 && sLL < 4) {
-                        d[0] = (uint8_t)w0;
-                        if (sLL > 1) d[1] = (uint8_t)(w0 >> 8);
-                        if (sLL > 2) d[2] = (uint8_t)(w0 >> 16);
-                    }
-                    if (sLL) publish(vmap, dstL, sLL);
-                }
-                uint64_t longs = __ballot(valid && LL > 16);
-                while (longs) {
-                    const int src = __builtin_ctzll(longs);
-                    longs &= longs - 1;
-                    const uint32_t n = (uint32_t)__shfl((int)LL, src, 64);
-                    const uint32_t d = (uint32_t)__shfl((int)dstL, src, 64);
-                    const uint32_t s = (uint32_t)__shfl((int)srcL, src, 64);
-                    if (litRle) for (uint32_t j = lane; j < n; j += 64) lbuf[d + j] = (uint8_t)rleWord;
-                    else for (uint32_t j = lane; j < n; j += 64) lbuf[d + j] = lits[s + j];
-                    // publish: lane k owns bytes [32k, 32k+32) of the run per round of 2 KiB
-                    for (uint32_t j = lane * 32; j < n; j += 64 * 32) publish(vmap, d + j, min(32u, n - j));
-                }
+            // software pipeline: records / tile bases of the NEXT tile are loaded while the current one runs
+            uint32_t tile = t0 + wave;
+            uint64_t rec_n = 0;
+            TileBase tb_n{0, 0};
+            if (tile < t1) {
+                const uint32_t si = tile * 64 + lane;
+                rec_n = si < b.n_seq ? brec[si] : 0ull;
+                tb_n = btile[tile];
             }
+            for (; tile < t1; tile += nwaves) {
+                const uint64_t rec = rec_n;
+                const TileBase tb = tb_n;
+                {
+                    const uint32_t nt = tile + nwaves;
+                    if (nt < t1) {
+                        const uint32_t si = nt * 64 + lane;
+                        rec_n = si < b.n_seq ? brec[si] : 0ull;
+                        tb_n = btile[nt];
+                    }
+                }
+                const bool valid = tile * 64 + lane < b.n_seq;
+                const uint32_t LL = (uint32_t)rec & kRecLlMask;
+                const uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;
+                const uint32_t offf = (uint32_t)(rec >> kRecOffShift) & kRecOffMask;
+                int off = (int)offf;
+                if (offf & kRecOffSymbolic) {
+                    uint32_t u = offf & (kRecOffSymbolic - 1);
+                    off = sel3(u & 3, H0, H1, H2) - (int)(u >> 2);
+                }
+                const uint32_t litEnd = tb.lit_pos + wave_incl_scan_dpp(LL);
+                const uint32_t outEnd = tb.out_pos + wave_incl_scan_dpp(LL + ML);
+                const uint32_t dstMb = outEnd - ML, srcL = litEnd - LL;  // block-relative
+                const bool bad = valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstMb);  // ringbuffer.go:206-214
+                if (__any(bad)) {
+                    if (lane == 0) atomicMax(&sh->error, MZD_ERR_OFFSET);
+                }
+                // chunk-relative positions
+                const uint32_t dstM = dstMb - chunkStart, dstL = dstM - LL;
+                const int srcM = (int)dstM - off;  // < 0: before the chunk (final, in HBM)
 
-            // ---- matches (sequence_execution.go:43-49, ringbuffer.go:242-277) as dataflow
-            bool pending = valid && ML > 0 && !bad;
-            const uint32_t span = min(ML, (uint32_t)max(off, 1));  // bytes that are true sources
-            const bool isShort = ML <= 32;
-            const bool overlap = (uint32_t)off < ML;
-            uint32_t spins = 0;
-            while (__any(pending)) {
-                // readiness of short matches: all source bytes at positions >= 0 must be valid
-                bool ready = false;
-                if (pending && isShort) {
-                    const int s0 = max(srcM, 0), s1 = srcM + (int)span;  // [s0, s1) inside this block
-                    if (s1 <= s0) ready = true;
-                    else {
-                        const uint64_t m = span_mask((uint32_t)s0 & 31, (uint32_t)(s1 - s0));
-                        const uint32_t w = (uint32_t)s0 >> 5;
-                        const uint32_t v0 = __hip_atomic_load(&vmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t v1 = __hip_atomic_load(&vmap[w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint64_t v = (uint64_t)v0 | ((uint64_t)v1 << 32);
-                        ready = (v & m) == m;
-                    }
-                }
-                asm volatile("" ::: "memory");  // data reads below stay below the validity reads
-                bool progressed = false;
-                // (1) short non-overlapping matches entirely inside this block: dword path
-                const bool fast = ready && !overlap && srcM >= 0;
-                if (__any(fast)) {
-                    progressed = true;
-                    uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    uint32_t t0 = 0, t1 = 0;
-                    // aligned dwords covering the source bytes [sbyte, sbyte + ML) of the LDS buffer
-                    const uint32_t sbyte = fast ? (mis + (uint32_t)srcM) : 0;
-                    const uint32_t sa = sbyte & 3;
-                    const uint32_t *base = (const uint32_t *)(buf + (sbyte & ~3u));
-                    const uint32_t ndw = fast ? ((sa + ML + 3) >> 2) : 0;
-#pragma unroll
-                    for (int j = 0; j < 9; j++)
-                        if ((uint32_t)j < ndw) w[j] = base[j];
-                    const uint32_t tb_byte = sbyte + ML - 4;  // tail dword = source bytes [ML-4, ML)
-                    if (fast && ML >= 4 && (ML & 3)) {
-                        const uint32_t *tp = (const uint32_t *)(buf + (tb_byte & ~3u));
-                        t0 = tp[0];
-                        t1 = tp[1];
-                    }
-                    if (fast) {
-                        uint8_t *d = lbuf + dstM;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            if ((uint32_t)(4 * j + 4) <= ML) st32u_l(d + 4 * j, __builtin_amdgcn_alignbyte(w[j + 1], w[j], sa));
+                // ---- literals (sequence_execution.go:19-34): they depend on nothing
+                {
+                    const uint32_t sLL = (valid && LL <= 16) ? LL : 0;
+                    if (__any(sLL != 0)) {
+                        uint32_t w0 = rleWord, w1 = rleWord, w2 = rleWord, w3 = rleWord, wt = rleWord;
+                        if (!litRle && sLL) {
+                            const U128U v = *(const U128U *)(lits + srcL);
+                            w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+                            if (sLL >= 4) wt = ld32u_g(lits + srcL + sLL - 4);
                         }
-                        if (ML >= 4 && (ML & 3)) st32u_l(d + ML - 4, __builtin_amdgcn_alignbyte(t1, t0, tb_byte & 3));
-                        if (ML < 4) {  // ML == 3 (or less on odd streams)
-                            const uint32_t x = __builtin_amdgcn_alignbyte(w[1], w[0], sa);
-                            if (ML > 0) d[0] = (uint8_t)x;
-                            if (ML > 1) d[1] = (uint8_t)(x >> 8);
-                            if (ML > 2) d[2] = (uint8_t)(x >> 16);
-                        }
-                        publish(vmap, dstM, ML);
+                        lds_store_upto16(lbuf + dstL, sLL, w0, w1, w2, w3, wt);
+                        if (sLL) publish(vmap, dstL, sLL);
                     }
-                }
-                // (2) short matches that overlap themselves or reach into earlier blocks: byte loop
-                const bool slowb = ready && !fast;
-                if (__any(slowb)) {
-                    progressed = true;
-                    const uint32_t n = slowb ? ML : 0;
-                    const uint32_t nmax = wave_max_u32(n);
-                    for (uint32_t j = 0; j < nmax; j++) {
-                        if (j < n) {
-                            const int q = srcM + (int)j;
-                            const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
-                            lbuf[dstM + j] = v;
-                        }
-                    }
-                    if (slowb) publish(vmap, dstM, ML);
-                }
-                pending = pending && !ready;
-                // (3) at most one long match per iteration, whole wavefront, non-blocking readiness test
-                uint64_t longs = __ballot(pending && !isShort);
-                if (longs) {
-                    const int src = __builtin_ctzll(longs);
-                    const uint32_t n = (uint32_t)__shfl((int)ML, src, 64);
-                    const uint32_t d = (uint32_t)__shfl((int)dstM, src, 64);
-                    const int s = __shfl(srcM, src, 64);
-                    const uint32_t o = (uint32_t)__shfl(off, src, 64);
-                    const uint32_t sp2 = (uint32_t)__shfl((int)span, src, 64);
-                    // readiness: every valid-map word overlapping [max(s,0), s+sp2) must be complete there
-                    bool ok = true;
-                    const int s0 = max(s, 0), s1 = s + (int)sp2;
-                    if (s1 > s0) {
-                        const uint32_t wf = (uint32_t)s0 >> 5, wl = (uint32_t)(s1 - 1) >> 5;
-                        for (uint32_t wi = wf + lane; wi <= wl; wi += 64) {
-                            uint32_t need = 0xFFFFFFFFu;
-                            if (wi == wf) need &= 0xFFFFFFFFu << ((uint32_t)s0 & 31);
-                            if (wi == wl) need &= 0xFFFFFFFFu >> (31 - ((uint32_t)(s1 - 1) & 31));
-                            const uint32_t v = __hip_atomic_load(&vmap[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            ok = ok && ((v & need) == need);
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-                    if (__all(ok)) {
-                        progressed = true;
-                        if (o >= 64) {
-                            // each 64-byte step only reads bytes written by earlier steps (in-order LDS)
-                            for (uint32_t j = lane; j < n; j += 64) {
-                                const int q = s + (int)j;
-                                const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
-                                lbuf[d + j] = v;
-                            }
-                        } else {
-                            // overlapping: periodic fill from the (final) pattern [s, s+o)
-                            uint32_t r = (uint32_t)lane % o;
-                            const uint32_t stepr = 64 % o;
-                            for (uint32_t j = lane; j < n; j += 64) {
-                                const int q = s + (int)r;
-                                const uint8_t v = q >= 0 ? lbuf[q] : out[(int64_t)outPos + q];
-                                lbuf[d + j] = v;
-                                r += stepr;
-                                if (r >= o) r -= o;
-                            }
-                        }
+                    uint64_t longs = __ballot(valid && LL > 16);
+                    while (longs) {
+                        const int src = __builtin_ctzll(longs);
+                        longs &= longs - 1;
+                        const uint32_t n = (uint32_t)__shfl((int)LL, src, 64);
+                        const uint32_t d = (uint32_t)__shfl((int)dstL, src, 64);
+                        const uint32_t s = (uint32_t)__shfl((int)srcL, src, 64);
+                        if (litRle) for (uint32_t j = lane; j < n; j += 64) lbuf[d + j] = (uint8_t)rleWord;
+                        else for (uint32_t j = lane; j < n; j += 64) lbuf[d + j] = lits[s + j];
                         for (uint32_t j = lane * 32; j < n; j += 64 * 32) publish(vmap, d + j, min(32u, n - j));
-                        if (lane == src) pending = false;
                     }
                 }
-                if (!progressed) {
-                    if ((++spins & 15) == 0 &&
-                        __hip_atomic_load(&sh->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != MZD_OK)
-                        break;  // corrupt input: a skipped match would never validate its bytes
-                    __builtin_amdgcn_s_sleep(1);
+
+                // ---- matches (sequence_execution.go:43-49, ringbuffer.go:242-277)
+                bool pending = valid && ML > 0 && !bad;
+                const bool overlap = (uint32_t)off < ML;
+                const uint32_t span = overlap ? (uint32_t)max(off, 1) : ML;  // bytes that are true sources
+                // (a) short matches sourced entirely before the chunk: final bytes in HBM, no waiting
+                {
+                    const bool g = pending && ML <= 32 && !overlap && srcM + (int)ML <= 0;
+                    if (__any(g)) {
+                        const uint8_t *sp = bout + (int)chunkStart + srcM;  // may point into earlier blocks
+                        U128U a{0, 0, 0, 0}, c{0, 0, 0, 0};
+                        uint32_t wt = 0;
+                        if (g) {
+                            a = *(const U128U *)sp;
+                            if (ML > 16) c = *(const U128U *)(sp + 16);
+                            if (ML >= 4) wt = ld32u_g(sp + ML - 4);
+                        }
+                        if (g) {
+                            uint8_t *d = lbuf + dstM;
+                            if (ML <= 16) lds_store_upto16(d, ML, a.x, a.y, a.z, a.w, wt);
+                            else {
+                                lds_store_upto16(d, 16, a.x, a.y, a.z, a.w, 0);
+                                lds_store_upto16(d + 16, ML - 16, c.x, c.y, c.z, c.w, wt);
+                            }
+                            publish(vmap, dstM, ML);
+                        }
+                        pending = pending && !g;
+                    }
+                }
+                // (b) everything else: dataflow on the validity bitmap
+                const bool isShort = ML <= 32;
+                // readiness mask of a short match: source bytes that lie inside the chunk
+                const int s0 = max(srcM, 0), s1 = srcM + (int)span;
+                const uint64_t needm = (isShort && s1 > s0) ? span_mask((uint32_t)s0 & 31, (uint32_t)(s1 - s0)) : 0ull;
+                const uint32_t needw = (uint32_t)s0 >> 5;
+                const bool fastKind = isShort && !overlap && srcM >= 0;
+                uint32_t spins = 0;
+                while (__any(pending)) {
+                    bool ready = false;
+                    if (pending && isShort) {
+                        const uint32_t v0 = __hip_atomic_load(&vmap[needw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t v1 = __hip_atomic_load(&vmap[needw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint64_t v = (uint64_t)v0 | ((uint64_t)v1 << 32);
+                        ready = (v & needm) == needm;
+                    }
+                    asm volatile("" ::: "memory");  // data reads below stay below the validity reads
+                    bool progressed = false;
+                    // (b1) short, non-overlapping, source inside the chunk: aligned dword reads + funnel
+                    const bool fast = ready && fastKind;
+                    if (__any(fast)) {
+                        progressed = true;
+                        // wave-uniform bound on the dword loop from two ballots (a shuffle reduction costs ~450 cycles)
+                        const uint32_t mlc = __any(fast && ML > 16) ? 32u : (__any(fast && ML > 8) ? 16u : 8u);
+                        const uint32_t sbyte = fast ? (mis + (uint32_t)srcM) : 0;
+                        const uint32_t sa = sbyte & 3;
+                        const uint32_t *base = (const uint32_t *)(buf + (sbyte & ~3u));
+                        uint8_t *d = lbuf + dstM;
+                        uint32_t prev = fast ? base[0] : 0;
+                        uint32_t first = 0;
+                        for (uint32_t j = 0; 4 * j < mlc; j++) {
+                            const bool on = fast && 4 * j < ML;
+                            const uint32_t nxt = on ? base[j + 1] : 0;
+                            const uint32_t x = __builtin_amdgcn_alignbyte(nxt, prev, sa);
+                            if (j == 0) first = x;
+                            if (fast && 4 * j + 4 <= ML) st32u_l(d + 4 * j, x);
+                            prev = nxt;
+                        }
+                        if (fast) {
+                            if (ML >= 4 && (ML & 3)) {
+                                const uint32_t tb_byte = sbyte + ML - 4;  // tail dword = source bytes [ML-4, ML)
+                                const uint32_t *tp = (const uint32_t *)(buf + (tb_byte & ~3u));
+                                st32u_l(d + ML - 4, __builtin_amdgcn_alignbyte(tp[1], tp[0], tb_byte & 3));
+                            }
+                            if (ML < 4) {
+                                if (ML > 0) d[0] = (uint8_t)first;
+                                if (ML > 1) d[1] = (uint8_t)(first >> 8);
+                                if (ML > 2) d[2] = (uint8_t)(first >> 16);
+                            }
+                            publish(vmap, dstM, ML);
+                        }
+                    }
+                    // (b2) short matches that overlap themselves or straddle the chunk start: byte loop
+                    const bool slowb = ready && !fastKind;
+                    if (__any(slowb)) {
+                        progressed = true;
+                        const uint32_t n = slowb ? ML : 0;
+                        const uint32_t nmax = wave_max_u32(n);
+                        const uint8_t *gsrc = bout + (int)chunkStart;  // HBM address of chunk-relative position 0
+                        for (uint32_t j = 0; j < nmax; j++) {
+                            if (j < n) {
+                                const int q = srcM + (int)j;
+                                const uint8_t v = q >= 0 ? lbuf[q] : gsrc[q];
+                                lbuf[dstM + j] = v;
+                            }
+                        }
+                        if (slowb) publish(vmap, dstM, ML);
+                    }
+                    pending = pending && !ready;
+                    // (b3) at most one long match per iteration, whole wavefront, non-blocking readiness test
+                    const uint64_t longs = __ballot(pending && !isShort);
+                    if (longs) {
+                        const int src = __builtin_ctzll(longs);
+                        const uint32_t n = (uint32_t)__shfl((int)ML, src, 64);
+                        const uint32_t d = (uint32_t)__shfl((int)dstM, src, 64);
+                        const int s = __shfl(srcM, src, 64);
+                        const uint32_t o = (uint32_t)__shfl(off, src, 64);
+                        const uint32_t sp2 = (uint32_t)__shfl((int)span, src, 64);
+                        bool ok = true;
+                        const int q0 = max(s, 0), q1 = s + (int)sp2;
+                        if (q1 > q0) {
+                            const uint32_t wf = (uint32_t)q0 >> 5, wl = (uint32_t)(q1 - 1) >> 5;
+                            for (uint32_t wi = wf + lane; wi <= wl; wi += 64) {
+                                uint32_t need = 0xFFFFFFFFu;
+                                if (wi == wf) need &= 0xFFFFFFFFu << ((uint32_t)q0 & 31);
+                                if (wi == wl) need &= 0xFFFFFFFFu >> (31 - ((uint32_t)(q1 - 1) & 31));
+                                const uint32_t v = __hip_atomic_load(&vmap[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                ok = ok && ((v & need) == need);
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) {
+                            progressed = true;
+                            const uint8_t *gsrc = bout + (int)chunkStart;
+                            if (o >= 64) {
+                                // each 64-byte step only reads bytes written by earlier steps (in-order LDS)
+                                for (uint32_t j = lane; j < n; j += 64) {
+                                    const int q = s + (int)j;
+                                    const uint8_t v = q >= 0 ? lbuf[q] : gsrc[q];
+                                    lbuf[d + j] = v;
+                                }
+                            } else {
+                                // overlapping: periodic fill from the (final) pattern [s, s+o)
+                                uint32_t r = (uint32_t)lane % o;
+                                const uint32_t stepr = 64 % o;
+                                for (uint32_t j = lane; j < n; j += 64) {
+                                    const int q = s + (int)r;
+                                    const uint8_t v = q >= 0 ? lbuf[q] : gsrc[q];
+                                    lbuf[d + j] = v;
+                                    r += stepr;
+                                    if (r >= o) r -= o;
+                                }
+                            }
+                            for (uint32_t j = lane * 32; j < n; j += 64 * 32) publish(vmap, d + j, min(32u, n - j));
+                            if (lane == src) pending = false;
+                        }
+                    }
+                    if (!progressed) {
+                        if ((++spins & 15) == 0 &&
+                            __hip_atomic_load(&sh->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != MZD_OK)
+                            break;  // corrupt input: a skipped match would never validate its bytes
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                 }
             }
+            __syncthreads();
+            // ---- the chunk leaves for HBM: head bytes, aligned 16-byte body, tail bytes
+            {
+                uint8_t *dst = bout + chunkStart;
+                const uint32_t head = min(chunkLen, (16u - mis) & 15u);
+                if ((uint32_t)tid < head) dst[tid] = lbuf[tid];
+                const uint32_t body = (chunkLen - head) >> 4;
+                const uint4 *lsrc = (const uint4 *)(lbuf + head);  // 16-byte aligned in LDS by construction
+                uint4 *gdst = (uint4 *)(dst + head);
+                for (uint32_t i = tid; i < body; i += nthr) gdst[i] = lsrc[i];
+                for (uint32_t i = head + (body << 4) + tid; i < chunkLen; i += nthr) dst[i] = lbuf[i];
+            }
+            __syncthreads();  // flushed bytes are visible to the whole workgroup before the next chunk reads them
+            t0 = t1;
         }
-        // ---- literals after the last sequence (sequence_execution.go:55-59)
+        // ---- literals after the last sequence (sequence_execution.go:55-59): straight to HBM
         {
             const uint32_t rest = b.lit_regen - litTotal;
-            uint8_t *d = lbuf + seqOut;
+            uint8_t *d = bout + seqOut;
             if (litRle) {
-                for (uint32_t j = tid; j < rest; j += nthr) d[j] = (uint8_t)rleWord;
+                const uint32_t n16 = rest >> 4;
+                const U128U f{rleWord, rleWord, rleWord, rleWord};
+                for (uint32_t j = tid; j < n16; j += nthr) *(U128U *)(d + 16 * j) = f;
+                for (uint32_t j = (n16 << 4) + tid; j < rest; j += nthr) d[j] = (uint8_t)rleWord;
             } else {
                 const uint8_t *s = lits + litTotal;
-                const uint32_t n4 = rest >> 2;
-                for (uint32_t j = tid; j < n4; j += nthr) st32u_l(d + 4 * j, ld32u_g(s + 4 * j));
-                for (uint32_t j = (n4 << 2) + tid; j < rest; j += nthr) d[j] = s[j];
+                const uint32_t n16 = rest >> 4;
+                for (uint32_t j = tid; j < n16; j += nthr) *(U128U *)(d + 16 * j) = *(const U128U *)(s + 16 * j);
+                for (uint32_t j = (n16 << 4) + tid; j < rest; j += nthr) d[j] = s[j];
             }
-        }
-        __syncthreads();
-        // ---- the block leaves for HBM: head bytes, aligned 16-byte body, tail bytes
-        {
-            uint8_t *dst = out + outPos;
-            const uint32_t head = min(blockOut, (16u - mis) & 15u);
-            if ((uint32_t)tid < head) dst[tid] = lbuf[tid];
-            const uint32_t body = (blockOut - head) >> 4;
-            const uint4 *lsrc = (const uint4 *)(lbuf + head);  // 16-byte aligned in LDS by construction
-            uint4 *gdst = (uint4 *)(dst + head);
-            for (uint32_t i = tid; i < body; i += nthr) gdst[i] = lsrc[i];
-            for (uint32_t i = head + (body << 4) + tid; i < blockOut; i += nthr) dst[i] = lbuf[i];
         }
         {
             // offset history carried to the next block (framedecompressor.go:23; persists across blocks)

@@ -663,6 +663,7 @@ const mzd_batch *mzd_plan_finalize(mzd_plan *p)
         p->frames[i].out_capacity = p->frame_bound[i];
         at += (p->frame_bound[i] + 255) & ~255ull;
     }
+    at += 256;  // tail slack: the execution kernel's 16-byte source loads may run past the last slab
     mzd_batch &v = p->view;
     v = mzd_batch{};
     v.abi_version = MZD_ABI_VERSION;
