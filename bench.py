@@ -57,20 +57,23 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
         per = (count + nthreads - 1) // nthreads
         outs = []
         ths = []
-        t0 = time.perf_counter()
         for t in range(nthreads):
             a, b = first + t * per, min(first + count, first + (t + 1) * per)
             if a >= b:
                 continue
             n = b - a
-            dst = np.empty(n * frame_bytes, dtype=np.uint8)
-            doff = (np.arange(n, dtype=np.uint64) * np.uint64(frame_bytes))
+            # every frame of a thread regenerates into the same pre-faulted buffer: the baseline is
+            # not charged for page faults or for writing 8 GB to DRAM (optimistic for the CPU)
+            dst = np.zeros(frame_bytes + 64, dtype=np.uint8)
+            doff = np.zeros(n, dtype=np.uint64)
             dcap = np.full(n, frame_bytes, dtype=np.uint64)
             olen = np.empty(n, dtype=np.uint64)
             st = np.empty(n, dtype=np.int32)
             o = np.ascontiguousarray(off[a:b])
             l = np.ascontiguousarray(ln[a:b])
-            outs.append((dst, olen, st, o, l, doff, dcap))
+            outs.append((dst, olen, st, o, l, doff, dcap, n))
+        t0 = time.perf_counter()
+        for (dst, olen, st, o, l, doff, dcap, n) in outs:
             th = threading.Thread(target=orc.lib.orc_decode_frames,
                                   args=(blob.ctypes.data, o.ctypes.data, l.ctypes.data, n, dst.ctypes.data,
                                         doff.ctypes.data, dcap.ctypes.data, olen.ctypes.data, st.ctypes.data))
@@ -79,14 +82,21 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
         for th in ths:
             th.join()
         dt = time.perf_counter() - t0
-        ok = all(int(x[2].max()) == 0 for x in outs)
+        ok = all(int(x[2].max()) == 0 and int(x[1].min()) == frame_bytes for x in outs)
         return dt, ok
 
-    calib = min(n_total, 4 * cores)
+    calib = min(n_total, 8 * cores)
     dt, ok = run(0, calib, cores)
     rate = calib / max(dt, 1e-6)  # frames/s on all cores
     sample = int(max(calib, min(n_total, rate * budget_s)))
     dt, ok2 = run(0, sample, cores)
+    if sample == n_total and dt < 0.5 * budget_s:  # fast host: repeat the whole batch to fill the budget
+        reps = max(1, int(budget_s / max(dt, 1e-3)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _, okr = run(0, sample, cores)
+            ok2 = ok2 and okr
+        dt = (time.perf_counter() - t0) / reps
     return {"value": round(sample * frame_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
             "sample": f"first {sample} frames of the same batch, oracle (C restatement of the reference "
                       f"algorithm) on {cores} host threads, {dt:.1f}s", "ok": bool(ok and ok2)}
@@ -198,9 +208,19 @@ def main():
         path_ms = sum(v for k, v in kms.items() if v > 0)
         dom = max(kms, key=lambda k: kms[k]) if kms else None
         achieved = alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else None
+        # HBM traffic per launch from the committed PMC passes (profiles/r1_traffic.json): sum over the
+        # three kernels of FETCH_SIZE (raw, may under-count up to 2x) + WRITE_SIZE, only valid for the
+        # default workload / geometry it was measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if a.config == 4 and per == 65536:
+                traffic = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in tj["kernels"].items() if k != "k_init")
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": f"hot path = k_huf + k_seq + k_exec in sequence; dominant {dom}",
                 "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
                 "algorithmic_bytes_per_launch": alg,
@@ -219,8 +239,8 @@ def main():
                        "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes,
                        "sequences_per_frame": round(float(nseq.mean()), 1),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective",
-                       "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 256,
-                       "exec_chunk": a.exec_chunk or 32768},
+                       "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 128,
+                       "exec_chunk": a.exec_chunk or 8192},
             "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok,
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 2), "upload": round(t_upload, 2)},

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmzd.so")
+LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 

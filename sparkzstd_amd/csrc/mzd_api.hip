@@ -422,10 +422,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
     const bool cell16 = ctx->opt.seq_variant != 1;  // default: 2-byte LDS cells (63 chains per CU)
-    const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 256;
-    if (exec_threads % 64 || exec_threads > 1024) return MZD_ERR_INVALID_ARG;
-    // LDS chunk of the execution kernel: default 32 KiB (4 workgroups per CU); multiple of 1024
-    uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 32768;
+    const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 128;
+    if (exec_threads % 64 || exec_threads > 256) return MZD_ERR_INVALID_ARG;
+    // LDS chunk of the execution kernel: default 8 KiB (up to 16 workgroups per CU); multiple of 1024
+    uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 8192;
     exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
     const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16
                                   : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32;

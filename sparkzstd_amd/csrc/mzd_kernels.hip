@@ -710,7 +710,10 @@ __device__ void exec_tile_in_hbm(uint8_t *out, uint64_t outPos, const uint8_t *l
     }
 }
 
-__global__ __launch_bounds__(1024) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
+#ifndef MZD_EXEC_WAVES_PER_SIMD
+#define MZD_EXEC_WAVES_PER_SIMD 8
+#endif
+__global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
                                                const TileBase *__restrict__ tiles, const uint8_t *__restrict__ litbuf,
