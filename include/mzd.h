@@ -186,7 +186,10 @@ typedef struct mzd_options {
     uint32_t seq_variant;     /* sequence-decode kernel variant, see DESIGN.md */
     uint32_t exec_threads;    /* threads per frame in the execution kernel (multiple of 64) */
     uint32_t exec_chunk;      /* LDS window chunk of the execution kernel in bytes (multiple of 1024) */
-    uint32_t reserved[5];
+    uint32_t huf_min_lds;     /* minimum LDS bytes requested per Huffman workgroup (residency cap) */
+    uint32_t no_split;        /* 1: never overlap k_seq(tail) with k_exec(head) on a second stream */
+    uint32_t assume_cus;      /* testing: pretend the device has this many CUs when choosing the split */
+    uint32_t reserved[2];
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

@@ -22,8 +22,12 @@ struct mzd_ctx {
     hipStream_t stream = nullptr;
     mzd_options opt{};
     std::string last_error;
+    hipStream_t stream2 = nullptr;  // the execution kernel of the head of a split batch runs here
+    hipEvent_t ev_head_ready = nullptr, ev_head_done = nullptr;
+    int num_cus = 256;
     // HIP events around every kernel of every mzd_batch_run since the last mzd_timing_reset
-    std::vector<hipEvent_t> ev;  // 5 per run
+    std::vector<hipEvent_t> ev;  // kEvPerRun per run
+    std::vector<uint8_t> run_split;
     size_t runs = 0;
     bool timing = true;
     bool attr_set = false;
@@ -50,12 +54,14 @@ struct mzd_dbatch {
     // geometry
     uint32_t n_frames = 0, n_blocks = 0, n_huf_tasks = 0, n_seq_tasks = 0;
     uint32_t huf_slot_cells = 2;
+    std::vector<uint32_t> frame_seq_task;  // host: index of the first SeqTask of every frame (+ total)
     uint64_t out_size = 0;
     mzd_batch_stats stats{};
 };
 
 namespace {
 
+constexpr size_t kEvPerRun = 9;
 thread_local std::string g_create_error;
 
 #define HIP_TRY(ctx, expr)                                                                    \
@@ -134,10 +140,18 @@ mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err)
     mzd_ctx *c = new mzd_ctx();
     c->device = device;
     if (opt) c->opt = *opt;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_head_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming) != hipSuccess) {
         if (err) *err = MZD_ERR_DEVICE;
         delete c;
         return nullptr;
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->num_cus = prop.multiProcessorCount;
     }
     if (err) *err = MZD_OK;
     return c;
@@ -149,6 +163,9 @@ void mzd_destroy(mzd_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_head_ready) (void)hipEventDestroy(ctx->ev_head_ready);
+    if (ctx->ev_head_done) (void)hipEventDestroy(ctx->ev_head_done);
     delete ctx;
 }
 
@@ -229,7 +246,9 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     uint64_t rec_total = 0, tile_total = 0, lit_total = 0;
     mzd_batch_stats st{};
     auto in_range = [&](uint64_t off, uint64_t n) { return off <= b->in_size && n <= b->in_size - off; };
+    std::vector<uint32_t> frame_seq_task(b->n_frames + 1, 0);
     for (uint32_t f = 0; f < b->n_frames; f++) {
+        frame_seq_task[f] = (uint32_t)seq_tasks.size();
         const mzd_frame_desc &fd = b->frames[f];
         DFrame &df = frames[f];
         df.out_offset = fd.out_offset;
@@ -346,6 +365,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         }
         if (df.plan_status != MZD_OK) df.n_blocks = 0;
     }
+    frame_seq_task[b->n_frames] = (uint32_t)seq_tasks.size();
     st.table_bytes = (uint64_t)b->n_fse_entries * 4 + (uint64_t)b->n_huf_entries * 2;
     st.scratch_bytes = rec_total * 8 + tile_total * 8 + lit_total;
 
@@ -356,6 +376,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->n_huf_tasks = (uint32_t)huf_tasks.size();
     db->n_seq_tasks = (uint32_t)seq_tasks.size();
     db->huf_slot_cells = 1u << max_huf_bits;
+    db->frame_seq_task = std::move(frame_seq_task);
     db->out_size = b->out_size;
     db->stats = st;
     int rc = MZD_OK;
@@ -430,7 +451,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16
                                   : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32;
     const size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
-    const size_t huf_lds = (size_t)kHufQuads * db->huf_slot_cells * 2;
+    // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
+    // overflow L2 and every refill goes to MALL/HBM; a minimum LDS request per workgroup limits the
+    // number of resident wavefronts (opt.huf_min_lds bytes, default 48 KiB -> 3 wavefronts per CU)
+    const size_t huf_lds = std::max<size_t>((size_t)kHufQuads * db->huf_slot_cells * 2,
+                                            ctx->opt.huf_min_lds ? ctx->opt.huf_min_lds : 49152);
     if (!ctx->attr_set) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
@@ -441,16 +466,56 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
         ctx->attr_set = true;
     }
+    // ---- split point: k_seq runs ceil(tasks / (chains per CU * CUs)) rounds of one chain latency each and
+    // the last, partial round leaves most CUs idle.  The batch is cut at the frame where the full rounds
+    // end: k_seq(tail) then runs on the caller's stream while k_exec(head) fills the idle CUs from a
+    // second stream (frames are independent, so the two never touch the same data).
+    const uint32_t nch = cell16 ? kSeqChains16 : kSeqChains32;
+    const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
+    uint32_t fA = db->n_frames, tA = db->n_seq_tasks;
+    if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
+        const uint64_t lim = (db->n_seq_tasks / per_round) * per_round;
+        // last frame boundary at or below the limit
+        uint32_t lo = 0, hi = db->n_frames;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) / 2;
+            if (db->frame_seq_task[mid] <= lim) lo = mid;
+            else hi = mid - 1;
+        }
+        if (lo > 0 && lo < db->n_frames) {
+            fA = lo;
+            tA = db->frame_seq_task[lo];
+        }
+    }
+    const bool split = fA < db->n_frames;
+
     hipEvent_t *ev = nullptr;
     if (ctx->timing) {
-        if (ctx->runs >= 4096) ctx->runs = 0;  // bounded ring
-        while (ctx->ev.size() < (ctx->runs + 1) * 5) {
+        if (ctx->runs >= 1024) ctx->runs = 0;  // bounded ring
+        while (ctx->ev.size() < (ctx->runs + 1) * kEvPerRun) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreate(&e));
             ctx->ev.push_back(e);
         }
-        ev = ctx->ev.data() + ctx->runs * 5;
+        if (ctx->run_split.size() < ctx->runs + 1) ctx->run_split.resize(ctx->runs + 1);
+        ctx->run_split[ctx->runs] = split;
+        ev = ctx->ev.data() + ctx->runs * kEvPerRun;
     }
+    auto launch_seq = [&](uint32_t first, uint32_t count) {
+        if (!count) return;
+        if (cell16)
+            k_seq<true><<<(count + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
+                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+        else
+            k_seq<false><<<(count + kSeqChains32 - 1) / kSeqChains32, 128, seq_lds, s>>>(
+                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+    };
+    auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {
+        if (!count) return;
+        k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames + first, db->d_blocks, db->d_sums,
+                                                     db->d_recs, db->d_tiles, db->d_litbuf, db->d_status + first,
+                                                     db->d_out_len + first, exec_cap);
+    };
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
@@ -458,21 +523,27 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                              db->d_litbuf, db->d_sums, db->huf_slot_cells);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s));
-    if (db->n_seq_tasks) {
-        if (cell16)
-            k_seq<true><<<(db->n_seq_tasks + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
-                db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
-        else
-            k_seq<false><<<(db->n_seq_tasks + kSeqChains32 - 1) / kSeqChains32, 128, seq_lds, s>>>(
-                db->d_in, db->d_seq_tasks, db->n_seq_tasks, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
-    }
+    launch_seq(0, tA);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
-    if (db->n_frames)
-        k_exec<<<db->n_frames, exec_threads, exec_lds, s>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
-                                                           db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
-                                                           db->d_out_len, exec_cap);
+    if (split) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_head_ready, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_head_ready, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[6], ctx->stream2));
+        launch_exec(ctx->stream2, 0, fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[7], ctx->stream2));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, ctx->stream2));
+        launch_seq(tA, db->n_seq_tasks - tA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
+        launch_exec(s, fA, db->n_frames - fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_head_done, 0));  // the caller's stream sees the whole batch done
+    } else {
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
+        launch_exec(s, 0, db->n_frames);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
+    }
     if (ev) {
-        HIP_TRY(ctx, hipEventRecord(ev[4], s));
+        HIP_TRY(ctx, hipEventRecord(ev[8], s));
         ctx->runs++;
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -528,21 +599,30 @@ int mzd_decode_batch(mzd_ctx *ctx, const mzd_batch *batch, int32_t *status, uint
 
 int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
 {
-    static const char *kNames[4] = {"k_init", "k_huf", "k_seq", "k_exec"};
+    // k_seq / k_exec: sum of their launches (head + tail of a split batch; those overlap in time);
+    // "path": first event to last completion of the whole hot path (what the roofline divides by)
+    static const char *kNames[5] = {"k_init", "k_huf", "k_seq", "k_exec", "path"};
     if (!ctx || ctx->runs == 0) return 0;
+    double acc[5] = {0, 0, 0, 0, 0};
+    size_t cnt = 0;
+    auto el = [](hipEvent_t a, hipEvent_t b) {
+        float t = 0;
+        return hipEventElapsedTime(&t, a, b) == hipSuccess ? (double)t : 0.0;
+    };
+    for (size_t r = 0; r < ctx->runs; r++) {
+        hipEvent_t *e = ctx->ev.data() + r * kEvPerRun;
+        const bool split = ctx->run_split[r];
+        acc[0] += el(e[0], e[1]);
+        acc[1] += el(e[1], e[2]);
+        acc[2] += el(e[2], e[3]) + (split ? el(e[3], e[4]) : 0.0);
+        acc[3] += el(e[4], e[5]) + (split ? el(e[6], e[7]) : 0.0);
+        acc[4] += el(e[0], e[8]);
+        cnt++;
+    }
     int n = 0;
-    for (int i = 0; i < 4 && n < cap; i++, n++) {
-        double acc = 0;
-        size_t cnt = 0;
-        for (size_t r = 0; r < ctx->runs; r++) {
-            float t = 0;
-            if (hipEventElapsedTime(&t, ctx->ev[r * 5 + i], ctx->ev[r * 5 + i + 1]) == hipSuccess) {
-                acc += t;
-                cnt++;
-            }
-        }
+    for (int i = 0; i < 5 && n < cap; i++, n++) {
         if (names) names[n] = kNames[i];
-        if (ms) ms[n] = cnt ? (float)(acc / cnt) : -1.0f;
+        if (ms) ms[n] = (float)(acc[i] / cnt);
     }
     return n;
 }

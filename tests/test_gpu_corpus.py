@@ -35,6 +35,48 @@ def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads):
     c.close()
 
 
+@pytest.mark.parametrize("assume_cus", [1, 3, 20])
+def test_split_batch_two_streams(corpus, assume_cus):
+    """k_seq(tail) on the caller's stream overlapped with k_exec(head) on the library's second
+    stream: force the split on the small corpus batch by pretending the device has few CUs."""
+    c = z.Context(0, assume_cus=assume_cus)
+    for _ in range(2):  # twice: the resident state is reset per run
+        outs, sts = _decode([comp for _, comp, *_ in corpus], c)
+        assert sts == [0] * len(corpus)
+        for (name, comp, length, sha, exp), got in zip(corpus, outs):
+            check_expected(name, got, length, sha, exp)
+    c.close()
+
+
+def test_synthetic_configs_small(ctx, oracle):
+    """BASELINE configs 2-4 at small size: device output == original content == oracle output."""
+    from tools import synth_binding as sb
+    for config in (2, 3, 4):
+        blob, off, ln, ck, ns = sb.make_batch(config, 7, 24, frame_bytes=131072, threads=4)
+        frames = [blob[int(o):int(o + l)].tobytes() for o, l in zip(off, ln)]
+        outs, sts = _decode(frames, ctx)
+        assert sts == [0] * len(frames), (config, sts)
+        for f, o, c in zip(frames, outs, ck):
+            assert sb.checksum64(o) == int(c)
+            rc, want, _, _ = oracle.decode_frame(f, cap=131072 + 64)
+            assert rc == 0 and o == want
+
+
+def test_long_matches_and_rle_literals(ctx, oracle):
+    """all-zero / periodic content: one sequence with a 128 KiB overlapping match (oversized tile
+    path), RLE literals, offsets 1..7."""
+    from tools import synth_binding as sb
+    frames, want = [], []
+    for period in (1, 2, 3, 5, 7, 64, 100, 4097):
+        data = (bytes(range(1, period + 1)) * (131072 // period + 1))[:131072] if period <= 255 else \
+            (sb.generate(sb.RANDOM, period, period) * (131072 // period + 1))[:131072]
+        frames.append(sb.compress(data, sb.MODE_FULL)[0])
+        want.append(data)
+    outs, sts = _decode(frames, ctx)
+    assert sts == [0] * len(frames)
+    assert outs == want
+
+
 def test_gpu_matches_oracle_per_frame(corpus, oracle, ctx):
     frames = [comp for _, comp, *_ in corpus[:20]]
     outs, sts = _decode(frames, ctx)
