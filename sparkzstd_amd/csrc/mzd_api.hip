@@ -23,7 +23,7 @@ struct mzd_ctx {
     mzd_options opt{};
     std::string last_error;
     hipStream_t stream2 = nullptr;  // the execution kernel of the head of a split batch runs here
-    hipEvent_t ev_head_ready = nullptr, ev_head_done = nullptr;
+    hipEvent_t ev_head_ready = nullptr, ev_head_done = nullptr, ev_init_done = nullptr, ev_huf_done = nullptr;
     int num_cus = 256;
     // HIP events around every kernel of every mzd_batch_run since the last mzd_timing_reset
     std::vector<hipEvent_t> ev;  // kEvPerRun per run
@@ -61,7 +61,7 @@ struct mzd_dbatch {
 
 namespace {
 
-constexpr size_t kEvPerRun = 9;
+constexpr size_t kEvPerRun = 10;
 thread_local std::string g_create_error;
 
 #define HIP_TRY(ctx, expr)                                                                    \
@@ -143,7 +143,9 @@ mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_head_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_init_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_huf_done, hipEventDisableTiming) != hipSuccess) {
         if (err) *err = MZD_ERR_DEVICE;
         delete c;
         return nullptr;
@@ -166,6 +168,8 @@ void mzd_destroy(mzd_ctx *ctx)
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_head_ready) (void)hipEventDestroy(ctx->ev_head_ready);
     if (ctx->ev_head_done) (void)hipEventDestroy(ctx->ev_head_done);
+    if (ctx->ev_init_done) (void)hipEventDestroy(ctx->ev_init_done);
+    if (ctx->ev_huf_done) (void)hipEventDestroy(ctx->ev_huf_done);
     delete ctx;
 }
 
@@ -454,8 +458,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
     // overflow L2 and every refill goes to MALL/HBM; a minimum LDS request per workgroup limits the
     // number of resident wavefronts (opt.huf_min_lds bytes, default 48 KiB -> 3 wavefronts per CU)
-    const size_t huf_lds = std::max<size_t>((size_t)kHufQuads * db->huf_slot_cells * 2,
-                                            ctx->opt.huf_min_lds ? ctx->opt.huf_min_lds : 49152);
+    const size_t huf_lds = std::max<size_t>((size_t)kHufQuads * db->huf_slot_cells * 2, ctx->opt.huf_min_lds);
     if (!ctx->attr_set) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
@@ -516,28 +519,41 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                                      db->d_recs, db->d_tiles, db->d_litbuf, db->d_status + first,
                                                      db->d_out_len + first, exec_cap);
     };
+    // Stream plan.  k_huf only feeds k_exec, so it runs on the second stream, in the shadow of k_seq
+    // (k_seq keeps ~2.7 KiB of LDS free per CU: a k_huf workgroup with small tables is co-resident):
+    //   s  : k_init -> k_seq(head) -> k_seq(tail) -> [wait huf] k_exec(tail) -> [wait head done]
+    //   s2 : [wait init] k_huf -> [wait k_seq(head)] k_exec(head)
+    hipStream_t s2 = ctx->stream2;
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
-    if (db->n_huf_tasks)
-        k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
-                                                             db->d_litbuf, db->d_sums, db->huf_slot_cells);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_init_done, s));
+    // k_seq(head) is submitted FIRST so that its workgroups (nearly all of a CU's LDS each) claim the
+    // CUs; k_huf's small workgroups then fill what is left instead of delaying them
     launch_seq(0, tA);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
+    HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
+    if (db->n_huf_tasks)
+        k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
+                                                              db->d_litbuf, db->d_sums, db->huf_slot_cells);
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
     if (split) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_head_ready, s));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_head_ready, 0));
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[6], ctx->stream2));
-        launch_exec(ctx->stream2, 0, fA);
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[7], ctx->stream2));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_head_ready, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[6], s2));
+        launch_exec(s2, 0, fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[7], s2));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s2));
         launch_seq(tA, db->n_seq_tasks - tA);
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
         launch_exec(s, fA, db->n_frames - fA);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_head_done, 0));  // the caller's stream sees the whole batch done
     } else {
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
         launch_exec(s, 0, db->n_frames);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
@@ -613,8 +629,8 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
         hipEvent_t *e = ctx->ev.data() + r * kEvPerRun;
         const bool split = ctx->run_split[r];
         acc[0] += el(e[0], e[1]);
-        acc[1] += el(e[1], e[2]);
-        acc[2] += el(e[2], e[3]) + (split ? el(e[3], e[4]) : 0.0);
+        acc[1] += el(e[9], e[2]);                                           // k_huf on the second stream
+        acc[2] += el(e[1], e[3]) + (split ? el(e[3], e[4]) : 0.0);          // k_seq head (+ tail, incl. its wait for k_huf)
         acc[3] += el(e[4], e[5]) + (split ? el(e[6], e[7]) : 0.0);
         acc[4] += el(e[0], e[8]);
         cnt++;
