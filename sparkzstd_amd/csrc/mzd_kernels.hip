@@ -449,6 +449,7 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
         br.pd = in; br.C = br.D = 0; br.k = 0;
     }
     const uint32_t sizeL = 1u << alL, sizeM = 1u << alM, sizeO = 1u << alO;
+    sL += sizeL; sM += sizeM; sO += sizeO;  // pre-biased states
     const int nbL0 = alL - 31, nbM0 = alM - 31, nbO0 = alO - 31;  // nbits = acc_log - 31 + clz(next)
 
     // One sequence step.  SLOW == false is the hot variant: all six bit fields are cut from one
@@ -458,7 +459,20 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
     // run one SLOW step (refills between fields) outside it, and the loop resumes.  This keeps a
     // single definition of every loop-carried register in the hot loop.
     // Returns (stall, packed queue entry).
-    auto step = [&](auto slow_tag, uint32_t i, bool only, uint64_t &entry) -> bool {
+    // raw table cells of the three current states; issued BEFORE the refill arithmetic so that the LDS
+    // latency overlaps it.  States are kept pre-biased by the table size (sX = state + size) and the
+    // slot pointers are biased the other way, which removes the "- size" of fse.go:213 from the chain.
+    const uint16_t *c16L = (const uint16_t *)smem + slot - sizeL;
+    const uint16_t *c16M = (const uint16_t *)smem + slot + 512 - sizeM;
+    const uint16_t *c16O = (const uint16_t *)smem + slot + 1024 - sizeO;
+    const uint32_t *c32L = (const uint32_t *)smem + slot - sizeL;
+    const uint32_t *c32M = (const uint32_t *)smem + slot + 512 - sizeM;
+    const uint32_t *c32O = (const uint32_t *)smem + slot + 1024 - sizeO;
+    auto load_cells = [&](uint32_t &xl, uint32_t &xm, uint32_t &xo) {
+        if (CELL16) { xl = c16L[sL]; xm = c16M[sM]; xo = c16O[sO]; }
+        else { xl = c32L[sL]; xm = c32M[sM]; xo = c32O[sO]; }
+    };
+    auto step = [&](auto slow_tag, uint32_t i, bool only, uint64_t &entry, uint32_t xl, uint32_t xm, uint32_t xo) -> bool {
         constexpr bool SLOW = decltype(slow_tag)::value;
         const bool base_act = only && i < t.n_seq && status == MZD_OK;
         const bool lastseq = (i + 1 == t.n_seq);
@@ -466,24 +480,21 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
         uint32_t symL, symM, symO, nbL, nbM, nbO, baseL, baseM, baseO, exL, exM;
         uint32_t cl, cm;
         if (CELL16) {
-            const uint16_t *c = (const uint16_t *)smem + slot;
-            const uint32_t xl = c[sL], xm = c[512 + sM], xo = c[1024 + sO];
             symL = xl >> 10; symM = xm >> 10; symO = xo >> 10;
             cl = CT[symL]; cm = CT[64 + symM];
             const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
             nbL = (uint32_t)(nbL0 + __builtin_clz(nl | 1));
             nbM = (uint32_t)(nbM0 + __builtin_clz(nm | 1));
             nbO = (uint32_t)(nbO0 + __builtin_clz(no | 1));
-            baseL = (nl << nbL) - sizeL;
-            baseM = (nm << nbM) - sizeM;
-            baseO = (no << nbO) - sizeO;
+            baseL = nl << nbL;  // biased: baseline + size
+            baseM = nm << nbM;
+            baseO = no << nbO;
             exL = cl >> 24; exM = cm >> 24;
         } else {
-            const uint32_t *c = (const uint32_t *)smem + slot;
-            const uint32_t el = c[sL], em = c[512 + sM], eo = c[1024 + sO];
-            baseL = el & 1023; nbL = (el >> 10) & 15; exL = (el >> 14) & 31; symL = el >> 19;
-            baseM = em & 1023; nbM = (em >> 10) & 15; exM = (em >> 14) & 31; symM = em >> 19;
-            baseO = eo & 1023; nbO = (eo >> 10) & 15; symO = eo >> 19;
+            const uint32_t el = xl, em = xm, eo = xo;
+            baseL = (el & 1023) + sizeL; nbL = (el >> 10) & 15; exL = (el >> 14) & 31; symL = el >> 19;
+            baseM = (em & 1023) + sizeM; nbM = (em >> 10) & 15; exM = (em >> 14) & 31; symM = em >> 19;
+            baseO = (eo & 1023) + sizeO; nbO = (eo >> 10) & 15; symO = eo >> 19;
             cl = CT[symL]; cm = CT[64 + symM];
         }
         const uint32_t exO = symO;
@@ -526,9 +537,10 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
             rem -= total;
             if (rem < 0) status = MZD_ERR_SEQ_BITS;  // over-read (cursor would pass -1)
             if (ofv >= kRecOffSymbolic) status = MZD_ERR_UNSUPPORTED;  // offset value >= 2^28
-            // next states: state = Baseline + Read(NumberOfBits) (fse.go:282-290), order LL, ML, OF
-            // (the masks are no-ops for valid tables; they keep a failing lane inside its LDS slot)
-            sL = (baseL + aL) & 511; sM = (baseM + aM) & 511; sO = (baseO + aO) & 255;
+            // next states: state = Baseline + Read(NumberOfBits) (fse.go:282-290), order LL, ML, OF.
+            // In range by construction: the host checked baseline + 2^nbits <= size for every cell, and
+            // idle / finished / failed lanes do not get here.
+            sL = baseL + aL; sM = baseM + aM; sO = baseO + aO;
         }
         const bool emit = act && status == MZD_OK;
         entry = emit ? ((uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)ofv << kRecOffShift) | (1ull << 63)) : 0ull;
@@ -551,8 +563,10 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
         do {
             if ((i & 31) == 0 && has)  // bytes not yet requested by the refills (for the helper wavefront)
                 shs->progress[lane] = (uint32_t)max((int)(br.pd - (in + t.in_off)), 0);
+            uint32_t xl, xm, xo;
+            load_cells(xl, xm, xo);
             br.refill();
-            stalled = step(std::false_type{}, i, true, entry);
+            stalled = step(std::false_type{}, i, true, entry, xl, xm, xo);
             any_stall = __any(stalled) != 0;
             if (!any_stall) {
                 // hand the step to the helper wavefront (space in the queue: i - tail < depth)
@@ -566,7 +580,9 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
         if (any_stall) {
             // lanes that advanced keep their entry; stalled lanes produce theirs now
             uint64_t e2 = 0;
-            step(std::true_type{}, i - 1, stalled, e2);
+            uint32_t xl, xm, xo;
+            load_cells(xl, xm, xo);
+            step(std::true_type{}, i - 1, stalled, e2, xl, xm, xo);
             if (stalled) entry = e2;
             wait_space(i - 1);
             shs->queue[(i - 1) % kSeqQueueDepth][lane] = entry;
