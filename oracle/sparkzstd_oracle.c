@@ -974,19 +974,24 @@ static void frame_state_free(frame_state *fs)
     free(fs->seq_buf);
 }
 
-int orc_decode_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len,
-                     size_t *consumed, orc_trace *trace)
+/* One frame with caller-provided scratch (`fs` zeroed or left over from a previous frame: the
+ * literal and sequence buffers are reused, tables are reset per frame as framedecompressor.go:42-52
+ * resets them). */
+static int decode_frame_with(frame_state *fs, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                             size_t *out_len, size_t *consumed, orc_trace *trace)
 {
     orc_frame_header h;
     int rc = orc_parse_frame_header(src, n, &h);
     if (rc) return rc;
-    frame_state *fs = (frame_state *)calloc(1, sizeof(frame_state));
-    if (!fs) return ORC_ERR_UNSUPPORTED;
+    if (fs->have_ll) orc_fse_free(&fs->ll);
+    if (fs->have_of) orc_fse_free(&fs->of);
+    if (fs->have_ml) orc_fse_free(&fs->ml);
+    fs->have_ll = fs->have_of = fs->have_ml = fs->have_huf = 0;
     fs->hist[0] = 1; /* framedecompressor.go:48,59 */
     fs->hist[1] = 4;
     fs->hist[2] = 8;
-    fs->lit_buf = (uint8_t *)malloc(128 * 1024 + 64);
-    if (!fs->lit_buf) { frame_state_free(fs); free(fs); return ORC_ERR_UNSUPPORTED; }
+    if (!fs->lit_buf) fs->lit_buf = (uint8_t *)malloc(128 * 1024 + 64);
+    if (!fs->lit_buf) return ORC_ERR_UNSUPPORTED;
     size_t p = (size_t)h.header_bytes;
     size_t op = 0;
     int last = 0;
@@ -1022,10 +1027,19 @@ int orc_decode_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, siz
         }
         if (bi) bi->out_end = op;
     }
-    frame_state_free(fs);
-    free(fs);
     if (out_len) *out_len = op;
     if (consumed) *consumed = p;
+    return rc;
+}
+
+int orc_decode_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len,
+                     size_t *consumed, orc_trace *trace)
+{
+    frame_state *fs = (frame_state *)calloc(1, sizeof(frame_state));
+    if (!fs) return ORC_ERR_UNSUPPORTED;
+    int rc = decode_frame_with(fs, src, n, dst, cap, out_len, consumed, trace);
+    frame_state_free(fs);
+    free(fs);
     return rc;
 }
 
@@ -1034,14 +1048,20 @@ int orc_decode_frames(const uint8_t *blob, const uint64_t *frame_off, const uint
                       uint64_t *out_len, int32_t *status)
 {
     int first = 0;
+    /* scratch reused across the frames of the call (the per-frame >128 KiB mallocs would be served by
+     * mmap/munmap, which serialises concurrent callers on the process-wide mapping lock) */
+    frame_state *fs = (frame_state *)calloc(1, sizeof(frame_state));
+    if (!fs) return ORC_ERR_UNSUPPORTED;
     for (int f = 0; f < n_frames; f++) {
         size_t ol = 0;
-        int rc = orc_decode_frame(blob + frame_off[f], (size_t)frame_len[f], dst + dst_off[f],
-                                  (size_t)dst_cap[f], &ol, NULL, NULL);
+        int rc = decode_frame_with(fs, blob + frame_off[f], (size_t)frame_len[f], dst + dst_off[f],
+                                   (size_t)dst_cap[f], &ol, NULL, NULL);
         if (out_len) out_len[f] = ol;
         if (status) status[f] = rc;
         if (rc && !first) first = rc;
     }
+    frame_state_free(fs);
+    free(fs);
     return first;
 }
 
