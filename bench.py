@@ -47,12 +47,37 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host threads this process can really run: min(cpu_count, affinity, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
     """Oracle ("port" of the reference algorithm, plain C) on the host cores, bounded sample of the
     SAME frames.  Reported next to the GPU number; never the thing measured as `value`."""
     from tests.oracle_binding import load_oracle
     orc = load_oracle()
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cores()
     n_total = len(off)
 
     def run(first, count, nthreads):
@@ -101,7 +126,8 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
         dt = (time.perf_counter() - t0) / reps
     return {"value": round(sample * frame_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
             "sample": f"first {sample} frames of the same batch, oracle (C restatement of the reference "
-                      f"algorithm) on {cores} host threads, {dt:.1f}s", "ok": bool(ok and ok2)}
+                      f"algorithm) on {cores} host threads ({os.cpu_count()} hardware threads, cgroup quota "
+                      f"{quota}), {dt:.2f}s per pass", "ok": bool(ok and ok2)}
 
 
 def main():
@@ -114,9 +140,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1 and a.gpus == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
+    # test hooks (tests of the N>1 control flow on a 1-GPU box): MZD_BENCH_BACKEND=gloo, MZD_BENCH_DEVICE=0
+    backend = os.environ.get("MZD_BENCH_BACKEND", "nccl")
+    if "MZD_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MZD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import sparkzstd_amd as z
     from tools import synth_binding as sb
@@ -132,7 +166,7 @@ def main():
 
     # ---- synthetic batch (host), planning (host), upload: all outside the timed region
     t0 = time.perf_counter()
-    gen_threads = a.gen_threads or max(1, (os.cpu_count() or 1) // max(1, world))
+    gen_threads = a.gen_threads or max(1, usable_cores()[0] // max(1, world))
     blob, off, ln, cks, nseq = sb.make_batch(a.config, first, per, frame_bytes, threads=gen_threads)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -175,7 +209,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kms = ctx.kernel_ms()  # HIP events on the launch stream, averaged over the K timed steps
@@ -194,7 +228,7 @@ def main():
             got = (o64[c:c + chunk] * wts).sum(dim=1)
             ok = ok and bool((got == exp[c:c + chunk]).all())
     if world > 1:
-        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item())
 
