@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-split", action="store_true", help="do not overlap k_seq(tail) with k_exec(head)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--gen-seconds", type=float, default=60.0,
+                    help="host time budget for generating the synthetic batch; if all-distinct frames would "
+                         "take longer, fewer distinct frames are generated and physically replicated")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
 
@@ -167,7 +170,25 @@ def main():
     # ---- synthetic batch (host), planning (host), upload: all outside the timed region
     t0 = time.perf_counter()
     gen_threads = a.gen_threads or max(1, usable_cores()[0] // max(1, world))
-    blob, off, ln, cks, nseq = sb.make_batch(a.config, first, per, frame_bytes, threads=gen_threads)
+    # calibrate, then generate as many DISTINCT frames as the time budget allows (normally all of them)
+    calib = min(per, 8 * gen_threads)
+    tc = time.perf_counter()
+    sb.make_batch(a.config, first, calib, frame_bytes, threads=gen_threads)
+    rate = calib / max(time.perf_counter() - tc, 1e-3)  # frames per second on this rank's threads
+    distinct = per
+    while distinct > 1024 and distinct / rate > a.gen_seconds:
+        distinct //= 2
+    blob, off, ln, cks, nseq = sb.make_batch(a.config, first, distinct, frame_bytes, threads=gen_threads)
+    if distinct < per:
+        # physical replication: content repeats, HBM addresses do not (SURVEY 8d option iii)
+        reps = (per + distinct - 1) // distinct
+        blob = np.ascontiguousarray(blob)
+        base_len = int(blob.size)
+        blob = np.tile(blob, reps)
+        off = np.concatenate([off + np.uint64(r * base_len) for r in range(reps)])[:per]
+        ln = np.tile(ln, reps)[:per]
+        cks = np.tile(cks, reps)[:per]
+        nseq = np.tile(nseq, reps)[:per]
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     plan = z.Plan()
@@ -275,7 +296,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": names.get(a.config, str(a.config)), "frames_per_gpu": per,
                        "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes,
-                       "sequences_per_frame": round(float(nseq.mean()), 1),
+                       "sequences_per_frame": round(float(nseq.mean()), 1), "distinct_frames_per_gpu": distinct,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 128,
                        "exec_chunk": a.exec_chunk or 8192},

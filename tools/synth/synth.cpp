@@ -37,6 +37,7 @@ inline int highbit(uint32_t v) { return 31 - __builtin_clz(v); }
 struct Vocab {
     std::vector<std::string> words;
     std::vector<double> cdf;
+    std::vector<uint16_t> quant;  // 2^20-entry inverse CDF: u >> 44 -> word index (O(1) Zipf sampling)
     Vocab()
     {
         uint64_t s = 0xC0FFEE1234ull;
@@ -50,6 +51,13 @@ struct Vocab {
             cdf.push_back(tot);
         }
         for (auto &c : cdf) c /= tot;
+        quant.resize((size_t)1 << 20);
+        size_t w = 0;
+        for (size_t q = 0; q < quant.size(); q++) {
+            const double u = ((double)q + 0.5) / (double)quant.size();
+            while (w + 1 < cdf.size() && cdf[w] < u) w++;
+            quant[q] = (uint16_t)w;
+        }
     }
 };
 const Vocab &vocab()
@@ -64,14 +72,18 @@ void gen_text(uint64_t seed, uint8_t *dst, size_t n)
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x7E57;
     size_t p = 0;
     while (p < n) {
-        double u = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
-        size_t idx = (size_t)(std::lower_bound(v.cdf.begin(), v.cdf.end(), u) - v.cdf.begin());
-        if (idx >= v.words.size()) idx = v.words.size() - 1;
-        const std::string &w = v.words[idx];
-        for (char c : w) {
-            if (p < n) dst[p++] = (uint8_t)c;
+        const std::string &w = v.words[v.quant[splitmix64(s) >> 44]];
+        const size_t l = w.size();
+        if (p + l + 1 <= n) {
+            memcpy(dst + p, w.data(), l);
+            dst[p + l] = ' ';
+            p += l + 1;
+        } else {
+            for (char c : w) {
+                if (p < n) dst[p++] = (uint8_t)c;
+            }
+            if (p < n) dst[p++] = ' ';
         }
-        if (p < n) dst[p++] = ' ';
     }
 }
 
