@@ -464,6 +464,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32)));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_quad, hipFuncAttributeMaxDynamicSharedMemorySize, kQuadLdsBytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
@@ -473,7 +474,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // the last, partial round leaves most CUs idle.  The batch is cut at the frame where the full rounds
     // end: k_seq(tail) then runs on the caller's stream while k_exec(head) fills the idle CUs from a
     // second stream (frames are independent, so the two never touch the same data).
-    const uint32_t nch = cell16 ? kSeqChains16 : kSeqChains32;
+    const uint32_t nch = ctx->opt.seq_variant == 2 ? (uint32_t)kQuadChains : (cell16 ? kSeqChains16 : kSeqChains32);
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames, tA = db->n_seq_tasks;
     if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
@@ -504,9 +505,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         ctx->run_split[ctx->runs] = split;
         ev = ctx->ev.data() + ctx->runs * kEvPerRun;
     }
+    const bool quad = ctx->opt.seq_variant == 2;
     auto launch_seq = [&](uint32_t first, uint32_t count) {
         if (!count) return;
-        if (cell16)
+        if (quad)
+            k_seq_quad<<<(count + kQuadChains - 1) / kQuadChains, 320, kQuadLdsBytes, s>>>(
+                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+        else if (cell16)
             k_seq<true><<<(count + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
         else

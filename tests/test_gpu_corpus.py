@@ -22,7 +22,7 @@ def _decode(frames, ctx):
     return outs, sts
 
 
-@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (0, 128), (0, 64), (1, 64)])
+@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (2, 128), (0, 128), (0, 64), (1, 64)])
 def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
