@@ -55,6 +55,13 @@ def test_no_cpu_fallback_without_gpu():
         raise AssertionError("Context() must fail without a GPU")
 
 
+def test_cpp_mirror_header_compiles():
+    """include/sparkzstd_frame.hpp (C++ FrameReader / FrameDecompressor mirror) builds against the ABI."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools", "verify")])
+    assert os.path.exists(os.path.join(ROOT, "tools", "verify", "sparkzstd_verify"))
+
+
 def test_product_does_not_link_oracle():
     so = open(_lib.LIB_PATH, "rb").read()
     assert b"orc_decode_frame" not in so and b"sparkzstd_oracle" not in so

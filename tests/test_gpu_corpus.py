@@ -103,6 +103,23 @@ def test_frame_reader_mirror(corpus, ctx):
     check_expected(name, sink.getvalue(), length, sha, exp)
 
 
+def test_cpp_frame_reader_verify_cli(corpus):
+    """The C++ mirror of FrameReader (include/sparkzstd_frame.hpp) driven like the reference's own
+    harness cmd/sparkzstd/main.go: decode x.zst, compare byte for byte with x."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "verify", "sparkzstd_verify")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tools", "verify")])
+    d = os.path.join(root, "tests", "golden", "decodecorpus")
+    files = [os.path.join(d, name + ".zst") for name, _, _, _, exp in corpus if exp is not None]
+    assert len(files) >= 30
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Found no diffs in any files" in r.stdout and "Found no unexpected errors" in r.stdout
+
+
 def test_raw_rle_frames(ctx):
     """BASELINE config 2 shape, small: raw / rle single-block frames incl. sizes 0, 1, 15, 16, 17, 131072."""
     frames, want = [], []

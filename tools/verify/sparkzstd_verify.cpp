@@ -1,0 +1,55 @@
+// sparkzstd_verify -- the reference's test harness (cmd/sparkzstd/main.go:113-195) on the device
+// path: every argument is a .zst file; the output of FrameReader is compared byte for byte with the
+// file of the same name minus ".zst" (main.go:46-111) and an average speed is printed (:177-191).
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/sparkzstd_frame.hpp"
+
+int main(int argc, char **argv)
+{
+    std::vector<std::string> diffs, errs;
+    sparkzstd::FrameReader comp;  // one shared reader, Reset per file (main.go:126,59)
+    double seconds = 0;
+    uint64_t bytes = 0;
+    for (int i = 1; i < argc; i++) {
+        const std::string path = argv[i];
+        const std::string original = path.substr(0, path.size() - 4);
+        std::ifstream z(path, std::ios::binary), o(original, std::ios::binary);
+        if (!z || !o) {
+            errs.push_back(path + ": cannot open");
+            continue;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            comp.Reset(&z);
+            std::vector<uint8_t> got(1 << 16), want(1 << 16);
+            bool differ = false;
+            for (;;) {
+                const size_t n = comp.Read(got.data(), got.size());
+                o.read(reinterpret_cast<char *>(want.data()), (std::streamsize)std::max<size_t>(n, 1));
+                const size_t m = (size_t)o.gcount();
+                if (n == 0) {  // io.EOF: both must end at the same byte (main.go:70-82)
+                    differ = differ || m != 0;
+                    break;
+                }
+                if (m != n || std::memcmp(got.data(), want.data(), n) != 0) differ = true;
+                bytes += n;
+            }
+            if (differ) diffs.push_back(original);
+        } catch (const sparkzstd::Error &e) {
+            errs.push_back(original + " Decompress-Read Err: " + e.what());
+        }
+        seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (diffs.empty()) printf("Found no diffs in any files! Good job you!\n");
+    else for (auto &d : diffs) printf("Found diffs in file: %s\n", d.c_str());
+    if (errs.empty()) printf("Found no unexpected errors in any files! Good job you!\n");
+    else for (auto &e : errs) printf("Found unexpected error: %s\n", e.c_str());
+    printf("Average detected Speed: %.1f MB/s (%llu bytes, includes host planning + H2D + D2H per file)\n",
+           seconds > 0 ? bytes / seconds / 1e6 : 0.0, (unsigned long long)bytes);
+    return diffs.empty() && errs.empty() ? 0 : 1;
+}
