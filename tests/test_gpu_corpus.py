@@ -62,6 +62,20 @@ def test_synthetic_configs_small(ctx, oracle):
             assert rc == 0 and o == want
 
 
+def test_multi_block_synthetic_frames(ctx):
+    """frames of up to 1 MiB (8 blocks): offset history carried across blocks (symbolic in k_seq),
+    raw blocks in between, block buffers reused."""
+    from tools import synth_binding as sb
+    frames, want = [], []
+    for kind, n in [(sb.TEXT, 1 << 20), (sb.EXP, 400000), (sb.TEXT, 131073), (sb.RANDOM, 300000), (sb.TEXT, 262144)]:
+        d = sb.generate(kind, n, n)
+        frames.append(sb.compress(d, sb.MODE_FULL)[0])
+        want.append(d)
+    outs, sts = _decode(frames, ctx)
+    assert sts == [0] * len(frames)
+    assert outs == want
+
+
 def test_long_matches_and_rle_literals(ctx, oracle):
     """all-zero / periodic content: one sequence with a 128 KiB overlapping match (oversized tile
     path), RLE literals, offsets 1..7."""

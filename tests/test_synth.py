@@ -27,7 +27,8 @@ def _libzstd():
 
 CASES = [(sb.TEXT, sb.MODE_FULL, 131072), (sb.TEXT, sb.MODE_LITERALS, 20000), (sb.EXP, sb.MODE_LITERALS, 131072),
          (sb.EXP, sb.MODE_FULL, 50000), (sb.RANDOM, sb.MODE_FULL, 4096), (sb.ZERO, sb.MODE_FULL, 131072),
-         (sb.TEXT, sb.MODE_FULL, 300000), (sb.TEXT, sb.MODE_FULL, 63), (sb.TEXT, sb.MODE_FULL, 0),
+         (sb.TEXT, sb.MODE_FULL, 300000), (sb.TEXT, sb.MODE_FULL, 1 << 20), (sb.EXP, sb.MODE_FULL, 400000),
+         (sb.TEXT, sb.MODE_FULL, 63), (sb.TEXT, sb.MODE_FULL, 0),
          (sb.RANDOM, sb.MODE_RAW, 1000), (sb.ZERO, sb.MODE_RLE, 1000)]
 
 

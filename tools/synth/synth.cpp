@@ -692,11 +692,13 @@ inline uint32_t rd32(const uint8_t *p)
 
 // Greedy single-probe hash matcher with repeat-offset checks; emits raw offset VALUES with the
 // decoder's repeat-code rules (sequence_execution.go:65-114) applied in reverse.
-void find_sequences(const uint8_t *src, size_t n, std::vector<Seq> &seqs, std::vector<uint8_t> &lits, int min_match)
+// `rep` is the frame's repeat-offset history: it persists across blocks (framedecompressor.go:23) and
+// is updated only by blocks that carry sequences.
+void find_sequences(const uint8_t *src, size_t n, std::vector<Seq> &seqs, std::vector<uint8_t> &lits, int min_match,
+                    uint32_t rep[3])
 {
     constexpr int HLOG = 16;
     std::vector<int32_t> table((size_t)1 << HLOG, -1);
-    uint32_t rep[3] = {1, 4, 8};
     size_t anchor = 0, ip = 0;
     const size_t limit = n >= 8 ? n - 8 : 0;
     auto hash = [&](const uint8_t *p) { return (rd32(p) * 2654435761u) >> (32 - HLOG); };
@@ -783,6 +785,7 @@ void encode_frame(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &
         put_block_header(out, 0, 0, true);
         return;
     }
+    uint32_t rep[3] = {1, 4, 8};  // framedecompressor.go:48
     while (p < n) {
         const size_t bn = std::min<size_t>(n - p, 128 * 1024);
         const bool last = p + bn == n;
@@ -796,7 +799,8 @@ void encode_frame(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &
             std::vector<uint8_t> body;
             std::vector<Seq> seqs;
             std::vector<uint8_t> lits;
-            if (mode == 0) find_sequences(src + p, bn, seqs, lits, min_match);
+            uint32_t rep_new[3] = {rep[0], rep[1], rep[2]};
+            if (mode == 0) find_sequences(src + p, bn, seqs, lits, min_match, rep_new);
             else lits.assign(src + p, src + p + bn);
             write_literals(lits.data(), lits.size(), body);
             write_sequences(seqs, body);
@@ -807,6 +811,7 @@ void encode_frame(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &
                 put_block_header(out, (uint32_t)body.size(), 2, last);
                 out.insert(out.end(), body.begin(), body.end());
                 if (n_seq_out) *n_seq_out += (uint32_t)seqs.size();
+                rep[0] = rep_new[0]; rep[1] = rep_new[1]; rep[2] = rep_new[2];  // history moves only with an emitted block
             }
         }
         p += bn;
