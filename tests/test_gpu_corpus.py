@@ -76,6 +76,37 @@ def test_multi_block_synthetic_frames(ctx):
     assert outs == want
 
 
+def test_randomized_differential(ctx):
+    """400 frames of random kind / size / mode in ONE batch (ragged, empty, multi-block, mixed block
+    types), checked byte for byte against the content they were made from."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(20261001)
+    frames, want = [], []
+    for i in range(400):
+        kind = int(rng.choice([sb.TEXT, sb.EXP, sb.RANDOM, sb.ZERO]))
+        n = int(rng.choice([0, 1, 2, 3, 7, 63, 64, 65, 255, 1000, 4095, 4096, 4097, 20000, 65535, 131071, 131072,
+                            131073, 200000, 300000]))
+        if rng.random() < 0.3:
+            n = int(rng.integers(0, 150000))
+        data = sb.generate(kind, 1000 + i, n)
+        if kind == sb.TEXT and n > 100 and rng.random() < 0.3:  # splice in periodic / repeated regions
+            k = int(rng.integers(1, 40))
+            data = data[:n // 3] + (data[:k] * (n // k + 1))[:n // 3] + data[2 * (n // 3):]
+            data = data[:n] + b"\0" * (n - len(data[:n]))
+        mode = int(rng.choice([sb.MODE_FULL, sb.MODE_FULL, sb.MODE_LITERALS, sb.MODE_RAW, sb.MODE_RLE]))
+        if mode == sb.MODE_RLE:
+            data = bytes([data[0] if data else 0]) * n
+        if mode == sb.MODE_LITERALS and n > 131072:
+            mode = sb.MODE_FULL
+        frames.append(sb.compress(data, mode)[0])
+        want.append(data)
+    outs, sts = _decode(frames, ctx)
+    bad = [(i, s) for i, s in enumerate(sts) if s != 0]
+    assert not bad, bad[:10]
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert o == w, f"frame {i}: {len(o)} vs {len(w)} bytes"
+
+
 def test_long_matches_and_rle_literals(ctx, oracle):
     """all-zero / periodic content: one sequence with a 128 KiB overlapping match (oversized tile
     path), RLE literals, offsets 1..7."""
