@@ -69,7 +69,10 @@ const Vocab &vocab()
 void gen_text(uint64_t seed, uint8_t *dst, size_t n)
 {
     const Vocab &v = vocab();
-    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x7E57;
+    // the seed is HASHED into the initial state: with state = seed * G + c consecutive seeds would
+    // just be the same splitmix stream advanced by one draw (frames shifted by one word)
+    uint64_t s0 = seed ^ 0x7E57C0DE5EEDull;
+    uint64_t s = splitmix64(s0) ^ (splitmix64(s0) << 1);
     size_t p = 0;
     while (p < n) {
         const std::string &w = v.words[v.quant[splitmix64(s) >> 44]];
@@ -90,7 +93,8 @@ void gen_text(uint64_t seed, uint8_t *dst, size_t n)
 // config 3 content: bytes min(255, floor(Exp(lambda = 0.08)))
 void gen_exp(uint64_t seed, uint8_t *dst, size_t n)
 {
-    uint64_t s = seed * 0xD1B54A32D192ED03ull + 0xE7;
+    uint64_t s0 = seed ^ 0xE7E7E7E7A5A5ull;
+    uint64_t s = splitmix64(s0) ^ (splitmix64(s0) << 1);
     for (size_t i = 0; i < n; i++) {
         double u = ((double)(splitmix64(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
         double x = -std::log(u) / 0.08;
