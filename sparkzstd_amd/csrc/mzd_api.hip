@@ -217,7 +217,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         }
         for (uint64_t j = 0; j < n; j++) {
             const mzd_fse_entry &e = b->fse_entries[d.entries_off + j];
-            if (e.symbol > kMaxSym[d.kind] || e.nbits > d.acc_log || (uint32_t)e.baseline + (1u << e.nbits) > n) {
+            // a decoding-table cell is canonical (fse.go:209-213): baseline + size is a multiple of
+            // 2^nbits; the kernels rebuild nbits and baseline from (baseline + size) >> nbits
+            if (e.symbol > kMaxSym[d.kind] || e.nbits > d.acc_log || (uint32_t)e.baseline + (1u << e.nbits) > n ||
+                (((uint32_t)e.baseline + (uint32_t)n) & ((1u << e.nbits) - 1)) != 0) {
                 fse_ok[i] = 0;
                 break;
             }
@@ -465,6 +468,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_quad, hipFuncAttributeMaxDynamicSharedMemorySize, kQuadLdsBytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_pipe, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kPipeFixedLds + kPipeMaxChains * kSeqCellsPerChain * 2));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
@@ -474,7 +479,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // the last, partial round leaves most CUs idle.  The batch is cut at the frame where the full rounds
     // end: k_seq(tail) then runs on the caller's stream while k_exec(head) fills the idle CUs from a
     // second stream (frames are independent, so the two never touch the same data).
-    const uint32_t nch = ctx->opt.seq_variant == 2 ? (uint32_t)kQuadChains : (cell16 ? kSeqChains16 : kSeqChains32);
+    const bool pipe = ctx->opt.seq_variant == 3;
+    const uint32_t nch = pipe ? (uint32_t)kPipeMaxChains
+                              : (ctx->opt.seq_variant == 2 ? (uint32_t)kQuadChains : (cell16 ? kSeqChains16 : kSeqChains32));
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames, tA = db->n_seq_tasks;
     if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
@@ -508,7 +515,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     const bool quad = ctx->opt.seq_variant == 2;
     auto launch_seq = [&](uint32_t first, uint32_t count) {
         if (!count) return;
-        if (quad)
+        if (pipe) {
+            // chains per workgroup: as few as fill the same number of rounds (a lone chain per CU when
+            // the batch is small -- the step latency does not depend on the number of lanes)
+            const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1);
+            const uint64_t rounds = (count + cus * nch - 1) / (cus * nch);
+            const uint32_t per_wg = (uint32_t)std::min<uint64_t>(nch, (count + rounds * cus - 1) / (rounds * cus));
+            k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
+                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg);
+        } else if (quad)
             k_seq_quad<<<(count + kQuadChains - 1) / kQuadChains, 320, kQuadLdsBytes, s>>>(
                 db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
         else if (cell16)

@@ -40,6 +40,14 @@ struct __attribute__((packed, aligned(1))) U128U { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { return ((const U64U *)p)->v; }
 
+// Touch a line: an ordinary load (it allocates in the CU's vL1D and in L2; a `volatile` access would
+// be emitted system-coherent, sc0 sc1, and bypass the vL1D) whose result is waited for and dropped.
+__device__ __forceinline__ void touch_line(const uint8_t *p)
+{
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 #pragma unroll
@@ -267,7 +275,11 @@ struct SeqBits {
         // ordering point: the old D must be dead before the new D is requested, otherwise the
         // compiler keeps both alive, copies at the loop back edge and waits vmcnt(0) for the copy
         asm volatile("" ::"v"((uint32_t)C), "v"((uint32_t)(C >> 32)) : "memory");
+#ifdef MZD_EXP_FAKE_REFILL  // timing experiment only (wrong results): every refill hits one resident line
+        D = ld64u((const uint8_t *)((uintptr_t)pd & ~(uintptr_t)0x3FFF));
+#else
         D = ld64u(pd);
+#endif
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(((C << k) >> 1) >> (63 - n)); }
 };
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
         uint32_t ofx, mlx, llx, aL, aM, aO;
         bool act, stall = false;
         if (!SLOW) {
-            stall = base_act && (br.k + total > 64);
+            stall = base_act && (br.k + total > 63);  // k must stay < 64: the refill shifts by 8 * (k >> 3)
             act = base_act && !stall;
             const uint64_t T = br.C << br.k;
             ofx = top_bits(T, exO);
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(320) void k_seq_quad(const uint8_t *__restrict__ in
         uint32_t fe, fs;
         bool act, stall = false;
         if (!SLOW) {
-            stall = base_act && (br.k + total > 64);
+            stall = base_act && (br.k + total > 63);  // k must stay < 64: the refill shifts by 8 * (k >> 3)
             act = base_act && !stall;
             const uint64_t T = br.C << br.k;
             fe = top_bits(T << oex, ex);
@@ -907,6 +919,440 @@ __global__ __launch_bounds__(320) void k_seq_quad(const uint8_t *__restrict__ in
         int st = status;
         if (st == MZD_OK && chas && c_n_seq > 0 && rem != 0) st = MZD_ERR_SEQ_BITS;
         if (chas && c_n_seq > 0 && role == 0 && st != MZD_OK) atomicCAS(&sums[blk].status, MZD_OK, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_seq_pipe: the sequence decode as a THREE-STAGE PIPELINE ACROSS THE SIMDs OF ONE CU.
+//
+// The LDS-resident tables bound a CU to ~60 chains = one wavefront, and a lone wavefront pays
+// ~4.4 cycles per instruction of whatever type plus ~100 cycles per DEPENDENT LDS round trip: the
+// per-step instruction stream and its LDS trips ARE the step latency.  So the step is cut by
+// dependence, not by data: only what the next state needs stays on the serial chain, everything
+// else moves to other wavefronts (= other SIMDs) that follow a few queue slots behind and work
+// on batches of four steps (one poll and one LDS latency per batch instead of per step).
+//   wave 0 (A, the chain): cells of the three states, extra-bit COUNTS, refill, the three
+//       next-state bit fields, state update.  ONE LDS trip per step; it never cuts the extra
+//       bits and never forms a value.  Hands {bit window T at the cursor, symbol codes} to B.
+//   wave 1 (B, stateless): cuts offset / match-length / literal-length extra bits out of T and
+//       adds the base values (sequences.go:99-120); hands {LL, ML, offset value} to C.
+//   wave 2 (C): running sums + tile bases, repeat-offset resolution on a concrete-or-symbolic
+//       history (sequence_execution.go:65-114), record packing, the record stores.
+//   wave 3 (P): walks ahead of every chain's read cursor and touches the bitstream lines so
+//       that A's refills hit the CU's vL1D (A's own touches would return in order with, and
+//       so delay, its refill loads).
+//
+// LDS cell (2 bytes): next(10) | c6(6).  next = (baseline + size) >> nbits, from which nbits =
+// acc_log - highbit(next) and baseline + size = next << nbits (fse.go:209-213 backwards).  c6 is
+// the symbol RE-CODED so that the extra-bit count is arithmetic: count = max(0, (c6 >> 2) - K)
+// with K = 3 for literal lengths and 7 for match lengths (seq_code6 below; predefined.go:5-20,
+// 36-50 are the counts it reproduces).  Stage B looks base values up by c6.  The few symbols
+// that do not fit (literal length >= 8192, match length >= 1027) get next = 0: "escape".
+//
+// A's hot step has no per-sequence predicate except ONE: a lane takes the general step instead
+// (refills between fields, values formed in A itself, queue entry mode 1) when
+//   - the step needs more bits than the window holds (k + total > 63) or the stream has left,
+//   - a cell is an escape (next = 0 makes clz = -1 and nbits negative = above any limit as unsigned),
+//   - it is the lane's last sequence (no state update, sequences.go:178).
+// Lanes without work, failed or finished are PARKED: bit budget 0 and a dummy state, so they
+// never move and need no exec masking.
+//
+// LDS: [CTc 128 dwords][PipeShared][cells: nch x 1280 x u16], nch <= kPipeMaxChains at launch.
+
+constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
+#ifndef MZD_PIPE_AHEAD
+#define MZD_PIPE_AHEAD 256  // bytes wave P keeps touched below every chain's cursor
+#endif
+struct PipeShared {
+    uint32_t head1, tail1, head2, tail2;  // steps produced / consumed on the A->B and B->C queues
+    uint32_t progress[64];                // per chain: bytes of bitstream not yet requested by A
+    int32_t stC[64];                      // final status of stage C
+    uint64_t q1t[kPipeDepth][64];         // mode 0: bit window T; mode 1: LL:17 | ML:18 | offset value:29
+    uint32_t q1p[kPipeDepth][64];         // mode 0: byte 0/1/2 = high byte of the LL/ML/OF cell; mode 1: bit 31
+    uint64_t q2[kPipeDepth][64];          // LL:17 | ML:18 | offset value:29 (2^28 = "too large")
+};
+constexpr int kPipeFixedLds = 512 + (int)sizeof(PipeShared);
+constexpr int kPipeMaxChains = (160 * 1024 - kPipeFixedLds) / (kSeqCellsPerChain * 2);
+static_assert(kPipeFixedLds % 16 == 0 && kPipeMaxChains >= 59, "k_seq_pipe LDS layout");
+constexpr uint32_t kPipeEscape = 64;
+
+// symbol -> c6 (see above); kind 0 = literal lengths, 1 = match lengths
+__device__ __forceinline__ uint32_t seq_code6(int kind, uint32_t s)
+{
+    if (kind == 0) {
+        if (s < 20) return s;                 // 0..15: 0 bits (classes 0-3); 16..19: 1 bit (class 4)
+        if (s < 22) return 20 + (s - 20);     // 2 bits (class 5)
+        if (s < 24) return 24 + (s - 22);     // 3 bits (class 6)
+        if (s == 24) return 28;               // 4 bits (class 7); class 8 (5 bits) does not exist
+        if (s < 32) return 36 + 4 * (s - 25); // 6..12 bits (classes 9..15)
+        return kPipeEscape;                   // 13..16 bits
+    }
+    if (s < 36) return s;                     // 0..31: 0 bits (classes 0-7); 32..35: 1 bit (class 8)
+    if (s < 38) return 36 + (s - 36);         // 2 bits (class 9)
+    if (s < 40) return 40 + (s - 38);         // 3 bits (class 10)
+    if (s < 42) return 44 + (s - 40);         // 4 bits (class 11)
+    if (s == 42) return 48;                   // 5 bits (class 12); class 13 (6 bits) does not exist
+    if (s == 43) return 56;                   // 7 bits (class 14)
+    if (s == 44) return 60;                   // 8 bits (class 15)
+    return kPipeEscape;                       // 9..16 bits
+}
+
+__device__ __forceinline__ uint32_t ffbh_raw(uint32_t x)  // v_ffbh_u32: clz, and -1 for 0 (wanted, see escape)
+{
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_sat(uint32_t a, uint32_t b)  // max(0, a - b) in one instruction
+{
+    uint32_t r;
+    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
+                                                  uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
+                                                  uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
+                                                  BlockSum *sums, uint32_t nch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *CTc = (uint32_t *)smem;  // [2][64] by c6: base(24) | extra(8)   (predefined.go:5-20,36-50)
+    PipeShared *shs = (PipeShared *)(smem + 512);
+    uint16_t *cells = (uint16_t *)(smem + kPipeFixedLds);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t tid = blockIdx.x * nch + lane;
+    const bool has = (uint32_t)lane < nch && tid < n_tasks;
+    SeqTask t;
+    if (has) t = tasks[tid];
+    else {
+        t.n_seq = 0; t.in_size = 0; t.ll_off = t.of_off = t.ml_off = 0; t.ll_log = t.of_log = t.ml_log = 0;
+        t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
+    }
+    if (wave == 3) {
+        CTc[lane] = 0;
+        CTc[64 + lane] = 0;
+        shs->progress[lane] = t.in_size;
+        shs->stC[lane] = MZD_OK;
+        if (lane == 0) { shs->head1 = 0; shs->tail1 = 0; shs->head2 = 0; shs->tail2 = 0; }
+        __builtin_amdgcn_s_waitcnt(0);  // the zero fill above before the scattered fill below (same wavefront: LDS is in order)
+        if (lane < 36 && seq_code6(0, lane) != kPipeEscape) CTc[seq_code6(0, lane)] = c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24);
+        if (lane < 53 && seq_code6(1, lane) != kPipeEscape) CTc[64 + seq_code6(1, lane)] = c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24);
+    }
+    // stage the three tables of every chain of this workgroup (all four wavefronts copy)
+    for (uint32_t ch = 0; ch < nch; ch++) {
+        if (blockIdx.x * nch + ch >= n_tasks) break;
+        uint32_t off[3], lg[3];
+        off[0] = (uint32_t)__shfl((int)t.ll_off, (int)ch, 64);
+        off[1] = (uint32_t)__shfl((int)t.ml_off, (int)ch, 64);
+        off[2] = (uint32_t)__shfl((int)t.of_off, (int)ch, 64);
+        lg[0] = (uint32_t)__shfl((int)t.ll_log, (int)ch, 64);
+        lg[1] = (uint32_t)__shfl((int)t.ml_log, (int)ch, 64);
+        lg[2] = (uint32_t)__shfl((int)t.of_log, (int)ch, 64);
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const uint32_t n = 1u << lg[kind];
+            const uint32_t base = ch * kSeqCellsPerChain + (uint32_t)kind * 512;
+            for (uint32_t i = threadIdx.x; i < n; i += 256) {
+                const uint32_t e = fse_entries[off[kind] + i];  // baseline(16) | nbits(8) | symbol(8)
+                const uint32_t baseline = e & 0xFFFF, nb = (e >> 16) & 0xFF, sym = e >> 24;
+                const uint32_t c6 = kind == 2 ? sym : seq_code6(kind, sym);
+                cells[base + i] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n) >> nb) | (c6 << 10));
+            }
+        }
+    }
+    __syncthreads();
+
+    // wave-uniform trip count; every wavefront computes the same value
+    const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(has ? t.n_seq : 0u));
+    int status = MZD_OK;
+
+    if (wave == 0) {
+        // ================= stage A: the serial chain =================
+        const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
+        SeqBits br;
+        int rem = 0;
+        uint32_t sL = 0, sM = 0, sO = 0;
+        bool live = has && t.n_seq > 0;
+        if (live) {
+            rem = br.init(in + t.in_off, (int)t.in_size);
+            if (rem < 0) {
+                status = MZD_ERR_BAD_PADDING;  // sequences.go:141-143
+                live = false;
+            } else {
+                // initial states in the order LL, OF, ML (sequences.go:145-159)
+                sL = br.peek(alL); br.k += alL;
+                sO = br.peek(alO); br.k += alO;
+                br.refill();
+                sM = br.peek(alM); br.k += alM;
+                rem -= alL + alO + alM;
+                if (rem < 0) { status = MZD_ERR_SEQ_BITS; live = false; }
+            }
+        }
+        const uint32_t sizeL = 1u << alL, sizeM = 1u << alM, sizeO = 1u << alO;
+        sL += sizeL; sM += sizeM; sO += sizeO;  // states are kept pre-biased by the table size
+        const uint32_t slot = live ? (uint32_t)lane * kSeqCellsPerChain : 0u;
+        auto park = [&]() { br.pd = in; br.C = br.D = 0; br.k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; };
+        if (!live) park();
+        const uint32_t nbL0 = (uint32_t)(alL - 31), nbM0 = (uint32_t)(alM - 31), nbO0 = (uint32_t)(alO - 31);  // nbits = acc_log - 31 + clz(next)
+        const uint16_t *cL = cells + slot - sizeL;
+        const uint16_t *cM = cells + slot + 512 - sizeM;
+        const uint16_t *cO = cells + slot + 1024 - sizeO;
+        const uint8_t *sbase = in + t.in_off;
+        const uint32_t last_i = t.n_seq - 1;  // parked lanes never look at it
+
+        uint32_t tail_seen = 0;
+        auto publish = [&](uint32_t at, uint64_t qt, uint32_t qp) {
+            while (at - tail_seen >= (uint32_t)kPipeDepth) {  // slot of step `at` is free once at - tail1 < depth
+                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->tail1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (at - tail_seen >= (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
+            }
+            shs->q1t[at % kPipeDepth][lane] = qt;
+            shs->q1p[at % kPipeDepth][lane] = qp;
+            asm volatile("" ::: "memory");
+            // every lane stores the same value to the same address: no exec juggling for "lane 0"
+            __hip_atomic_store(&shs->head1, at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // (symbol, next, base | extra << 24) of a literal-length / match-length cell, escape or not
+        auto full_cell = [&](int kind, uint32_t x, uint32_t idx, uint32_t toff, uint32_t size, uint32_t &next, uint32_t &ct) {
+            next = x & 1023;
+            ct = CTc[kind * 64 + (x >> 10)];
+            if (next == 0) {  // escape: the symbol is only in the host cell
+                const uint32_t e = fse_entries[toff + idx];
+                const uint32_t sym = e >> 24;
+                next = ((e & 0xFFFF) + size) >> ((e >> 16) & 0xFF);
+                ct = kind == 0 ? (c_ll_base[min(sym, 35u)] | ((uint32_t)c_ll_extra[min(sym, 35u)] << 24))
+                               : (c_ml_base[min(sym, 52u)] | ((uint32_t)c_ml_extra[min(sym, 52u)] << 24));
+            }
+        };
+        // general step of sequence `idx` for the lanes in `mine`
+        auto general_step = [&](uint32_t idx, bool mine, uint64_t &qt, uint32_t &qp) {
+            const bool lastseq = idx == last_i;
+            const uint32_t xl = cL[sL], xm = cM[sM], xo = cO[sO];
+            uint32_t nl = 1, nm = 1, cl = 0, cm = 0;
+            if (mine) {
+                full_cell(0, xl, sL - sizeL, t.ll_off, sizeL, nl, cl);
+                full_cell(1, xm, sM - sizeM, t.ml_off, sizeM, nm, cm);
+            }
+            const uint32_t no = xo & 1023, exO = xo >> 10;
+            uint32_t nbL = nbL0 + (uint32_t)__builtin_clz(nl | 1);
+            uint32_t nbM = nbM0 + (uint32_t)__builtin_clz(nm | 1);
+            uint32_t nbO = nbO0 + (uint32_t)__builtin_clz(no | 1);
+            if (lastseq) { nbL = 0; nbM = 0; nbO = 0; }  // sequences.go:178
+            const uint32_t exL = cl >> 24, exM = cm >> 24;
+            const int total = (int)(exO + exM + exL + nbL + nbM + nbO);
+            bool ok = mine;
+            if (mine && total > rem) {  // the cursor would pass the start of the stream
+                status = MZD_ERR_SEQ_BITS;
+                ok = false;
+            }
+            const uint32_t m = ok ? 0xFFFFFFFFu : 0u;  // lanes that do not step must not move their cursor
+            const int wO = (int)(exO & m), wM = (int)(exM & m), wL = (int)(exL & m);
+            const int vL = (int)(nbL & m), vM = (int)(nbM & m), vO = (int)(nbO & m);
+            const uint32_t ofx = br.peek(wO); br.k += wO; br.refill();
+            const uint32_t mlx = br.peek(wM); br.k += wM;
+            const uint32_t llx = br.peek(wL); br.k += wL; br.refill();
+            const uint32_t aL = br.peek(vL); br.k += vL;
+            const uint32_t aM = br.peek(vM); br.k += vM;
+            const uint32_t aO = br.peek(vO); br.k += vO;
+            if (ok) {
+                rem -= total;
+                sL = (nl << nbL) + aL; sM = (nm << nbM) + aM; sO = (no << nbO) + aO;  // fse.go:282-290
+                const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
+                qt = (uint64_t)((cl & 0xFFFFFF) + llx) | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                     ((uint64_t)ofv << kRecOffShift);
+                qp = 0x80000000u;
+            }
+            if (mine && (lastseq || !ok)) {
+                if (ok && rem != 0) status = MZD_ERR_SEQ_BITS;  // sequences.go:197-204
+                park();
+            }
+        };
+
+        uint32_t i = 0;
+        while (i < nmax) {
+            bool special = false;
+            uint64_t any_special = 0;
+            uint64_t qt = 0;
+            uint32_t qp = 0;
+            do {  // blocks of <= 16 steps: the cursor is published for wave P once per block
+                shs->progress[lane] = (uint32_t)max((int)(br.pd - sbase), 0);
+                const uint32_t iend = min(nmax, (i | 15u) + 1u);
+                do {
+                    const uint32_t xl = cL[sL], xm = cM[sM], xo = cO[sO];
+                    br.refill();  // overlaps the LDS latency of the cells
+                    const uint32_t exO = xo >> 10;
+                    const uint32_t exL = sub_sat(xl >> 12, 3u), exM = sub_sat(xm >> 12, 7u);
+                    const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
+                    const uint32_t nbL = nbL0 + ffbh_raw(nl);  // escape: next = 0 -> clz = -1 -> nbits < 0
+                    const uint32_t nbM = nbM0 + ffbh_raw(nm);
+                    const uint32_t nbO = nbO0 + ffbh_raw(no);
+                    // bit offsets in stream order: OF extra, ML extra, LL extra | LL state, ML state, OF state
+                    const uint32_t o3 = exO + exM + exL;
+                    const uint32_t c1 = o3 + nbL, c2 = c1 + nbM, total = c2 + nbO;
+                    // k stays < 64 (the refill shifts by 8 * (k >> 3)); never past the start of the stream;
+                    // unsigned: a wrapped total (escape) is larger than any limit, a parked lane has limit 0
+                    // (an escape makes its nbits negative: OR-ing them in sets bit 31 even if the sum wrapped back)
+                    const bool go = (total | nbL | nbM) <= (uint32_t)min(63 - br.k, rem);
+                    const uint64_t T = br.C << br.k;
+                    const uint32_t X = (uint32_t)((T << o3) >> 32);  // the <= 26 state bits start at bit 31
+                    const uint32_t tb = 32 + o3;
+                    const uint32_t aL = __builtin_amdgcn_ubfe(X, tb - c1, nbL);
+                    const uint32_t aM = __builtin_amdgcn_ubfe(X, tb - c2, nbM);
+                    const uint32_t aO = __builtin_amdgcn_ubfe(X, tb - total, nbO);
+                    qt = T;
+                    qp = __builtin_amdgcn_perm(xo, __builtin_amdgcn_perm(xm, xl, 0x0c0c0501u), 0x0c050100u);
+                    special = live && (!go || i == last_i);
+                    const bool adv = go && !special;
+                    const int n = adv ? (int)total : 0;
+                    sL = adv ? (nl << nbL) + aL : sL;
+                    sM = adv ? (nm << nbM) + aM : sM;
+                    sO = adv ? (no << nbO) + aO : sO;
+                    br.k += n;
+                    rem -= n;
+                    any_special = __builtin_amdgcn_ballot_w64(special);
+                    if (!any_special) publish(i, qt, qp);
+                    i++;
+                } while (i < iend && !any_special);
+            } while (i < nmax && !any_special);
+            if (any_special) {
+                general_step(i - 1, special, qt, qp);
+                publish(i - 1, qt, qp);
+            }
+        }
+    } else if (wave == 1) {
+        // ================= stage B: field extraction and values, four steps at a time =================
+        uint32_t head_seen = 0, tail_seen = 0;
+        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+            const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+            while (head_seen < need) {
+                head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head_seen < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            uint64_t T[kPipeBatch];
+            uint32_t P[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) {
+                T[u] = shs->q1t[(j0 + u) % kPipeDepth][lane];
+                P[u] = shs->q1p[(j0 + u) % kPipeDepth][lane];
+            }
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->tail1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint64_t q[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) {
+                const uint32_t cl = CTc[__builtin_amdgcn_ubfe(P[u], 2, 6)];
+                const uint32_t cm = CTc[64 + __builtin_amdgcn_ubfe(P[u], 10, 6)];
+                const uint32_t exO = __builtin_amdgcn_ubfe(P[u], 18, 6);
+                const uint32_t hi = (uint32_t)(T[u] >> 32);
+                const uint32_t exL = cl >> 24, exM = cm >> 24;
+                const uint32_t ofx = __builtin_amdgcn_ubfe(hi, 32u - exO, exO);
+                const uint32_t Y = (uint32_t)((T[u] << exO) >> 32);
+                const uint32_t mlx = __builtin_amdgcn_ubfe(Y, 32u - exM, exM);
+                const uint32_t llx = __builtin_amdgcn_ubfe(Y, 32u - exM - exL, exL);
+                const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
+                const uint64_t v = (uint64_t)((cl & 0xFFFFFF) + llx) | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                   ((uint64_t)ofv << kRecOffShift);
+                q[u] = (P[u] >> 31) ? T[u] : v;
+            }
+            while (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) {
+                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->tail2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][lane] = q[u];
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->head2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (wave == 2) {
+        // ================= stage C: sums, offset history, records =================
+        int h0, h1, h2;
+        if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
+        else { h0 = -1; h1 = -2; h2 = -3; }
+        uint32_t litPos = 0, outPos = 0;
+        uint64_t *myrec = recs + t.rec_off;
+        TileBase *mytile = tiles + t.tile_off;
+        uint32_t head_seen = 0;
+        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+            const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+            while (head_seen < need) {
+                head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->head2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head_seen < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            uint64_t q[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][lane];
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((j0 & 63) == 0 && has && j0 < t.n_seq && status == MZD_OK) mytile[j0 >> 6] = TileBase{litPos, outPos};
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) {
+                const uint32_t j = j0 + u;
+                const bool act = has && j < t.n_seq && status == MZD_OK;
+                const uint32_t LL = (uint32_t)q[u] & kRecLlMask;
+                const uint32_t ML = (uint32_t)(q[u] >> kRecMlShift) & kRecMlMask;
+                const uint32_t ofv = (uint32_t)(q[u] >> kRecOffShift);
+                const bool isnew = ofv > 3;
+                const int idx = isnew ? 4 : (int)ofv - 1 + (LL == 0 ? 1 : 0);  // 0..3 repeat cases, 4 = new offset
+                int off = idx == 0 ? h0 : (idx == 1 ? h1 : (idx == 2 ? h2 : hist_dec(h0)));
+                if (isnew) off = (int)(ofv - 3);
+                if (act) {
+                    if (ofv >= kRecOffSymbolic) status = MZD_ERR_UNSUPPORTED;  // offset value >= 2^28
+                    else if (off == 0) status = MZD_ERR_OFFSET;
+                    if (idx >= 2) h2 = h1;
+                    if (idx >= 1) { h1 = h0; h0 = off; }
+                    litPos += LL;
+                    outPos += LL + ML;
+                    if (outPos > kBlockMax && status == MZD_OK) status = MZD_ERR_CORRUPT_SIZES;  // a block regenerates <= 128 KiB
+                }
+                if (act && status == MZD_OK) {
+                    const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
+                    myrec[j] = (q[u] & ((1ull << kRecOffShift) - 1)) | ((uint64_t)offfield << kRecOffShift);
+                }
+            }
+        }
+        if (has && t.n_seq > 0) {
+            BlockSum *bs = &sums[t.block];
+            bs->lit_total = litPos;
+            bs->out_total = outPos;
+            bs->hist[0] = h0;
+            bs->hist[1] = h1;
+            bs->hist[2] = h2;
+        }
+        shs->stC[lane] = status;
+    } else {
+        // ================= wave P: touch the bitstream lines ahead of stage A =================
+        const uint8_t *sbase = in + t.in_off;
+        int low = (int)t.in_size;  // everything at or above `low` has been requested
+        constexpr int kAhead = MZD_PIPE_AHEAD, kLine = 128;
+        for (;;) {
+            const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)__hip_atomic_load(&shs->head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const int cur = (int)__hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int target = max(cur - kAhead, 0);
+            int guard = 0;
+            while (has && low > target && guard < 8) {
+                low = max(low - kLine, 0);
+                touch_line(sbase + (low & ~3));
+                guard++;
+            }
+            if (hd >= nmax) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    // decode-stage errors come first, as in the reference, where DecodeSequences runs to its end
+    // before ExecuteSequences starts
+    if (wave == 0 && has && t.n_seq > 0) {
+        int st = status;
+        if (st == MZD_OK) st = shs->stC[lane];
+        if (st != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, st);
     }
 }
 

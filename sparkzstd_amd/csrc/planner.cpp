@@ -515,7 +515,8 @@ struct FrameParser {
             out.blocks.push_back(bd);
         }
         out.consumed = p - begin;
-        out.out_bound = out.content_size != MZD_UNKNOWN_SIZE ? out.content_size : bound;
+        // never more than the blocks can regenerate: a (corrupt) header may declare any content size
+        out.out_bound = out.content_size != MZD_UNKNOWN_SIZE ? std::min<uint64_t>(out.content_size, bound) : bound;
     }
 };
 

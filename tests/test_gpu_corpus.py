@@ -22,7 +22,7 @@ def _decode(frames, ctx):
     return outs, sts
 
 
-@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (2, 128), (0, 128), (0, 64), (1, 64)])
+@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (2, 128), (3, 128), (3, 256), (0, 128), (0, 64), (1, 64)])
 def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
@@ -202,3 +202,36 @@ def test_corrupt_input_reports_status_not_fault(corpus, ctx):
     outs2, sts2 = _decode([bytes(comp)], ctx)
     assert sts2 == [0]
     check_expected(name, outs2[0], length, sha, exp)
+
+
+@pytest.mark.parametrize("seq_variant", [0, 3])
+def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant):
+    """Every corpus frame, mutated 6 times (random byte flips past the frame header, seeded), all
+    in ONE device batch.  The device must not fault; a frame it reports as decoded must be one
+    the oracle decodes to the same bytes, and a frame the oracle rejects must carry a status."""
+    rng = np.random.default_rng(20260101)
+    frames = []
+    for _, comp, *_ in corpus:
+        if len(comp) < 24:
+            continue
+        for k in range(6):
+            b = bytearray(comp)
+            nflip = 1 + (k % 3)
+            for pos in rng.integers(8, len(b), size=nflip):
+                b[int(pos)] ^= int(rng.integers(1, 256))
+            frames.append(bytes(b))
+    c = z.Context(0, seq_variant=seq_variant)
+    outs, sts = _decode(frames, c)
+    n_ok = 0
+    for f, o, s in zip(frames, outs, sts):
+        rc, want, _, _ = oracle.decode_frame(f, cap=4 << 20)
+        if s == 0:
+            assert rc == 0, (oracle.strerror(rc), len(f))
+            assert o == want
+            n_ok += 1
+        if rc != 0:
+            assert s != 0
+    assert 0 < n_ok < len(frames)  # some mutations are harmless (unread checksum, literals), most are not
+    # the context survives
+    outs2, sts2 = _decode([corpus[3][1]], c)
+    assert sts2 == [0]
