@@ -37,6 +37,7 @@ struct mzd_dbatch {
     // device memory
     uint8_t *d_in_alloc = nullptr;  // owned input allocation (with padding) or null when adopted
     const uint8_t *d_in = nullptr;
+    uint64_t in_size = 0;
     uint8_t *d_out = nullptr;
     bool own_out = false;
     DFrame *d_frames = nullptr;
@@ -407,12 +408,14 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
 
     if (b->flags & MZD_BATCH_IN_ON_DEVICE) {
         db->d_in = b->in;
+        db->in_size = b->in_size;
     } else {
         HIP_OR_FAIL(hipMalloc((void **)&db->d_in_alloc, b->in_size + 2 * MZD_IN_PAD));
         HIP_OR_FAIL(hipMemset(db->d_in_alloc, 0, MZD_IN_PAD));
         HIP_OR_FAIL(hipMemset(db->d_in_alloc + MZD_IN_PAD + b->in_size, 0, MZD_IN_PAD));
         if (b->in_size) HIP_OR_FAIL(hipMemcpy(db->d_in_alloc + MZD_IN_PAD, b->in, b->in_size, hipMemcpyHostToDevice));
         db->d_in = db->d_in_alloc + MZD_IN_PAD;
+        db->in_size = b->in_size;
     }
     if ((b->flags & MZD_BATCH_OUT_ON_DEVICE) && b->out) {
         db->d_out = b->out;
@@ -479,7 +482,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // the last, partial round leaves most CUs idle.  The batch is cut at the frame where the full rounds
     // end: k_seq(tail) then runs on the caller's stream while k_exec(head) fills the idle CUs from a
     // second stream (frames are independent, so the two never touch the same data).
-    const bool pipe = ctx->opt.seq_variant == 3;
+    // k_seq_pipe addresses the bitstreams with 32-bit offsets from the blob's front slack
+    const bool pipe = ctx->opt.seq_variant == 3 && db->in_size + 2 * MZD_IN_PAD < (1ull << 32);
     const uint32_t nch = pipe ? (uint32_t)kPipeMaxChains
                               : (ctx->opt.seq_variant == 2 ? (uint32_t)kQuadChains : (cell16 ? kSeqChains16 : kSeqChains32));
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);

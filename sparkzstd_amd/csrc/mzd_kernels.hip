@@ -959,6 +959,8 @@ __global__ __launch_bounds__(320) void k_seq_quad(const uint8_t *__restrict__ in
 //
 // LDS: [CTc 128 dwords][PipeShared][cells: nch x 1280 x u16], nch <= kPipeMaxChains at launch.
 
+#define MZD_STR2(x) #x
+#define MZD_STR(x) MZD_STR2(x)
 constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
 #ifndef MZD_PIPE_AHEAD
 #define MZD_PIPE_AHEAD 256  // bytes wave P keeps touched below every chain's cursor
@@ -1032,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     if (wave == 3) {
         CTc[lane] = 0;
         CTc[64 + lane] = 0;
-        shs->progress[lane] = t.in_size;
+        shs->progress[lane] = (uint32_t)t.in_off + MZD_IN_PAD + t.in_size;
         shs->stC[lane] = MZD_OK;
         if (lane == 0) { shs->head1 = 0; shs->tail1 = 0; shs->head2 = 0; shs->tail2 = 0; }
         __builtin_amdgcn_s_waitcnt(0);  // the zero fill above before the scattered fill below (same wavefront: LDS is in order)
@@ -1070,21 +1072,36 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     if (wave == 0) {
         // ================= stage A: the serial chain =================
         const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
-        SeqBits br;
-        int rem = 0;
+        // bit window as in SeqBits, with the refill address as a 32-bit offset from the start of the
+        // blob's front slack (the whole blob, slack included, is < 4 GiB for this kernel: mzd_batch_run checks)
+        const uint8_t *inb = in - MZD_IN_PAD;
+        uint64_t C = 0, D = 0;
+        uint32_t off = 0;
+        int k = 0, rem = 0;
+        auto refill = [&]() {
+            const int nb = k >> 3, sh = nb * 8;
+            C = (C << sh) | ((D >> 1) >> (63 - sh));
+            off -= (uint32_t)nb;
+            k &= 7;
+            asm volatile("" ::"v"((uint32_t)C), "v"((uint32_t)(C >> 32)) : "memory");  // see SeqBits::refill
+            D = ld64u(inb + off);
+        };
+        auto peek = [&](int n) -> uint32_t { return (uint32_t)(((C << k) >> 1) >> (63 - n)); };
         uint32_t sL = 0, sM = 0, sO = 0;
         bool live = has && t.n_seq > 0;
         if (live) {
+            SeqBits br;
             rem = br.init(in + t.in_off, (int)t.in_size);
+            C = br.C; D = br.D; k = br.k; off = (uint32_t)(br.pd - inb);
             if (rem < 0) {
                 status = MZD_ERR_BAD_PADDING;  // sequences.go:141-143
                 live = false;
             } else {
                 // initial states in the order LL, OF, ML (sequences.go:145-159)
-                sL = br.peek(alL); br.k += alL;
-                sO = br.peek(alO); br.k += alO;
-                br.refill();
-                sM = br.peek(alM); br.k += alM;
+                sL = peek(alL); k += alL;
+                sO = peek(alO); k += alO;
+                refill();
+                sM = peek(alM); k += alM;
                 rem -= alL + alO + alM;
                 if (rem < 0) { status = MZD_ERR_SEQ_BITS; live = false; }
             }
@@ -1092,28 +1109,33 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         const uint32_t sizeL = 1u << alL, sizeM = 1u << alM, sizeO = 1u << alO;
         sL += sizeL; sM += sizeM; sO += sizeO;  // states are kept pre-biased by the table size
         const uint32_t slot = live ? (uint32_t)lane * kSeqCellsPerChain : 0u;
-        auto park = [&]() { br.pd = in; br.C = br.D = 0; br.k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; };
+        uint32_t last_i = t.n_seq - 1;
+        // parked: limit 0, cell 0 of its slot, refills from the (readable) front slack of the blob
+        auto park = [&]() { off = 0; C = D = 0; k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; last_i = 0xFFFFFFFFu; };
         if (!live) park();
         const uint32_t nbL0 = (uint32_t)(alL - 31), nbM0 = (uint32_t)(alM - 31), nbO0 = (uint32_t)(alO - 31);  // nbits = acc_log - 31 + clz(next)
         const uint16_t *cL = cells + slot - sizeL;
         const uint16_t *cM = cells + slot + 512 - sizeM;
         const uint16_t *cO = cells + slot + 1024 - sizeO;
-        const uint8_t *sbase = in + t.in_off;
-        const uint32_t last_i = t.n_seq - 1;  // parked lanes never look at it
 
         uint32_t tail_seen = 0;
-        auto publish = [&](uint32_t at, uint64_t qt, uint32_t qp) {
-            while (at - tail_seen >= (uint32_t)kPipeDepth) {  // slot of step `at` is free once at - tail1 < depth
+#ifdef MZD_PIPE_PROF
+        long long prof_wait = 0, prof_t0 = clock64(), prof_r0 = wall_clock64();
+#endif
+        auto wait_space = [&](uint32_t at) {  // slot of step `at` is free once at - tail1 < depth
+#ifdef MZD_PIPE_PROF
+            const long long w0 = clock64();
+#endif
+            while (at - tail_seen >= (uint32_t)kPipeDepth) {
                 tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
                     (int)__hip_atomic_load(&shs->tail1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (at - tail_seen >= (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
             }
-            shs->q1t[at % kPipeDepth][lane] = qt;
-            shs->q1p[at % kPipeDepth][lane] = qp;
-            asm volatile("" ::: "memory");
-            // every lane stores the same value to the same address: no exec juggling for "lane 0"
-            __hip_atomic_store(&shs->head1, at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MZD_PIPE_PROF
+            prof_wait += clock64() - w0;
+#endif
         };
+        (void)wait_space;  // used by the C++ statement of the hot loop only
         // (symbol, next, base | extra << 24) of a literal-length / match-length cell, escape or not
         auto full_cell = [&](int kind, uint32_t x, uint32_t idx, uint32_t toff, uint32_t size, uint32_t &next, uint32_t &ct) {
             next = x & 1023;
@@ -1126,8 +1148,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                                : (c_ml_base[min(sym, 52u)] | ((uint32_t)c_ml_extra[min(sym, 52u)] << 24));
             }
         };
-        // general step of sequence `idx` for the lanes in `mine`
-        auto general_step = [&](uint32_t idx, bool mine, uint64_t &qt, uint32_t &qp) {
+        // General step of sequence `idx` for the lanes in `mine` (their queue entries of this step are
+        // rewritten as mode 1); the other lanes' entries are already in the slot.
+        auto general_step = [&](uint32_t idx, bool mine) {
             const bool lastseq = idx == last_i;
             const uint32_t xl = cL[sL], xm = cM[sM], xo = cO[sO];
             uint32_t nl = 1, nm = 1, cl = 0, cm = 0;
@@ -1150,19 +1173,20 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             const uint32_t m = ok ? 0xFFFFFFFFu : 0u;  // lanes that do not step must not move their cursor
             const int wO = (int)(exO & m), wM = (int)(exM & m), wL = (int)(exL & m);
             const int vL = (int)(nbL & m), vM = (int)(nbM & m), vO = (int)(nbO & m);
-            const uint32_t ofx = br.peek(wO); br.k += wO; br.refill();
-            const uint32_t mlx = br.peek(wM); br.k += wM;
-            const uint32_t llx = br.peek(wL); br.k += wL; br.refill();
-            const uint32_t aL = br.peek(vL); br.k += vL;
-            const uint32_t aM = br.peek(vM); br.k += vM;
-            const uint32_t aO = br.peek(vO); br.k += vO;
+            const uint32_t ofx = peek(wO); k += wO; refill();
+            const uint32_t mlx = peek(wM); k += wM;
+            const uint32_t llx = peek(wL); k += wL; refill();
+            const uint32_t aL = peek(vL); k += vL;
+            const uint32_t aM = peek(vM); k += vM;
+            const uint32_t aO = peek(vO); k += vO;
             if (ok) {
                 rem -= total;
                 sL = (nl << nbL) + aL; sM = (nm << nbM) + aM; sO = (no << nbO) + aO;  // fse.go:282-290
                 const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
-                qt = (uint64_t)((cl & 0xFFFFFF) + llx) | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
-                     ((uint64_t)ofv << kRecOffShift);
-                qp = 0x80000000u;
+                shs->q1t[idx % kPipeDepth][lane] = (uint64_t)((cl & 0xFFFFFF) + llx) |
+                                                   ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                                   ((uint64_t)ofv << kRecOffShift);
+                shs->q1p[idx % kPipeDepth][lane] = 0x80000000u;
             }
             if (mine && (lastseq || !ok)) {
                 if (ok && rem != 0) status = MZD_ERR_SEQ_BITS;  // sequences.go:197-204
@@ -1170,67 +1194,230 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             }
         };
 
+        // ---- the hot loop.  Runs steps until a lane needs the general step (returns the mask of those
+        // lanes; their step is NOT done, everybody's queue entry IS written, head1 not yet moved) or
+        // nmax is reached.  One step = refill, three cell reads, bit counts, three state fields.
         uint32_t i = 0;
+#ifdef MZD_PIPE_PROF2
+        uint32_t prof_vm = 0, prof_lds = 0;
+#endif
+        const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u, vzero = 0;
+        // LDS byte addresses of cL / cM / cO
+        const uint32_t cbL = kPipeFixedLds + 2u * (slot - sizeL), cbM = kPipeFixedLds + 2u * (slot + 512 - sizeM),
+                       cbO = kPipeFixedLds + 2u * (slot + 1024 - sizeO);
         while (i < nmax) {
-            bool special = false;
-            uint64_t any_special = 0;
-            uint64_t qt = 0;
-            uint32_t qp = 0;
-            do {  // blocks of <= 16 steps: the cursor is published for wave P once per block
-                shs->progress[lane] = (uint32_t)max((int)(br.pd - sbase), 0);
-                const uint32_t iend = min(nmax, (i | 15u) + 1u);
-                do {
-                    const uint32_t xl = cL[sL], xm = cM[sM], xo = cO[sO];
-                    br.refill();  // overlaps the LDS latency of the cells
-                    const uint32_t exO = xo >> 10;
-                    const uint32_t exL = sub_sat(xl >> 12, 3u), exM = sub_sat(xm >> 12, 7u);
-                    const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
-                    const uint32_t nbL = nbL0 + ffbh_raw(nl);  // escape: next = 0 -> clz = -1 -> nbits < 0
-                    const uint32_t nbM = nbM0 + ffbh_raw(nm);
-                    const uint32_t nbO = nbO0 + ffbh_raw(no);
-                    // bit offsets in stream order: OF extra, ML extra, LL extra | LL state, ML state, OF state
-                    const uint32_t o3 = exO + exM + exL;
-                    const uint32_t c1 = o3 + nbL, c2 = c1 + nbM, total = c2 + nbO;
-                    // k stays < 64 (the refill shifts by 8 * (k >> 3)); never past the start of the stream;
-                    // unsigned: a wrapped total (escape) is larger than any limit, a parked lane has limit 0
-                    // (an escape makes its nbits negative: OR-ing them in sets bit 31 even if the sum wrapped back)
-                    const bool go = (total | nbL | nbM) <= (uint32_t)min(63 - br.k, rem);
-                    const uint64_t T = br.C << br.k;
-                    const uint32_t X = (uint32_t)((T << o3) >> 32);  // the <= 26 state bits start at bit 31
-                    const uint32_t tb = 32 + o3;
-                    const uint32_t aL = __builtin_amdgcn_ubfe(X, tb - c1, nbL);
-                    const uint32_t aM = __builtin_amdgcn_ubfe(X, tb - c2, nbM);
-                    const uint32_t aO = __builtin_amdgcn_ubfe(X, tb - total, nbO);
-                    qt = T;
-                    qp = __builtin_amdgcn_perm(xo, __builtin_amdgcn_perm(xm, xl, 0x0c0c0501u), 0x0c050100u);
-                    special = live && (!go || i == last_i);
-                    const bool adv = go && !special;
-                    const int n = adv ? (int)total : 0;
-                    sL = adv ? (nl << nbL) + aL : sL;
-                    sM = adv ? (nm << nbM) + aM : sM;
-                    sO = adv ? (no << nbO) + aO : sO;
-                    br.k += n;
-                    rem -= n;
-                    any_special = __builtin_amdgcn_ballot_w64(special);
-                    if (!any_special) publish(i, qt, qp);
-                    i++;
-                } while (i < iend && !any_special);
-            } while (i < nmax && !any_special);
-            if (any_special) {
-                general_step(i - 1, special, qt, qp);
-                publish(i - 1, qt, qp);
+            uint64_t smask = 0;
+#ifdef MZD_PIPE_CXX_STEP
+            do {
+                wait_space(i);
+                shs->progress[lane] = off;
+                const uint32_t xl = cL[sL], xm = cM[sM], xo = cO[sO];
+                refill();  // overlaps the LDS latency of the cells
+                const uint32_t exO = xo >> 10;
+                const uint32_t exL = sub_sat(xl >> 12, 3u), exM = sub_sat(xm >> 12, 7u);
+                const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
+                const uint32_t nbL = nbL0 + ffbh_raw(nl);  // escape: next = 0 -> clz = -1 -> nbits < 0
+                const uint32_t nbM = nbM0 + ffbh_raw(nm);
+                const uint32_t nbO = nbO0 + ffbh_raw(no);
+                // bit offsets in stream order: OF extra, ML extra, LL extra | LL state, ML state, OF state
+                const uint32_t o3 = exO + exM + exL;
+                const uint32_t c1 = o3 + nbL, c2 = c1 + nbM, total = c2 + nbO;
+                // k stays < 64 (the refill shifts by 8 * (k >> 3)); never past the start of the stream;
+                // unsigned: a parked lane has limit 0; an escape makes its nbits negative, and OR-ing
+                // them in keeps bit 31 set even if the sum wrapped back
+                const bool go = (total | nbL | nbM) <= (uint32_t)min(63 - k, rem);
+                const bool last = i == last_i;  // never true for a parked lane (last_i = ~0)
+                const uint64_t T = C << k;
+                const uint32_t X = (uint32_t)((T << o3) >> 32);  // the <= 26 state bits start at bit 31
+                const uint32_t tb = 32 + o3;
+                const uint32_t aL = __builtin_amdgcn_ubfe(X, tb - c1, nbL);
+                const uint32_t aM = __builtin_amdgcn_ubfe(X, tb - c2, nbM);
+                const uint32_t aO = __builtin_amdgcn_ubfe(X, tb - total, nbO);
+                const bool adv = go && !last;
+                const int n = adv ? (int)total : 0;
+                sL = adv ? (nl << nbL) + aL : sL;
+                sM = adv ? (nm << nbM) + aM : sM;
+                sO = adv ? (no << nbO) + aO : sO;
+                k += n;
+                rem -= n;
+                shs->q1t[i % kPipeDepth][lane] = T;
+                shs->q1p[i % kPipeDepth][lane] =
+                    __builtin_amdgcn_perm(xo, __builtin_amdgcn_perm(xm, xl, 0x0c0c0501u), 0x0c050100u);
+                smask = __builtin_amdgcn_ballot_w64(last || (live && !go));
+                i++;
+                if (!smask) {
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_store(&shs->head1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } while (i < nmax && !smask);
+#else
+            {
+                // The same step, hand-scheduled: as a lone wavefront pays ~4.4 cycles per instruction of any
+                // kind, the instruction count IS the step latency (~85 here; hipcc's version of the C++
+                // statement above: ~110).  The refill load of a step is issued FIRST and merged into the
+                // window one step later, after that step's cell decode: a 59-line gather takes ~450
+                // cycles to come back.  Two D registers alternate, so the loop body is the step twice.
+                // Temporaries are fixed registers v200..v231 / s[86:93].
+                const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
+                const uint32_t sel1 = 0x0c0c0501u, sel2 = 0x0c050100u;
+                uint64_t D2 = 0;
+#define MZD_PIPE_STEP(DM, DL, TAG)                                                                          \
+    "L_pipe_top" TAG "_%=:\n\t"                                                                             \
+    "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
+    "s_cmp_lt_u32 s86, %[depth]\n\t"                                                                        \
+    "s_cbranch_scc1 L_pipe_go" TAG "_%=\n"                                                                  \
+    "L_pipe_poll" TAG "_%=:\n\t"                                                                            \
+    "ds_read_b32 v200, %[vzero] offset:%[o_tail1]\n\t"                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_readfirstlane_b32 %[tail], v200\n\t"                                                                 \
+    "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
+    "s_cmp_lt_u32 s86, %[depth]\n\t"                                                                        \
+    "s_cbranch_scc1 L_pipe_go" TAG "_%=\n\t"                                                                \
+    "s_sleep 1\n\t"                                                                                         \
+    "s_branch L_pipe_poll" TAG "_%=\n"                                                                      \
+    "L_pipe_go" TAG "_%=:\n\t"                                                                              \
+    /* next refill load first: off -= k >> 3; DL = 8 bytes at off */                                        \
+    "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
+    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
+    "global_load_dwordx2 " DL ", %[off], %[inb]\n\t"                                                        \
+    "v_lshl_add_u32 v200, %[sL], 1, %[cbL]\n\t"                                                             \
+    "v_lshl_add_u32 v201, %[sM], 1, %[cbM]\n\t"                                                             \
+    "v_lshl_add_u32 v202, %[sO], 1, %[cbO]\n\t"                                                             \
+    "ds_read_u16 v203, v200\n\t" /* xl */                                                                   \
+    "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
+    "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
+    "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"                                                    \
+    /* C <<= 8 * (k >> 3); k &= 7 (the bytes that come in from DM are merged below) */                      \
+    "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
+    "v_sub_u32 v208, 63, v206\n\t"                                                                          \
+    "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
+    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_lshrrev_b32 v214, 10, v205\n\t" /* exO */                                                            \
+    "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
+    "v_sub_u32_e64 v215, v215, 3 clamp\n\t" /* exL */                                                       \
+    "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
+    "v_sub_u32_e64 v216, v216, 7 clamp\n\t" /* exM */                                                       \
+    "v_and_b32 v217, 0x3ff, v203\n\t"       /* nl */                                                        \
+    "v_and_b32 v218, 0x3ff, v204\n\t"       /* nm */                                                        \
+    "v_and_b32 v219, 0x3ff, v205\n\t"       /* no */                                                        \
+    "v_ffbh_u32 v220, v217\n\t"                                                                             \
+    "v_ffbh_u32 v221, v218\n\t"                                                                             \
+    "v_ffbh_u32 v222, v219\n\t"                                                                             \
+    "v_add_u32 v220, v220, %[nbL0]\n\t" /* nbL */                                                           \
+    "v_add_u32 v221, v221, %[nbM0]\n\t" /* nbM */                                                           \
+    "v_add_u32 v222, v222, %[nbO0]\n\t" /* nbO */                                                           \
+    "v_add3_u32 v223, v214, v216, v215\n\t" /* o3 */                                                        \
+    "v_add_u32 v224, v223, v220\n\t"        /* c1 */                                                        \
+    "v_add3_u32 v225, v223, v220, v221\n\t" /* c2 */                                                        \
+    "v_add_u32 v230, v225, v222\n\t"        /* total */                                                     \
+    "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
+    "v_sub_u32 v228, 63, %[k]\n\t"                                                                          \
+    "v_min_i32 v228, v228, %[rem]\n\t"                                                                      \
+    "v_cmp_le_u32 vcc, v227, v228\n\t"                  /* go */                                            \
+    "v_cmp_eq_u32_e64 s[88:89], %[i], %[last]\n\t"      /* last sequence of the lane */                     \
+    "s_andn2_b64 s[90:91], vcc, s[88:89]\n\t"           /* adv = go & ~last */                              \
+    "s_andn2_b64 s[92:93], %[live], vcc\n\t"                                                                \
+    "s_or_b64 %[smask], s[92:93], s[88:89]\n\t"         /* special = last | (live & ~go) */                 \
+    "v_add_u32 v229, 32, v223\n\t"                                                                          \
+    "v_sub_u32 v224, v229, v224\n\t"                                                                        \
+    "v_sub_u32 v225, v229, v225\n\t"                                                                        \
+    "v_sub_u32 v226, v229, v230\n\t"                                                                        \
+    "v_cndmask_b32_e64 v230, 0, v230, s[90:91]\n\t"                                                         \
+    "v_sub_u32 %[rem], %[rem], v230\n\t"                                                                    \
+    /* merge the bytes of the load issued one step ago: C += (DM >> 1) >> (63 - 8nb) */                     \
+    "s_waitcnt vmcnt(1)\n\t"                                                                                \
+    "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
+    "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
+    "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
+    "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T */                                             \
+    "v_lshlrev_b64 v[210:211], v223, v[212:213]\n\t"    /* X = T << o3 (high half used) */                  \
+    "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
+    "v_bfe_u32 v224, v211, v224, v220\n\t" /* aL */                                                         \
+    "v_bfe_u32 v225, v211, v225, v221\n\t" /* aM */                                                         \
+    "v_bfe_u32 v226, v211, v226, v222\n\t" /* aO */                                                         \
+    "v_lshl_add_u32 v224, v217, v220, v224\n\t"                                                             \
+    "v_lshl_add_u32 v225, v218, v221, v225\n\t"                                                             \
+    "v_lshl_add_u32 v226, v219, v222, v226\n\t"                                                             \
+    "v_cndmask_b32_e64 %[sL], %[sL], v224, s[90:91]\n\t"                                                    \
+    "v_cndmask_b32_e64 %[sM], %[sM], v225, s[90:91]\n\t"                                                    \
+    "v_cndmask_b32_e64 %[sO], %[sO], v226, s[90:91]\n\t"                                                    \
+    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
+    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"                                                              \
+    "s_and_b32 s86, %[i], %[depthm1]\n\t"                                                                   \
+    "s_lshl_b32 s87, s86, 9\n\t"                                                                            \
+    "v_add_u32 v200, s87, %[lane8]\n\t"                                                                     \
+    "ds_write_b64 v200, v[212:213] offset:%[o_q1t]\n\t"                                                     \
+    "s_lshl_b32 s87, s86, 8\n\t"                                                                            \
+    "v_add_u32 v201, s87, %[lane4]\n\t"                                                                     \
+    "ds_write_b32 v201, v231 offset:%[o_q1p]\n\t"                                                           \
+    "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
+    "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
+    "s_cbranch_scc1 L_pipe_out" TAG "_%=\n\t"                                                               \
+    "v_mov_b32 v202, %[i]\n\t"                                                                              \
+    "ds_write_b32 %[vzero], v202 offset:%[o_head1]\n\t"                                                     \
+    "s_cmp_lt_u32 %[i], %[nmax]\n\t"
+                asm volatile(
+                    // entry: %[D] holds the bytes below the window (valid), %[D2] is free
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "a")
+                    "s_cbranch_scc0 L_pipe_outa_%=\n\t"
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "b")
+                    "s_cbranch_scc1 L_pipe_topa_%=\n\t"
+                    "s_branch L_pipe_outb_%=\n"
+                    "L_pipe_outa_%=:\n\t"  // left after the first half: the current lookahead is in D2
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "v_lshlrev_b64 %[D], 0, %[D2]\n\t"
+                    "L_pipe_outb_%=:\n\t"
+                    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                    : [sL] "+v"(sL), [sM] "+v"(sM), [sO] "+v"(sO), [k] "+v"(k), [rem] "+v"(rem), [off] "+v"(off),
+                      [C] "+v"(C), [D] "+v"(D), [D2] "+v"(D2), [i] "+s"(i), [tail] "+s"(tail_seen), [smask] "=&s"(smask)
+                    : [cbL] "v"(cbL), [cbM] "v"(cbM), [cbO] "v"(cbO), [nbL0] "v"(nbL0), [nbM0] "v"(nbM0), [nbO0] "v"(nbO0),
+                      [last] "v"(last_i), [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [nmax] "s"(nmax),
+                      [live] "s"(livemask), [inb] "s"(inb), [sel1] "s"(sel1), [sel2] "s"(sel2),
+                      [depth] "n"(kPipeDepth), [depthm1] "n"(kPipeDepth - 1),
+                      [o_tail1] "n"(512 + offsetof(PipeShared, tail1)), [o_head1] "n"(512 + offsetof(PipeShared, head1)),
+                      [o_prog] "n"(512 + offsetof(PipeShared, progress)), [o_q1t] "n"(512 + offsetof(PipeShared, q1t)),
+                      [o_q1p] "n"(512 + offsetof(PipeShared, q1p))
+                    : "memory", "vcc", "scc", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+                      "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v210", "v211", "v212", "v213",
+                      "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
+                      "v227", "v228", "v229", "v230", "v231");
+#undef MZD_PIPE_STEP
+            }
+#endif
+            if (smask) {
+                // i has moved past the step; lanes in smask have not done it yet
+                general_step(i - 1, ((smask >> lane) & 1) != 0);
+                asm volatile("" ::: "memory");
+                __hip_atomic_store(&shs->head1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+#ifdef MZD_PIPE_PROF
+        if (blockIdx.x == 0 && lane == 0)
+            printf("A: steps %u cycles %lld wait %lld real(100MHz) %lld\n", nmax, clock64() - prof_t0, prof_wait, wall_clock64() - prof_r0);
+#endif
+#ifdef MZD_PIPE_PROF2
+        if (blockIdx.x == 0 && lane == 0) printf("A2: vm wait %u lds wait %u (each includes ~2 s_memtime round trips per step)\n", prof_vm, prof_lds);
+#endif
     } else if (wave == 1) {
         // ================= stage B: field extraction and values, four steps at a time =================
         uint32_t head_seen = 0, tail_seen = 0;
+#ifdef MZD_PIPE_PROF
+        long long prof_wait = 0, prof_wait2 = 0, prof_t0 = clock64();
+#endif
         for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
             const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+#ifdef MZD_PIPE_PROF
+            const long long w0 = clock64();
+#endif
             while (head_seen < need) {
                 head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
                     (int)__hip_atomic_load(&shs->head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (head_seen < need) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef MZD_PIPE_PROF
+            prof_wait += clock64() - w0;
+#endif
             asm volatile("" ::: "memory");
             uint64_t T[kPipeBatch];
             uint32_t P[kPipeBatch];
@@ -1258,65 +1445,91 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                                    ((uint64_t)ofv << kRecOffShift);
                 q[u] = (P[u] >> 31) ? T[u] : v;
             }
+#ifdef MZD_PIPE_PROF
+            const long long w1 = clock64();
+#endif
             while (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) {
                 tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
                     (int)__hip_atomic_load(&shs->tail2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef MZD_PIPE_PROF
+            prof_wait2 += clock64() - w1;
+#endif
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][lane] = q[u];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->head2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#ifdef MZD_PIPE_PROF
+        if (blockIdx.x == 0 && lane == 0)
+            printf("B: cycles %lld wait_in %lld wait_out %lld\n", clock64() - prof_t0, prof_wait, prof_wait2);
+#endif
     } else if (wave == 2) {
         // ================= stage C: sums, offset history, records =================
+        // Branch-free per sequence: errors are sticky flags (a failed block's records, sums and history
+        // are never used), the history update is a chain of selects, only the record store is masked.
         int h0, h1, h2;
         if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
         else { h0 = -1; h1 = -2; h2 = -3; }
         uint32_t litPos = 0, outPos = 0;
+        uint32_t err_unsup = 0, err_off = 0, err_size = 0;
         uint64_t *myrec = recs + t.rec_off;
         TileBase *mytile = tiles + t.tile_off;
+        const uint32_t my_n = has ? t.n_seq : 0u;
         uint32_t head_seen = 0;
+#ifdef MZD_PIPE_PROF
+        long long prof_wait = 0, prof_t0 = clock64();
+#endif
         for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
             const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+#ifdef MZD_PIPE_PROF
+            const long long w0 = clock64();
+#endif
             while (head_seen < need) {
                 head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
                     (int)__hip_atomic_load(&shs->head2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (head_seen < need) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef MZD_PIPE_PROF
+            prof_wait += clock64() - w0;
+#endif
             asm volatile("" ::: "memory");
             uint64_t q[kPipeBatch];
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][lane];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((j0 & 63) == 0 && has && j0 < t.n_seq && status == MZD_OK) mytile[j0 >> 6] = TileBase{litPos, outPos};
+            if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
                 const uint32_t j = j0 + u;
-                const bool act = has && j < t.n_seq && status == MZD_OK;
-                const uint32_t LL = (uint32_t)q[u] & kRecLlMask;
-                const uint32_t ML = (uint32_t)(q[u] >> kRecMlShift) & kRecMlMask;
-                const uint32_t ofv = (uint32_t)(q[u] >> kRecOffShift);
-                const bool isnew = ofv > 3;
-                const int idx = isnew ? 4 : (int)ofv - 1 + (LL == 0 ? 1 : 0);  // 0..3 repeat cases, 4 = new offset
-                int off = idx == 0 ? h0 : (idx == 1 ? h1 : (idx == 2 ? h2 : hist_dec(h0)));
-                if (isnew) off = (int)(ofv - 3);
-                if (act) {
-                    if (ofv >= kRecOffSymbolic) status = MZD_ERR_UNSUPPORTED;  // offset value >= 2^28
-                    else if (off == 0) status = MZD_ERR_OFFSET;
-                    if (idx >= 2) h2 = h1;
-                    if (idx >= 1) { h1 = h0; h0 = off; }
-                    litPos += LL;
-                    outPos += LL + ML;
-                    if (outPos > kBlockMax && status == MZD_OK) status = MZD_ERR_CORRUPT_SIZES;  // a block regenerates <= 128 KiB
-                }
-                if (act && status == MZD_OK) {
-                    const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
-                    myrec[j] = (q[u] & ((1ull << kRecOffShift) - 1)) | ((uint64_t)offfield << kRecOffShift);
-                }
+                const bool act = j < my_n;
+                const uint32_t lo = (uint32_t)q[u], hi = (uint32_t)(q[u] >> 32);
+                const uint32_t LL = lo & kRecLlMask;
+                const uint32_t ML = __builtin_amdgcn_alignbit(hi, lo, kRecMlShift) & kRecMlMask;
+                const uint32_t ofv = hi >> (kRecOffShift - 32);
+                // 0 = not active (history untouched), 1..4 = repeat cases 0..3, 5 = new offset
+                uint32_t idx = ofv > 3 ? 5u : ofv + (LL == 0 ? 1u : 0u);
+                idx = act ? idx : 0u;
+                int off = (int)(ofv - 3);                 // idx 5
+                off = idx == 4 ? hist_dec(h0) : off;      // sequence_execution.go:65-114
+                off = idx == 3 ? h2 : off;
+                off = idx == 2 ? h1 : off;
+                off = idx <= 1 ? h0 : off;
+                h2 = idx >= 3 ? h1 : h2;
+                h1 = idx >= 2 ? h0 : h1;
+                h0 = idx >= 2 ? off : h0;
+                err_unsup |= act && ofv >= kRecOffSymbolic;  // offset value >= 2^28
+                err_off |= act && off == 0;
+                litPos += act ? LL : 0u;
+                outPos += act ? LL + ML : 0u;
+                err_size |= outPos > kBlockMax;  // a block regenerates <= 128 KiB
+                const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
+                if (act) myrec[j] = (uint64_t)lo | ((uint64_t)((hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32))) << 32);
             }
         }
+        status = err_unsup ? MZD_ERR_UNSUPPORTED : (err_off ? MZD_ERR_OFFSET : (err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK));
         if (has && t.n_seq > 0) {
             BlockSum *bs = &sums[t.block];
             bs->lit_total = litPos;
@@ -1326,6 +1539,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             bs->hist[2] = h2;
         }
         shs->stC[lane] = status;
+#ifdef MZD_PIPE_PROF
+        if (blockIdx.x == 0 && lane == 0) printf("C: cycles %lld wait_in %lld\n", clock64() - prof_t0, prof_wait);
+#endif
     } else {
         // ================= wave P: touch the bitstream lines ahead of stage A =================
         const uint8_t *sbase = in + t.in_off;
@@ -1334,8 +1550,11 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         for (;;) {
             const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)__hip_atomic_load(&shs->head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const int cur = (int)__hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int target = max(cur - kAhead, 0);
+            // parked lanes point outside the stream
+            const uint32_t raw = __hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int cur = (int)(raw - ((uint32_t)t.in_off + MZD_IN_PAD));  // A publishes its refill offset from in - MZD_IN_PAD
+            const bool inside = cur >= -64 && cur <= (int)t.in_size;
+            const int target = inside ? max(cur - kAhead, 0) : low;
             int guard = 0;
             while (has && low > target && guard < 8) {
                 low = max(low - kLine, 0);
