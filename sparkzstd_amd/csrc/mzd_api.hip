@@ -452,25 +452,20 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (!ctx || !db) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    const bool cell16 = ctx->opt.seq_variant != 1;  // default: 2-byte LDS cells (63 chains per CU)
     const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 128;
     if (exec_threads % 64 || exec_threads > 256) return MZD_ERR_INVALID_ARG;
     // LDS chunk of the execution kernel: default 8 KiB (up to 16 workgroups per CU); multiple of 1024
     uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 8192;
     exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
-    const size_t seq_lds = cell16 ? (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16
-                                  : (size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32;
+    const size_t seq_lds = (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16;
     const size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
     // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
     // overflow L2 and every refill goes to MALL/HBM; a minimum LDS request per workgroup limits the
     // number of resident wavefronts (opt.huf_min_lds bytes, default 48 KiB -> 3 wavefronts per CU)
     const size_t huf_lds = std::max<size_t>((size_t)kHufQuads * db->huf_slot_cells * 2, ctx->opt.huf_min_lds);
     if (!ctx->attr_set) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)((size_t)kSeqChains32 * kSeqCellsPerChain * 4 + kSeqExtraLds32)));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_quad, hipFuncAttributeMaxDynamicSharedMemorySize, kQuadLdsBytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_pipe, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kPipeFixedLds + kPipeMaxChains * kSeqCellsPerChain * 2));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -482,10 +477,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // the last, partial round leaves most CUs idle.  The batch is cut at the frame where the full rounds
     // end: k_seq(tail) then runs on the caller's stream while k_exec(head) fills the idle CUs from a
     // second stream (frames are independent, so the two never touch the same data).
-    // k_seq_pipe addresses the bitstreams with 32-bit offsets from the blob's front slack
-    const bool pipe = ctx->opt.seq_variant == 3 && db->in_size + 2 * MZD_IN_PAD < (1ull << 32);
-    const uint32_t nch = pipe ? (uint32_t)kPipeMaxChains
-                              : (ctx->opt.seq_variant == 2 ? (uint32_t)kQuadChains : (cell16 ? kSeqChains16 : kSeqChains32));
+    // seq_variant 0 (default): k_seq_pipe; 1: k_seq, the two-wavefront kernel.  k_seq_pipe addresses the
+    // bitstreams with 32-bit offsets from the blob's front slack, so larger blobs take k_seq as well.
+    if (ctx->opt.seq_variant > 1) return MZD_ERR_INVALID_ARG;
+    const bool pipe = ctx->opt.seq_variant == 0 && db->in_size + 2 * MZD_IN_PAD < (1ull << 32);
+    // k_seq_pipe: two chains fewer than fit, so that ~6 KiB of every CU's LDS stay free and the small
+    // k_huf workgroups run in k_seq's shadow instead of queueing for whole CUs (measured: -0.9 ms per step)
+    const uint32_t nch = pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16;
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames, tA = db->n_seq_tasks;
     if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
@@ -516,7 +514,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         ctx->run_split[ctx->runs] = split;
         ev = ctx->ev.data() + ctx->runs * kEvPerRun;
     }
-    const bool quad = ctx->opt.seq_variant == 2;
     auto launch_seq = [&](uint32_t first, uint32_t count) {
         if (!count) return;
         if (pipe) {
@@ -527,15 +524,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             const uint32_t per_wg = (uint32_t)std::min<uint64_t>(nch, (count + rounds * cus - 1) / (rounds * cus));
             k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
                 db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg);
-        } else if (quad)
-            k_seq_quad<<<(count + kQuadChains - 1) / kQuadChains, 320, kQuadLdsBytes, s>>>(
+        } else {
+            k_seq<<<(count + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
-        else if (cell16)
-            k_seq<true><<<(count + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
-                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
-        else
-            k_seq<false><<<(count + kSeqChains32 - 1) / kSeqChains32, 128, seq_lds, s>>>(
-                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+        }
     };
     auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {
         if (!count) return;
@@ -589,6 +581,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     HIP_TRY(ctx, hipGetLastError());
     return MZD_OK;
 }
+
+#ifdef MZD_EXEC_STATS
+extern "C" int mzd_debug_exec_stats(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_exec_stats), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_exec_stats), z, sizeof z); }
+    return 0;
+}
+#endif
 
 int mzd_sync(mzd_ctx *ctx)
 {

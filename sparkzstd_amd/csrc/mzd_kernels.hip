@@ -228,11 +228,9 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
 // ------------------------------------------------------------------------------------------
 // k_seq: FSE sequence decode.  One wavefront per workgroup, lane = one block's chain.
 //
-// LDS cell formats (built from the host cells {baseline, nbits, symbol} while staging):
-//   CELL16: next(10) | symbol(6)       nbits = acc_log - highbit(next), baseline = (next << nbits) - size
-//           (fse.go:209-213 run backwards); 2 bytes -> 63 chains per CU
-//   CELL32: baseline(10) | nbits(4) | extra_bits(5) | symbol(6); 4 bytes -> 31 chains per CU,
-//           no second lookup for the extra-bit count on the serial chain
+// LDS cell (built from the host cells {baseline, nbits, symbol} while staging), 2 bytes:
+//   next(10) | symbol(6)       nbits = acc_log - highbit(next), baseline = (next << nbits) - size
+//   (fse.go:209-213 run backwards) -> 61 chains per CU
 // Constant LDS table CT[kind][symbol] = base_value(24) | extra_bits(8)  (predefined.go:5-20,36-50).
 
 __constant__ uint32_t c_ll_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
@@ -275,11 +273,7 @@ struct SeqBits {
         // ordering point: the old D must be dead before the new D is requested, otherwise the
         // compiler keeps both alive, copies at the loop back edge and waits vmcnt(0) for the copy
         asm volatile("" ::"v"((uint32_t)C), "v"((uint32_t)(C >> 32)) : "memory");
-#ifdef MZD_EXP_FAKE_REFILL  // timing experiment only (wrong results): every refill hits one resident line
-        D = ld64u((const uint8_t *)((uintptr_t)pd & ~(uintptr_t)0x3FFF));
-#else
         D = ld64u(pd);
-#endif
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(((C << k) >> 1) >> (63 - n)); }
 };
@@ -302,17 +296,16 @@ struct SeqShared {
     uint64_t queue[DEPTH][64];  // LL:17 | ML:18 | offset value:28 | valid:1
 };
 
-template <bool CELL16>
 __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                              uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                              uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
                                              BlockSum *sums)
 {
-    constexpr int NCH = CELL16 ? kSeqChains16 : kSeqChains32;
-    constexpr int CELL_BYTES = CELL16 ? 2 : 4;
+    constexpr int NCH = kSeqChains16;
+    constexpr int CELL_BYTES = 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *CT = (uint32_t *)(smem + (size_t)NCH * kSeqCellsPerChain * CELL_BYTES);  // [2][64]
-    constexpr int kSeqQueueDepth = CELL16 ? kSeqQueue16 : kSeqQueue32;
+    constexpr int kSeqQueueDepth = kSeqQueue16;
     SeqShared<kSeqQueueDepth> *shs = (SeqShared<kSeqQueueDepth> *)(CT + 128);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -347,13 +340,8 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
             for (uint32_t i = threadIdx.x; i < n; i += 128) {
                 uint32_t e = fse_entries[off[kind] + i];  // baseline(16) | nbits(8) | symbol(8)
                 uint32_t baseline = e & 0xFFFF, nb = (e >> 16) & 0xFF, sym = e >> 24;
-                if (CELL16) {
-                    uint32_t next = (baseline + n) >> nb;
-                    ((uint16_t *)smem)[base + i] = (uint16_t)(next | (sym << 10));
-                } else {
-                    uint32_t extra = kind == 0 ? c_ll_extra[min(sym, 35u)] : (kind == 1 ? c_ml_extra[min(sym, 52u)] : sym);
-                    ((uint32_t *)smem)[base + i] = baseline | (nb << 10) | (extra << 14) | ((sym & 63) << 19);
-                }
+                const uint32_t next = (baseline + n) >> nb;
+                ((uint16_t *)smem)[base + i] = (uint16_t)(next | (sym << 10));
             }
         }
     }
@@ -477,12 +465,8 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
     const uint16_t *c16L = (const uint16_t *)smem + slot - sizeL;
     const uint16_t *c16M = (const uint16_t *)smem + slot + 512 - sizeM;
     const uint16_t *c16O = (const uint16_t *)smem + slot + 1024 - sizeO;
-    const uint32_t *c32L = (const uint32_t *)smem + slot - sizeL;
-    const uint32_t *c32M = (const uint32_t *)smem + slot + 512 - sizeM;
-    const uint32_t *c32O = (const uint32_t *)smem + slot + 1024 - sizeO;
     auto load_cells = [&](uint32_t &xl, uint32_t &xm, uint32_t &xo) {
-        if (CELL16) { xl = c16L[sL]; xm = c16M[sM]; xo = c16O[sO]; }
-        else { xl = c32L[sL]; xm = c32M[sM]; xo = c32O[sO]; }
+        xl = c16L[sL]; xm = c16M[sM]; xo = c16O[sO];
     };
     auto step = [&](auto slow_tag, uint32_t i, bool only, uint64_t &entry, uint32_t xl, uint32_t xm, uint32_t xo) -> bool {
         constexpr bool SLOW = decltype(slow_tag)::value;
@@ -491,24 +475,16 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
         // ---- table cells for the three current states
         uint32_t symL, symM, symO, nbL, nbM, nbO, baseL, baseM, baseO, exL, exM;
         uint32_t cl, cm;
-        if (CELL16) {
-            symL = xl >> 10; symM = xm >> 10; symO = xo >> 10;
-            cl = CT[symL]; cm = CT[64 + symM];
-            const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
-            nbL = (uint32_t)(nbL0 + __builtin_clz(nl | 1));
-            nbM = (uint32_t)(nbM0 + __builtin_clz(nm | 1));
-            nbO = (uint32_t)(nbO0 + __builtin_clz(no | 1));
-            baseL = nl << nbL;  // biased: baseline + size
-            baseM = nm << nbM;
-            baseO = no << nbO;
-            exL = cl >> 24; exM = cm >> 24;
-        } else {
-            const uint32_t el = xl, em = xm, eo = xo;
-            baseL = (el & 1023) + sizeL; nbL = (el >> 10) & 15; exL = (el >> 14) & 31; symL = el >> 19;
-            baseM = (em & 1023) + sizeM; nbM = (em >> 10) & 15; exM = (em >> 14) & 31; symM = em >> 19;
-            baseO = (eo & 1023) + sizeO; nbO = (eo >> 10) & 15; symO = eo >> 19;
-            cl = CT[symL]; cm = CT[64 + symM];
-        }
+        symL = xl >> 10; symM = xm >> 10; symO = xo >> 10;
+        cl = CT[symL]; cm = CT[64 + symM];
+        const uint32_t nl = xl & 1023, nm = xm & 1023, no = xo & 1023;
+        nbL = (uint32_t)(nbL0 + __builtin_clz(nl | 1));
+        nbM = (uint32_t)(nbM0 + __builtin_clz(nm | 1));
+        nbO = (uint32_t)(nbO0 + __builtin_clz(no | 1));
+        baseL = nl << nbL;  // biased: baseline + size
+        baseM = nm << nbM;
+        baseO = no << nbO;
+        exL = cl >> 24; exM = cm >> 24;
         const uint32_t exO = symO;
         if (lastseq) { nbL = 0; nbM = 0; nbO = 0; }  // no state update after the last sequence (sequences.go:178)
         // cumulative bit offsets in stream order: OF extra, ML extra, LL extra, LL state, ML state, OF state
@@ -609,320 +585,6 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 }
 
 // ------------------------------------------------------------------------------------------
-// k_seq_quad: the same sequence decode with INTRA-CHAIN SIMD.  A lone wavefront issues one
-// instruction per ~4.4 cycles, so the length of the per-step instruction stream is the step
-// latency.  Here FOUR adjacent lanes serve one chain: lane role 0 = literal-length table, 1 =
-// match-length table, 2 = offset table (3 = spare, mirrors role 0).  Every lane does ONE cell read
-// and unpack and cuts only ITS OWN two bit fields (extra bits, next-state bits); the six field widths
-// travel between the lanes of a quad with three quad_perm DPP broadcasts.  The bit window is
-// replicated in the four lanes (identical refills, same cache line).  61 chains -> 4 decode
-// wavefronts of 16 quads (one per SIMD) + 1 helper wavefront (lane = chain) that drains one
-// queue per decode wavefront.
-
-constexpr int kQuadChains = 61;
-constexpr int kQuadDepth = 8;
-struct QuadShared {
-    uint32_t progress[64];              // per chain: bytes of bitstream not yet requested
-    uint32_t head[4];                   // per decode wavefront: steps produced
-    uint32_t tail[4];                   // per decode wavefront: steps consumed by the helper
-    uint64_t queue[4][kQuadDepth][16];  // [decode wavefront][slot][quad]: LL:17 | ML:18 | offset value:28 | valid:1
-};
-constexpr int kQuadLdsBytes = kQuadChains * kSeqCellsPerChain * 2 + 3 * 64 * 4 + (int)sizeof(QuadShared);
-
-template <int LANE>
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
-{
-    constexpr int perm = LANE | (LANE << 2) | (LANE << 4) | (LANE << 6);
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, perm, 0xf, 0xf, true);
-}
-
-__global__ __launch_bounds__(320) void k_seq_quad(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
-                                                  uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
-                                                  uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
-                                                  BlockSum *sums)
-{
-    constexpr int NCH = kQuadChains;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *CT = (uint32_t *)(smem + (size_t)NCH * kSeqCellsPerChain * 2);  // [3][64]: base(24) | extra(8)
-    QuadShared *shs = (QuadShared *)(CT + 3 * 64);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;  // 0..3 decode, 4 helper
-    // every wavefront holds the tasks of all chains of the workgroup, one per lane (staging + shuffles)
-    const uint32_t tid = blockIdx.x * NCH + lane;
-    const bool has = lane < NCH && tid < n_tasks;
-    SeqTask t;
-    if (has) t = tasks[tid];
-    else {
-        t.n_seq = 0; t.in_size = 0; t.ll_off = t.of_off = t.ml_off = 0; t.ll_log = t.of_log = t.ml_log = 0;
-        t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
-    }
-    if (wave == 4) {
-        CT[lane] = lane < 36 ? (c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24)) : 0u;
-        CT[64 + lane] = lane < 53 ? (c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24)) : 0u;
-        CT[128 + lane] = lane < 32 ? ((uint32_t)lane << 24) : 0u;  // offsets: extra bits = code, base = 1 << code
-        shs->progress[lane] = t.in_size;
-        if (lane < 4) { shs->head[lane] = 0; shs->tail[lane] = 0; }
-    }
-    // stage the three tables of every chain (all five wavefronts copy)
-    for (int ch = 0; ch < NCH; ch++) {
-        if (blockIdx.x * NCH + ch >= n_tasks) break;
-        uint32_t off[3], lg[3];
-        off[0] = (uint32_t)__shfl((int)t.ll_off, ch, 64);
-        off[1] = (uint32_t)__shfl((int)t.ml_off, ch, 64);
-        off[2] = (uint32_t)__shfl((int)t.of_off, ch, 64);
-        lg[0] = (uint32_t)__shfl((int)t.ll_log, ch, 64);
-        lg[1] = (uint32_t)__shfl((int)t.ml_log, ch, 64);
-        lg[2] = (uint32_t)__shfl((int)t.of_log, ch, 64);
-#pragma unroll
-        for (int kind = 0; kind < 3; kind++) {
-            const uint32_t n = 1u << lg[kind];
-            const uint32_t base = (uint32_t)ch * kSeqCellsPerChain + (uint32_t)kind * 512;
-            for (uint32_t i = threadIdx.x; i < n; i += 320) {
-                uint32_t e = fse_entries[off[kind] + i];  // baseline(16) | nbits(8) | symbol(8)
-                uint32_t baseline = e & 0xFFFF, nb = (e >> 16) & 0xFF, sym = e >> 24;
-                uint32_t next = (baseline + n) >> nb;
-                ((uint16_t *)smem)[base + i] = (uint16_t)(next | (sym << 10));
-            }
-        }
-    }
-    __syncthreads();
-
-    if (wave == 4) {
-        // ---- helper wavefront: lane = chain; chains 16w .. 16w+15 belong to decode wavefront w
-        const int grp = lane >> 4, qd = lane & 15;
-        // steps every group will produce (its decode wavefront loops to the group's longest chain)
-        uint32_t gmax = has ? t.n_seq : 0u;
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, d, 64));
-        const uint8_t *sbase = in + t.in_off;
-        int low = (int)t.in_size;
-        uint32_t sink = 0;
-        constexpr int kAhead = 1024, kLine = 128;
-        int h0, h1, h2;
-        if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
-        else { h0 = -1; h1 = -2; h2 = -3; }
-        uint32_t litPos = 0, outPos = 0;
-        int status = MZD_OK;
-        uint64_t *myrec = recs + t.rec_off;
-        TileBase *mytile = tiles + t.tile_off;
-        // All groups are consumed in lock step (one uniform iteration serves every chain of the
-        // workgroup); the 8-deep queues absorb the drift between the four decode wavefronts.
-        const uint32_t jmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(gmax));
-        uint32_t seqno = 0, head_seen = 0;
-        for (uint32_t j = 0; j < jmax; j++) {
-            if ((j & 31) == 0) {
-                const int cur = (int)__hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int target = max(cur - kAhead, 0);
-                int guard = 0;
-                while (has && low > target && guard < 16) {
-                    low = max(low - kLine, 0);
-                    sink ^= *(const volatile uint32_t *)(sbase + (low & ~3));
-                    guard++;
-                }
-            }
-            const bool avail = j < gmax;  // this lane's group still produces step j
-            for (;;) {
-                if (avail && head_seen <= j)
-                    head_seen = __hip_atomic_load(&shs->head[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__all(!avail || head_seen > j)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-            uint64_t q = 0;
-            if (avail) q = shs->queue[grp][j % kQuadDepth][qd];
-            asm volatile("" ::: "memory");
-            if (avail && qd == 0) __hip_atomic_store(&shs->tail[grp], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool act = avail && (q >> 63) != 0 && status == MZD_OK;
-            const uint32_t LL = (uint32_t)q & kRecLlMask;
-            const uint32_t ML = (uint32_t)(q >> kRecMlShift) & kRecMlMask;
-            const uint32_t ofv = (uint32_t)(q >> kRecOffShift) & (kRecOffSymbolic - 1);
-            if (act && (seqno & 63) == 0) mytile[seqno >> 6] = TileBase{litPos, outPos};
-            const bool isnew = ofv > 3;
-            const int idx = isnew ? 4 : (int)ofv - 1 + (LL == 0 ? 1 : 0);  // 0..3 repeat cases, 4 = new offset
-            int off = idx == 0 ? h0 : (idx == 1 ? h1 : (idx == 2 ? h2 : hist_dec(h0)));
-            if (isnew) off = (int)(ofv - 3);
-            if (act) {
-                if (off == 0) status = MZD_ERR_OFFSET;
-                if (idx >= 2) h2 = h1;
-                if (idx >= 1) { h1 = h0; h0 = off; }
-            }
-            if (act && status == MZD_OK) {
-                const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
-                myrec[seqno] = (uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)offfield << kRecOffShift);
-                litPos += LL;
-                outPos += LL + ML;
-                seqno++;
-                if (outPos > kBlockMax) status = MZD_ERR_CORRUPT_SIZES;  // a block regenerates <= 128 KiB
-            }
-        }
-        if (has && t.n_seq > 0) {
-            BlockSum *bs = &sums[t.block];
-            bs->lit_total = litPos;
-            bs->out_total = outPos;
-            bs->hist[0] = h0;
-            bs->hist[1] = h1;
-            bs->hist[2] = h2;
-            if (status != MZD_OK) atomicCAS(&bs->status, MZD_OK, status);
-        }
-        if (sink == 0x9E3779B9u && lane == 77) sums[0].pad[0] = sink;  // keeps the touches alive; never true
-        return;
-    }
-
-    // ---- decode wavefronts: quad = chain, lane role = table
-    const int qd = lane >> 2, role = lane & 3;
-    const int rr = role == 3 ? 0 : role;  // spare lane mirrors the LL lane
-    const int chain = wave * 16 + qd;     // chain index inside the workgroup == helper lane
-    const bool isLL = rr == 0, isML = rr == 1, isOF = rr == 2;
-    // this chain's task fields come from lane `chain` of the per-wavefront task copy
-    const uint32_t c_n_seq = (uint32_t)__shfl((int)t.n_seq, chain, 64);
-    const uint32_t c_in_size = (uint32_t)__shfl((int)t.in_size, chain, 64);
-    const uint32_t c_in_lo = (uint32_t)__shfl((int)(uint32_t)t.in_off, chain, 64);
-    const uint32_t c_in_hi = (uint32_t)__shfl((int)(uint32_t)(t.in_off >> 32), chain, 64);
-    const int alL = __shfl((int)t.ll_log, chain, 64), alM = __shfl((int)t.ml_log, chain, 64),
-              alO = __shfl((int)t.of_log, chain, 64);
-    const bool chas = (bool)__shfl((int)has, chain, 64) && chain < NCH;
-    const uint8_t *cin = in + (((uint64_t)c_in_hi << 32) | c_in_lo);
-    const int al = isLL ? alL : (isML ? alM : alO);
-    const uint32_t size_r = 1u << al;
-    const int nb0 = al - 31;  // nbits = acc_log - 31 + clz(next)
-    const uint16_t *cells = (const uint16_t *)smem + (uint32_t)chain * kSeqCellsPerChain + (uint32_t)rr * 512 - size_r;
-    const uint32_t *ctr = CT + rr * 64;
-
-    SeqBits br;
-    int rem = 0;
-    int status = MZD_OK;
-    uint32_t s = 0;  // this lane's state, pre-biased by the table size
-    if (chas && c_n_seq > 0) {
-        rem = br.init(cin, (int)c_in_size);
-        if (rem < 0) {
-            status = MZD_ERR_BAD_PADDING;
-            rem = 0;
-        } else {
-            // initial states in the order LL, OF, ML (sequences.go:145-159); every lane keeps its own
-            const uint32_t sL = br.peek(alL); br.k += alL;
-            const uint32_t sO = br.peek(alO); br.k += alO;
-            br.refill();
-            const uint32_t sM = br.peek(alM); br.k += alM;
-            rem -= alL + alO + alM;
-            if (rem < 0) status = MZD_ERR_SEQ_BITS;
-            s = isLL ? sL : (isML ? sM : sO);
-        }
-    } else {
-        br.pd = in; br.C = br.D = 0; br.k = 0;
-    }
-    s += size_r;
-    const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(chas ? c_n_seq : 0u));
-
-    // one step; SLOW refills between fields (see k_seq).  Returns (stall) and the lane-0 queue entry.
-    auto step = [&](auto slow_tag, uint32_t i, bool only, uint64_t &entry, uint32_t x) -> bool {
-        constexpr bool SLOW = decltype(slow_tag)::value;
-        const bool base_act = only && i < c_n_seq && status == MZD_OK;
-        const bool lastseq = (i + 1 == c_n_seq);
-        const uint32_t sym = x >> 10, nx = x & 1023;
-        const uint32_t c = ctr[sym];
-        uint32_t nb = (uint32_t)(nb0 + __builtin_clz(nx | 1));
-        const uint32_t base = nx << nb;  // biased: baseline + size
-        if (lastseq) nb = 0;             // no state update after the last sequence (sequences.go:178)
-        const uint32_t ex = c >> 24;
-        // widths of all six fields, via the quad
-        const uint32_t p = ex | (nb << 8);
-        const uint32_t pLL = quad_bcast<0>(p), pML = quad_bcast<1>(p), pOF = quad_bcast<2>(p);
-        const uint32_t exO = pOF & 255, exM = pML & 255, exL = pLL & 255;
-        const uint32_t nbL = pLL >> 8, nbM = pML >> 8, nbO = pOF >> 8;
-        // cumulative bit offsets in stream order: OF extra, ML extra, LL extra, LL state, ML state, OF state
-        const uint32_t o2 = exO + exM, o3 = o2 + exL, o4 = o3 + nbL, o5 = o4 + nbM;
-        const int total = (int)(o5 + nbO);
-        const uint32_t oex = isOF ? 0u : (isML ? exO : o2);
-        const uint32_t onb = isLL ? o3 : (isML ? o4 : o5);
-        uint32_t fe, fs;
-        bool act, stall = false;
-        if (!SLOW) {
-            stall = base_act && (br.k + total > 63);  // k must stay < 64: the refill shifts by 8 * (k >> 3)
-            act = base_act && !stall;
-            const uint64_t T = br.C << br.k;
-            fe = top_bits(T << oex, ex);
-            fs = top_bits(T << onb, nb);
-            br.k += act ? total : 0;  // idle, finished, failed and stalled chains must not advance
-        } else {
-            act = base_act;
-            const uint32_t m = act ? 0xFFFFFFFFu : 0u;
-            const int wO = (int)(exO & m), wM = (int)(exM & m), wL = (int)(exL & m);
-            const int vL = (int)(nbL & m), vM = (int)(nbM & m), vO = (int)(nbO & m);
-            const uint32_t f0 = br.peek(wO); br.k += wO; br.refill();
-            const uint32_t f1 = br.peek(wM); br.k += wM;
-            const uint32_t f2 = br.peek(wL); br.k += wL; br.refill();
-            const uint32_t f3 = br.peek(vL); br.k += vL;
-            const uint32_t f4 = br.peek(vM); br.k += vM;
-            const uint32_t f5 = br.peek(vO); br.k += vO;
-            fe = isOF ? f0 : (isML ? f1 : f2);
-            fs = isLL ? f3 : (isML ? f4 : f5);
-        }
-        // ---- values (sequences.go:99-120): own value, then LL / ML / offset value gathered in every lane
-        const uint32_t val = (isOF ? (1u << ex) : (c & 0xFFFFFF)) + fe;
-        const uint32_t LL = quad_bcast<0>(val), ML = quad_bcast<1>(val), ofv = quad_bcast<2>(val);
-        if (act) {
-            rem -= total;
-            if (rem < 0) status = MZD_ERR_SEQ_BITS;                    // over-read (cursor would pass -1)
-            if (ofv >= kRecOffSymbolic) status = MZD_ERR_UNSUPPORTED;  // offset value >= 2^28
-            s = base + fs;  // state = Baseline + Read(NumberOfBits) (fse.go:282-290); in range for valid tables
-        }
-        const bool emit = act && status == MZD_OK;
-        entry = emit ? ((uint64_t)LL | ((uint64_t)ML << kRecMlShift) | ((uint64_t)ofv << kRecOffShift) | (1ull << 63)) : 0ull;
-        return stall;
-    };
-
-    uint32_t i = 0;
-    uint32_t tail_seen = 0;
-    auto wait_space = [&](uint32_t at) {
-        while (at - tail_seen >= (uint32_t)kQuadDepth) {
-            tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
-                (int)__hip_atomic_load(&shs->tail[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (at - tail_seen >= (uint32_t)kQuadDepth) __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    auto push = [&](uint32_t at, uint64_t entry) {
-        wait_space(at);
-        if (role == 0) shs->queue[wave][at % kQuadDepth][qd] = entry;
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&shs->head[wave], at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    while (i < nmax) {
-        bool stalled = false;
-        bool any_stall = false;
-        uint64_t entry = 0;
-        do {
-            if ((i & 31) == 0 && chas && role == 0)  // bytes not yet requested by the refills (for the helper)
-                shs->progress[chain] = (uint32_t)max((int)(br.pd - cin), 0);
-            const uint32_t x = cells[s];
-            br.refill();
-            stalled = step(std::false_type{}, i, true, entry, x);
-            any_stall = __any(stalled) != 0;
-            if (!any_stall) push(i, entry);
-            i++;
-        } while (i < nmax && !any_stall);
-        if (any_stall) {
-            uint64_t e2 = 0;
-            const uint32_t x = cells[s];
-            step(std::true_type{}, i - 1, stalled, e2, x);
-            if (stalled) entry = e2;
-            push(i - 1, entry);
-        }
-    }
-    if (chas && c_n_seq > 0 && role == 0) {
-        if (status == MZD_OK && rem != 0) status = MZD_ERR_SEQ_BITS;  // sequences.go:197-204
-        const uint32_t blk = (uint32_t)__shfl((int)t.block, chain, 64);
-        (void)blk;
-    }
-    {
-        // report the decode-side status of every chain (uniform shuffle, then the role-0 lane writes)
-        const uint32_t blk = (uint32_t)__shfl((int)t.block, chain, 64);
-        int st = status;
-        if (st == MZD_OK && chas && c_n_seq > 0 && rem != 0) st = MZD_ERR_SEQ_BITS;
-        if (chas && c_n_seq > 0 && role == 0 && st != MZD_OK) atomicCAS(&sums[blk].status, MZD_OK, st);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // k_seq_pipe: the sequence decode as a THREE-STAGE PIPELINE ACROSS THE SIMDs OF ONE CU.
 //
 // The LDS-resident tables bound a CU to ~60 chains = one wavefront, and a lone wavefront pays
@@ -959,8 +621,6 @@ __global__ __launch_bounds__(320) void k_seq_quad(const uint8_t *__restrict__ in
 //
 // LDS: [CTc 128 dwords][PipeShared][cells: nch x 1280 x u16], nch <= kPipeMaxChains at launch.
 
-#define MZD_STR2(x) #x
-#define MZD_STR(x) MZD_STR2(x)
 constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
 #ifndef MZD_PIPE_AHEAD
 #define MZD_PIPE_AHEAD 256  // bytes wave P keeps touched below every chain's cursor
@@ -1198,9 +858,6 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         // lanes; their step is NOT done, everybody's queue entry IS written, head1 not yet moved) or
         // nmax is reached.  One step = refill, three cell reads, bit counts, three state fields.
         uint32_t i = 0;
-#ifdef MZD_PIPE_PROF2
-        uint32_t prof_vm = 0, prof_lds = 0;
-#endif
         const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u, vzero = 0;
         // LDS byte addresses of cL / cM / cO
         const uint32_t cbL = kPipeFixedLds + 2u * (slot - sizeL), cbM = kPipeFixedLds + 2u * (slot + 512 - sizeM),
@@ -1276,80 +933,81 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_pipe_poll" TAG "_%=\n"                                                                      \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
-    /* next refill load first: off -= k >> 3; DL = 8 bytes at off */                                        \
+    /* next refill load first: off -= k >> 3; DL = 8 bytes at off.  Independent instructions are      */  \
+    /* interleaved throughout: a dependent VALU pair costs about twice an independent one.            */  \
     "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
-    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
-    "global_load_dwordx2 " DL ", %[off], %[inb]\n\t"                                                        \
     "v_lshl_add_u32 v200, %[sL], 1, %[cbL]\n\t"                                                             \
     "v_lshl_add_u32 v201, %[sM], 1, %[cbM]\n\t"                                                             \
+    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
     "v_lshl_add_u32 v202, %[sO], 1, %[cbO]\n\t"                                                             \
     "ds_read_u16 v203, v200\n\t" /* xl */                                                                   \
     "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
+    "global_load_dwordx2 " DL ", %[off], %[inb]\n\t"                                                        \
     "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
     "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"                                                    \
     /* C <<= 8 * (k >> 3); k &= 7 (the bytes that come in from DM are merged below) */                      \
     "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
+    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
     "v_sub_u32 v208, 63, v206\n\t"                                                                          \
     "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
-    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
+    "v_sub_u32 v228, 63, %[k]\n\t"                                                                          \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_lshrrev_b32 v214, 10, v205\n\t" /* exO */                                                            \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
-    "v_sub_u32_e64 v215, v215, 3 clamp\n\t" /* exL */                                                       \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
-    "v_sub_u32_e64 v216, v216, 7 clamp\n\t" /* exM */                                                       \
     "v_and_b32 v217, 0x3ff, v203\n\t"       /* nl */                                                        \
     "v_and_b32 v218, 0x3ff, v204\n\t"       /* nm */                                                        \
     "v_and_b32 v219, 0x3ff, v205\n\t"       /* no */                                                        \
+    "v_lshrrev_b32 v214, 10, v205\n\t"      /* exO */                                                       \
     "v_ffbh_u32 v220, v217\n\t"                                                                             \
     "v_ffbh_u32 v221, v218\n\t"                                                                             \
     "v_ffbh_u32 v222, v219\n\t"                                                                             \
-    "v_add_u32 v220, v220, %[nbL0]\n\t" /* nbL */                                                           \
-    "v_add_u32 v221, v221, %[nbM0]\n\t" /* nbM */                                                           \
-    "v_add_u32 v222, v222, %[nbO0]\n\t" /* nbO */                                                           \
-    "v_add3_u32 v223, v214, v216, v215\n\t" /* o3 */                                                        \
-    "v_add_u32 v224, v223, v220\n\t"        /* c1 */                                                        \
-    "v_add3_u32 v225, v223, v220, v221\n\t" /* c2 */                                                        \
-    "v_add_u32 v230, v225, v222\n\t"        /* total */                                                     \
-    "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
-    "v_sub_u32 v228, 63, %[k]\n\t"                                                                          \
-    "v_min_i32 v228, v228, %[rem]\n\t"                                                                      \
-    "v_cmp_le_u32 vcc, v227, v228\n\t"                  /* go */                                            \
+    "v_sub_u32_e64 v215, v215, 3 clamp\n\t" /* exL */                                                       \
+    "v_sub_u32_e64 v216, v216, 7 clamp\n\t" /* exM */                                                       \
+    "v_add_u32 v220, v220, %[nbL0]\n\t"     /* nbL */                                                       \
+    "v_add_u32 v221, v221, %[nbM0]\n\t"     /* nbM */                                                       \
+    "v_add_u32 v222, v222, %[nbO0]\n\t"     /* nbO */                                                       \
+    "v_add3_u32 v223, v214, v216, v215\n\t" /* o3 = exO + exM + exL */                                      \
+    "v_min_i32 v228, v228, %[rem]\n\t"      /* limit = min(63 - k, rem) */                                  \
+    "v_add_u32 v225, v220, v221\n\t"        /* nbL + nbM */                                                 \
+    "v_sub_u32 v224, 32, v220\n\t"          /* field positions in X: 32 - nbL, ... */                       \
+    "v_add_u32 v229, v223, %[k]\n\t"        /* k + o3 */                                                    \
+    "v_add_u32 v226, v225, v222\n\t"        /* nbL + nbM + nbO */                                           \
+    "v_sub_u32 v225, 32, v225\n\t"                                                                          \
+    "v_add_u32 v230, v223, v226\n\t"        /* total */                                                     \
+    "v_sub_u32 v226, 32, v226\n\t"                                                                          \
     "v_cmp_eq_u32_e64 s[88:89], %[i], %[last]\n\t"      /* last sequence of the lane */                     \
-    "s_andn2_b64 s[90:91], vcc, s[88:89]\n\t"           /* adv = go & ~last */                              \
-    "s_andn2_b64 s[92:93], %[live], vcc\n\t"                                                                \
-    "s_or_b64 %[smask], s[92:93], s[88:89]\n\t"         /* special = last | (live & ~go) */                 \
-    "v_add_u32 v229, 32, v223\n\t"                                                                          \
-    "v_sub_u32 v224, v229, v224\n\t"                                                                        \
-    "v_sub_u32 v225, v229, v225\n\t"                                                                        \
-    "v_sub_u32 v226, v229, v230\n\t"                                                                        \
-    "v_cndmask_b32_e64 v230, 0, v230, s[90:91]\n\t"                                                         \
-    "v_sub_u32 %[rem], %[rem], v230\n\t"                                                                    \
+    "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
     /* merge the bytes of the load issued one step ago: C += (DM >> 1) >> (63 - 8nb) */                     \
     "s_waitcnt vmcnt(1)\n\t"                                                                                \
     "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
+    "v_cmp_le_u32 vcc, v227, v228\n\t"                  /* go */                                            \
     "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
+    "s_andn2_b64 s[90:91], vcc, s[88:89]\n\t"           /* adv = go & ~last */                              \
+    "s_andn2_b64 s[92:93], %[live], vcc\n\t"                                                                \
     "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
-    "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T */                                             \
-    "v_lshlrev_b64 v[210:211], v223, v[212:213]\n\t"    /* X = T << o3 (high half used) */                  \
+    "s_or_b64 %[smask], s[92:93], s[88:89]\n\t"         /* special = last | (live & ~go) */                 \
+    "v_cndmask_b32_e64 v230, 0, v230, s[90:91]\n\t"                                                         \
+    "v_lshlrev_b64 v[210:211], v229, %[C]\n\t"          /* X = C << (k + o3): state bits from bit 63 */     \
+    "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T = C << k */                                    \
+    "v_sub_u32 %[rem], %[rem], v230\n\t"                                                                    \
     "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
+    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
     "v_bfe_u32 v224, v211, v224, v220\n\t" /* aL */                                                         \
     "v_bfe_u32 v225, v211, v225, v221\n\t" /* aM */                                                         \
     "v_bfe_u32 v226, v211, v226, v222\n\t" /* aO */                                                         \
+    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"                                                              \
     "v_lshl_add_u32 v224, v217, v220, v224\n\t"                                                             \
     "v_lshl_add_u32 v225, v218, v221, v225\n\t"                                                             \
     "v_lshl_add_u32 v226, v219, v222, v226\n\t"                                                             \
+    "s_and_b32 s86, %[i], %[depthm1]\n\t"                                                                   \
     "v_cndmask_b32_e64 %[sL], %[sL], v224, s[90:91]\n\t"                                                    \
     "v_cndmask_b32_e64 %[sM], %[sM], v225, s[90:91]\n\t"                                                    \
     "v_cndmask_b32_e64 %[sO], %[sO], v226, s[90:91]\n\t"                                                    \
-    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
-    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"                                                              \
-    "s_and_b32 s86, %[i], %[depthm1]\n\t"                                                                   \
     "s_lshl_b32 s87, s86, 9\n\t"                                                                            \
     "v_add_u32 v200, s87, %[lane8]\n\t"                                                                     \
-    "ds_write_b64 v200, v[212:213] offset:%[o_q1t]\n\t"                                                     \
     "s_lshl_b32 s87, s86, 8\n\t"                                                                            \
     "v_add_u32 v201, s87, %[lane4]\n\t"                                                                     \
+    "ds_write_b64 v200, v[212:213] offset:%[o_q1t]\n\t"                                                     \
     "ds_write_b32 v201, v231 offset:%[o_q1p]\n\t"                                                           \
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
@@ -1395,9 +1053,6 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
 #ifdef MZD_PIPE_PROF
         if (blockIdx.x == 0 && lane == 0)
             printf("A: steps %u cycles %lld wait %lld real(100MHz) %lld\n", nmax, clock64() - prof_t0, prof_wait, wall_clock64() - prof_r0);
-#endif
-#ifdef MZD_PIPE_PROF2
-        if (blockIdx.x == 0 && lane == 0) printf("A2: vm wait %u lds wait %u (each includes ~2 s_memtime round trips per step)\n", prof_vm, prof_lds);
 #endif
     } else if (wave == 1) {
         // ================= stage B: field extraction and values, four steps at a time =================
@@ -1597,6 +1252,12 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
 //   * a tile that regenerates more than a chunk (one very long sequence) is executed in order
 //     straight in HBM by one wavefront.
 
+#ifdef MZD_EXEC_STATS
+__device__ unsigned long long g_exec_stats[32];
+#define EXEC_STAT(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (lane == 0) atomicAdd(&g_exec_stats[i], n_); } while (0)
+#else
+#define EXEC_STAT(i, n) do { } while (0)
+#endif
 struct ExecShared {
     int error;
     uint32_t next_tile;  // first tile of the next chunk (written by thread 0)
@@ -1849,6 +1510,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     }
                 }
                 const bool valid = tile * 64 + lane < b.n_seq;
+                EXEC_STAT(0, 1);
                 const uint32_t LL = (uint32_t)rec & kRecLlMask;
                 const uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;
                 const uint32_t offf = (uint32_t)(rec >> kRecOffShift) & kRecOffMask;
@@ -1870,18 +1532,28 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
 
                 // ---- literals (sequence_execution.go:19-34): they depend on nothing
                 {
-                    const uint32_t sLL = (valid && LL <= 16) ? LL : 0;
+                    const uint32_t sLL = (valid && LL <= 32) ? LL : 0;  // up to two 16-byte loads per lane
                     if (__any(sLL != 0)) {
-                        uint32_t w0 = rleWord, w1 = rleWord, w2 = rleWord, w3 = rleWord, wt = rleWord;
+                        U128U a{rleWord, rleWord, rleWord, rleWord}, c{rleWord, rleWord, rleWord, rleWord};
+                        uint32_t wt = rleWord;
                         if (!litRle && sLL) {
-                            const U128U v = *(const U128U *)(lits + srcL);
-                            w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+                            a = *(const U128U *)(lits + srcL);
+                            if (sLL > 16) c = *(const U128U *)(lits + srcL + 16);
                             if (sLL >= 4) wt = ld32u_g(lits + srcL + sLL - 4);
                         }
-                        lds_store_upto16(lbuf + dstL, sLL, w0, w1, w2, w3, wt);
-                        if (sLL) publish(vmap, dstL, sLL);
+                        if (sLL) {
+                            uint8_t *d = lbuf + dstL;
+                            if (sLL <= 16) lds_store_upto16(d, sLL, a.x, a.y, a.z, a.w, wt);
+                            else {
+                                lds_store_upto16(d, 16, a.x, a.y, a.z, a.w, 0);
+                                lds_store_upto16(d + 16, sLL - 16, c.x, c.y, c.z, c.w, wt);
+                            }
+                            publish(vmap, dstL, sLL);
+                        }
                     }
-                    uint64_t longs = __ballot(valid && LL > 16);
+                    uint64_t longs = __ballot(valid && LL > 32);
+                    EXEC_STAT(10, __popcll(longs));
+                    EXEC_STAT(11, __popcll(__ballot(sLL != 0)));
                     while (longs) {
                         const int src = __builtin_ctzll(longs);
                         longs &= longs - 1;
@@ -1901,6 +1573,8 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                 // (a) short matches sourced entirely before the chunk: final bytes in HBM, no waiting
                 {
                     const bool g = pending && ML <= 32 && !overlap && srcM + (int)ML <= 0;
+                    EXEC_STAT(1, __popcll(__ballot(pending)));
+                    EXEC_STAT(2, __popcll(__ballot(g)));
                     if (__any(g)) {
                         const uint8_t *sp = bout + (int)chunkStart + srcM;  // may point into earlier blocks
                         U128U a{0, 0, 0, 0}, c{0, 0, 0, 0};
@@ -1931,6 +1605,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                 const bool fastKind = isShort && !overlap && srcM >= 0;
                 uint32_t spins = 0;
                 while (__any(pending)) {
+                    EXEC_STAT(3, 1);
                     bool ready = false;
                     if (pending && isShort) {
                         const uint32_t v0 = __hip_atomic_load(&vmap[needw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1943,6 +1618,8 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     // (b1) short, non-overlapping, source inside the chunk: aligned dword reads + funnel
                     const bool fast = ready && fastKind;
                     if (__any(fast)) {
+                        EXEC_STAT(4, 1);
+                        EXEC_STAT(5, __popcll(__ballot(fast)));
                         progressed = true;
                         // wave-uniform bound on the dword loop from two ballots (a shuffle reduction costs ~450 cycles)
                         const uint32_t mlc = __any(fast && ML > 16) ? 32u : (__any(fast && ML > 8) ? 16u : 8u);
@@ -1977,6 +1654,8 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     // (b2) short matches that overlap themselves or straddle the chunk start: byte loop
                     const bool slowb = ready && !fastKind;
                     if (__any(slowb)) {
+                        EXEC_STAT(6, 1);
+                        EXEC_STAT(7, __popcll(__ballot(slowb)));
                         progressed = true;
                         const uint32_t n = slowb ? ML : 0;
                         const uint32_t nmax = wave_max_u32(n);
@@ -1994,6 +1673,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     // (b3) at most one long match per iteration, whole wavefront, non-blocking readiness test
                     const uint64_t longs = __ballot(pending && !isShort);
                     if (longs) {
+                        EXEC_STAT(8, 1);
                         const int src = __builtin_ctzll(longs);
                         const uint32_t n = (uint32_t)__shfl((int)ML, src, 64);
                         const uint32_t d = (uint32_t)__shfl((int)dstM, src, 64);
@@ -2040,6 +1720,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         }
                     }
                     if (!progressed) {
+                        EXEC_STAT(9, 1);
                         if ((++spins & 15) == 0 &&
                             __hip_atomic_load(&sh->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != MZD_OK)
                             break;  // corrupt input: a skipped match would never validate its bytes
@@ -2095,5 +1776,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
         frame_out_len[blockIdx.x] = outPos;
     }
 }
+
+
 
 }  // namespace mzd
