@@ -1,6 +1,8 @@
 // ubench.hip -- micro-benchmarks that steer the kernel design (run on the GPU box):
 //   1. LDS access cost by width and misalignment (correctness + cycles per wave-instruction)
 //   2. DPP-based wave64 inclusive scan / min-reduce vs the shuffle versions
+//   4. issue rates of one CU: VALU (per SIMD) and scalar ALU (per CU) with 16 resident wavefronts
+//   3. cost of predicating an LDS store: exec mask vs a per-lane dump address vs an out-of-range address
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,6 +44,105 @@ __global__ void k_lds(uint64_t *res, uint32_t *sink, int mis, int stride, int it
     uint64_t t1 = clock64();
     if (lane == 0) res[0] = t1 - t0;
     sink[blockIdx.x * blockDim.x + lane] = acc + smem[lane];
+}
+
+
+
+// Issue rates: 16 wavefronts (4 per SIMD) run `iters` x 32 independent instructions of one kind.
+template <int KIND>  // 0: v_add_u32, 1: s_add_u32, 2: v_cndmask_b32, 3: s_and_saveexec/s_or pair
+__global__ void k_issue(uint64_t *res, uint32_t *sink, int iters)
+{
+    uint32_t a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+    __syncthreads();
+    uint64_t t0 = clock64();
+    for (int it = 0; it < iters; it++) {
+        if (KIND == 0) {
+            asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n"
+                         "v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n"
+                         "v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n"
+                         "v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n"
+                         "v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n"
+                         "v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n"
+                         "v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n"
+                         "v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (KIND == 1) {
+            asm volatile("s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n"
+                         "s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n s_add_u32 s26, s26, 1\n s_add_u32 s27, s27, 1\n"
+                         "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n"
+                         "s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n s_add_u32 s26, s26, 1\n s_add_u32 s27, s27, 1\n"
+                         "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n"
+                         "s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n s_add_u32 s26, s26, 1\n s_add_u32 s27, s27, 1\n"
+                         "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n"
+                         "s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n s_add_u32 s26, s26, 1\n s_add_u32 s27, s27, 1\n"
+                         ::: "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
+        } else if (KIND == 2) {
+            asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                         "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                         "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                         "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                         "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                         "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                         "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                         "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "vcc");
+        } else if (KIND == 4) {
+            asm volatile("v_cndmask_b32_e64 %0, %0, %0, s[20:21]\n v_cndmask_b32_e64 %1, %1, %1, s[20:21]\n v_cndmask_b32_e64 %2, %2, %2, s[20:21]\n v_cndmask_b32_e64 %3, %3, %3, s[20:21]\n v_cndmask_b32_e64 %4, %4, %4, s[20:21]\n v_cndmask_b32_e64 %5, %5, %5, s[20:21]\n v_cndmask_b32_e64 %6, %6, %6, s[20:21]\n v_cndmask_b32_e64 %7, %7, %7, s[20:21]\n v_cndmask_b32_e64 %0, %0, %0, s[20:21]\n v_cndmask_b32_e64 %1, %1, %1, s[20:21]\n v_cndmask_b32_e64 %2, %2, %2, s[20:21]\n v_cndmask_b32_e64 %3, %3, %3, s[20:21]\n v_cndmask_b32_e64 %4, %4, %4, s[20:21]\n v_cndmask_b32_e64 %5, %5, %5, s[20:21]\n v_cndmask_b32_e64 %6, %6, %6, s[20:21]\n v_cndmask_b32_e64 %7, %7, %7, s[20:21]\n v_cndmask_b32_e64 %0, %0, %0, s[20:21]\n v_cndmask_b32_e64 %1, %1, %1, s[20:21]\n v_cndmask_b32_e64 %2, %2, %2, s[20:21]\n v_cndmask_b32_e64 %3, %3, %3, s[20:21]\n v_cndmask_b32_e64 %4, %4, %4, s[20:21]\n v_cndmask_b32_e64 %5, %5, %5, s[20:21]\n v_cndmask_b32_e64 %6, %6, %6, s[20:21]\n v_cndmask_b32_e64 %7, %7, %7, s[20:21]\n v_cndmask_b32_e64 %0, %0, %0, s[20:21]\n v_cndmask_b32_e64 %1, %1, %1, s[20:21]\n v_cndmask_b32_e64 %2, %2, %2, s[20:21]\n v_cndmask_b32_e64 %3, %3, %3, s[20:21]\n v_cndmask_b32_e64 %4, %4, %4, s[20:21]\n v_cndmask_b32_e64 %5, %5, %5, s[20:21]\n v_cndmask_b32_e64 %6, %6, %6, s[20:21]\n v_cndmask_b32_e64 %7, %7, %7, s[20:21]\n " : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20", "s21");
+        } else if (KIND == 5) {
+            asm volatile("v_add_u32 %0, s22, %0\n v_add_u32 %1, s22, %1\n v_add_u32 %2, s22, %2\n v_add_u32 %3, s22, %3\n v_add_u32 %4, s22, %4\n v_add_u32 %5, s22, %5\n v_add_u32 %6, s22, %6\n v_add_u32 %7, s22, %7\n v_add_u32 %0, s22, %0\n v_add_u32 %1, s22, %1\n v_add_u32 %2, s22, %2\n v_add_u32 %3, s22, %3\n v_add_u32 %4, s22, %4\n v_add_u32 %5, s22, %5\n v_add_u32 %6, s22, %6\n v_add_u32 %7, s22, %7\n v_add_u32 %0, s22, %0\n v_add_u32 %1, s22, %1\n v_add_u32 %2, s22, %2\n v_add_u32 %3, s22, %3\n v_add_u32 %4, s22, %4\n v_add_u32 %5, s22, %5\n v_add_u32 %6, s22, %6\n v_add_u32 %7, s22, %7\n v_add_u32 %0, s22, %0\n v_add_u32 %1, s22, %1\n v_add_u32 %2, s22, %2\n v_add_u32 %3, s22, %3\n v_add_u32 %4, s22, %4\n v_add_u32 %5, s22, %5\n v_add_u32 %6, s22, %6\n v_add_u32 %7, s22, %7\n " : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s22");
+        } else if (KIND == 6) {
+            asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %4\n v_cmp_lt_u32 vcc, %4, %5\n v_cmp_lt_u32 vcc, %5, %6\n v_cmp_lt_u32 vcc, %6, %7\n v_cmp_lt_u32 vcc, %7, %0\n v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %4\n v_cmp_lt_u32 vcc, %4, %5\n v_cmp_lt_u32 vcc, %5, %6\n v_cmp_lt_u32 vcc, %6, %7\n v_cmp_lt_u32 vcc, %7, %0\n v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %4\n v_cmp_lt_u32 vcc, %4, %5\n v_cmp_lt_u32 vcc, %5, %6\n v_cmp_lt_u32 vcc, %6, %7\n v_cmp_lt_u32 vcc, %7, %0\n v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %4\n v_cmp_lt_u32 vcc, %4, %5\n v_cmp_lt_u32 vcc, %5, %6\n v_cmp_lt_u32 vcc, %6, %7\n v_cmp_lt_u32 vcc, %7, %0\n " : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "vcc");
+        } else if (KIND == 7) {
+            asm volatile("v_cndmask_b32 %0, %0, %0, vcc\n v_cndmask_b32 %1, %1, %1, vcc\n v_cndmask_b32 %2, %2, %2, vcc\n v_cndmask_b32 %3, %3, %3, vcc\n v_cndmask_b32 %4, %4, %4, vcc\n v_cndmask_b32 %5, %5, %5, vcc\n v_cndmask_b32 %6, %6, %6, vcc\n v_cndmask_b32 %7, %7, %7, vcc\n v_cndmask_b32 %0, %0, %0, vcc\n v_cndmask_b32 %1, %1, %1, vcc\n v_cndmask_b32 %2, %2, %2, vcc\n v_cndmask_b32 %3, %3, %3, vcc\n v_cndmask_b32 %4, %4, %4, vcc\n v_cndmask_b32 %5, %5, %5, vcc\n v_cndmask_b32 %6, %6, %6, vcc\n v_cndmask_b32 %7, %7, %7, vcc\n v_cndmask_b32 %0, %0, %0, vcc\n v_cndmask_b32 %1, %1, %1, vcc\n v_cndmask_b32 %2, %2, %2, vcc\n v_cndmask_b32 %3, %3, %3, vcc\n v_cndmask_b32 %4, %4, %4, vcc\n v_cndmask_b32 %5, %5, %5, vcc\n v_cndmask_b32 %6, %6, %6, vcc\n v_cndmask_b32 %7, %7, %7, vcc\n v_cndmask_b32 %0, %0, %0, vcc\n v_cndmask_b32 %1, %1, %1, vcc\n v_cndmask_b32 %2, %2, %2, vcc\n v_cndmask_b32 %3, %3, %3, vcc\n v_cndmask_b32 %4, %4, %4, vcc\n v_cndmask_b32 %5, %5, %5, vcc\n v_cndmask_b32 %6, %6, %6, vcc\n v_cndmask_b32 %7, %7, %7, vcc\n " : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "vcc");
+        } else {
+            asm volatile("s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]\n"
+                         ::: "s20", "s21", "s22", "s23", "scc");
+        }
+    }
+    __syncthreads();
+    uint64_t t1 = clock64();
+    if (threadIdx.x == 0) res[0] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// LDS store predication.  `nact` of 64 lanes store to scattered addresses; the others are disabled by
+//   MODE 0: the exec mask (if), MODE 1: redirecting them to a per-lane dump dword,
+//   MODE 2: redirecting them to an address beyond the workgroup's LDS allocation (hardware drops it).
+template <int MODE>
+__global__ void k_pred(uint64_t *res, uint32_t *sink, int nact, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool active = (lane * nact) / 64 != ((lane + 1) * nact) / 64 || (nact == 64);
+    const uint32_t real = (uint32_t)(wave * 2048 + ((lane * 37) & 511) * 4 + 1);   // scattered, misaligned
+    const uint32_t dump = 60000u + (uint32_t)threadIdx.x * 4u;
+    const uint32_t addr = MODE == 0 ? real : (active ? real : (MODE == 1 ? dump : 0x00FF0000u));
+    uint32_t acc = lane;
+    __syncthreads();
+    uint64_t t0 = clock64();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (MODE == 0) {
+                if (active) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(acc), "n"(0) : "memory");
+            } else {
+                asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(acc) : "memory");
+            }
+            acc += u;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint64_t t1 = clock64();
+    if (threadIdx.x == 0) res[0] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = acc + smem[lane];
 }
 
 // correctness of misaligned LDS dword read/write
@@ -140,6 +241,42 @@ int main()
                 run(k_lds<8, true>, "write b64", mis, stride, threads);
             }
         }
+    }
+
+
+    {
+        auto runi = [&](auto kern, const char *name, int threads) {
+            uint64_t r;
+            kern<<<1, threads>>>(d_res, d_sink, 20000);
+            hipDeviceSynchronize();
+            hipMemcpy(&r, d_res, 8, hipMemcpyDeviceToHost);
+            const double instrs = 20000.0 * 32 * (threads / 64);
+            printf("issue rate %-28s %2d waves on one CU: %.2f cycles per wave-instruction (CU-wide), %.2f per SIMD\n", name,
+                   threads / 64, (double)r / instrs, (double)r / instrs * 4);
+        };
+        for (int threads : {64, 256, 1024}) {
+            runi(k_issue<0>, "v_add_u32", threads);
+            runi(k_issue<2>, "v_cndmask_b32", threads);
+            runi(k_issue<1>, "s_add_u32", threads);
+            runi(k_issue<3>, "s_and_saveexec / s_or exec", threads);
+            runi(k_issue<4>, "v_cndmask_e64 sgpr mask", threads);
+            runi(k_issue<7>, "v_cndmask vcc independent", threads);
+            runi(k_issue<5>, "v_add_u32 v, s, v", threads);
+            runi(k_issue<6>, "v_cmp_lt_u32 vcc", threads);
+        }
+    }
+    for (int nact : {4, 16, 64}) {
+        auto runp = [&](auto kern, const char *name) {
+            uint64_t r;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            kern<<<1, 1024, 65536>>>(d_res, d_sink, nact, iters);
+            hipDeviceSynchronize();
+            hipMemcpy(&r, d_res, 8, hipMemcpyDeviceToHost);
+            printf("store predication %-12s active lanes %2d, 16 waves: %.1f cycles per wave-instruction (per wave)\n", name, nact, (double)r / (iters * 8.0));
+        };
+        runp(k_pred<0>, "exec mask");
+        runp(k_pred<1>, "dump slot");
+        runp(k_pred<2>, "out of range");
     }
     k_scan<<<1, 64>>>(d_sink, d_res, 10000);
     CHECK(hipDeviceSynchronize());
