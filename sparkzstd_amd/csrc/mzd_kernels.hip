@@ -4,7 +4,7 @@
 //
 //   k_huf   Huffman literal decode      replaces structure/huffman.go:221-264 DecodeStream
 //                                       (+ the 1/4-stream dispatch literals.go:295-371)
-//   k_seq   FSE sequence decode         replaces structure/sequences.go:126-206 DecodeSequences,
+//   k_seq_pipe / k_seq  FSE sequence decode   replaces structure/sequences.go:126-206 DecodeSequences,
 //                                       :64-123 DecodeSequence, fse/fse.go:253-290 state accessors,
 //                                       and folds in sequence_execution.go:65-114 nextOffset
 //   k_exec  sequence execution          replaces decompression/sequence_execution.go:14-63 and
@@ -14,13 +14,15 @@
 // Mapping (see DESIGN.md for the reasoning and the roofline of each):
 //   k_huf   one LANE per Huffman stream; the 4 streams of a literals section sit in 4 adjacent
 //           lanes and share one decode table staged in LDS; 16 sections per wavefront.
-//   k_seq   one LANE per block = one serial LL/ML/OF state chain; each chain's three FSE tables
-//           live in LDS (that is what bounds the number of resident chains), the bitstream is
-//           consumed through a 128-bit register window refilled ahead of use.
-//   k_exec  one WORKGROUP per frame; the block being regenerated lives in a 128 KiB LDS buffer
-//           (the "window" all near matches hit), 64-sequence tiles are executed by wavefronts
-//           out of order with an in-order commit watermark, and the finished block leaves for HBM
-//           in aligned 16-byte stores.
+//   k_seq_pipe  one LANE per block = one serial LL/ML/OF state chain; each chain's three FSE tables
+//           live in LDS (that is what bounds the number of resident chains to one wavefront per CU).
+//           The step is a three-stage pipeline across the CU's SIMDs: only the recurrence stays on
+//           the chain wavefront (hand-scheduled ISA), field extraction and record/history work
+//           follow in two more wavefronts through LDS queues.  k_seq is the two-wavefront
+//           predecessor (fallback for blobs >= 4 GiB).
+//   k_exec  one WORKGROUP per frame, up to 16 per CU; the chunk (8 KiB) of the block being regenerated
+//           lives in LDS, older output is final in the frame's HBM slab; 64-sequence tiles run as a
+//           dataflow on a per-byte validity bitmap, finished chunks leave in aligned 16-byte stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
