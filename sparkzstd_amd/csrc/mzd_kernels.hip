@@ -703,25 +703,45 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         if (lane < 36 && seq_code6(0, lane) != kPipeEscape) CTc[seq_code6(0, lane)] = c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24);
         if (lane < 53 && seq_code6(1, lane) != kPipeEscape) CTc[64 + seq_code6(1, lane)] = c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24);
     }
-    // stage the three tables of every chain of this workgroup (all four wavefronts copy)
-    for (uint32_t ch = 0; ch < nch; ch++) {
-        if (blockIdx.x * nch + ch >= n_tasks) break;
-        uint32_t off[3], lg[3];
-        off[0] = (uint32_t)__shfl((int)t.ll_off, (int)ch, 64);
-        off[1] = (uint32_t)__shfl((int)t.ml_off, (int)ch, 64);
-        off[2] = (uint32_t)__shfl((int)t.of_off, (int)ch, 64);
-        lg[0] = (uint32_t)__shfl((int)t.ll_log, (int)ch, 64);
-        lg[1] = (uint32_t)__shfl((int)t.ml_log, (int)ch, 64);
-        lg[2] = (uint32_t)__shfl((int)t.of_log, (int)ch, 64);
+#ifdef MZD_PIPE_PROF
+    const long long prof_k0 = clock64();
+#endif
+    // ---- stage the three tables of every chain of this workgroup: ONE flat loop over the cells of
+    // all chains (the LDS cell array is exactly [chain][1280]), 8 independent loads in flight per
+    // thread; a loop per chain and table serialises ~340 dependent memory round trips (0.35 ms of a
+    // 3.9 ms round).  The table descriptors of the chains go through LDS (the A->B queue is idle yet).
+    {
+        uint32_t *desc = (uint32_t *)&shs->q1t[0][0];  // [chain][4]: ll_off, ml_off, of_off, logs
+        if (wave == 0) {
+            desc[4 * lane + 0] = t.ll_off;
+            desc[4 * lane + 1] = t.ml_off;
+            desc[4 * lane + 2] = t.of_off;
+            desc[4 * lane + 3] = has ? ((uint32_t)t.ll_log | ((uint32_t)t.ml_log << 8) | ((uint32_t)t.of_log << 16)) : 0x00FFFFFFu;
+        }
+        __syncthreads();
+        const uint32_t ncell = min(nch, n_tasks - blockIdx.x * nch) * kSeqCellsPerChain;
+        constexpr int UNR = 8;
+        for (uint32_t idx0 = threadIdx.x; idx0 < ncell; idx0 += 256 * UNR) {
+            uint32_t e[UNR], n[UNR], c6k[UNR];
+            bool ok[UNR];
 #pragma unroll
-        for (int kind = 0; kind < 3; kind++) {
-            const uint32_t n = 1u << lg[kind];
-            const uint32_t base = ch * kSeqCellsPerChain + (uint32_t)kind * 512;
-            for (uint32_t i = threadIdx.x; i < n; i += 256) {
-                const uint32_t e = fse_entries[off[kind] + i];  // baseline(16) | nbits(8) | symbol(8)
-                const uint32_t baseline = e & 0xFFFF, nb = (e >> 16) & 0xFF, sym = e >> 24;
-                const uint32_t c6 = kind == 2 ? sym : seq_code6(kind, sym);
-                cells[base + i] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n) >> nb) | (c6 << 10));
+            for (int u = 0; u < UNR; u++) {
+                const uint32_t idx = idx0 + 256 * u;
+                const uint32_t ch = idx / kSeqCellsPerChain, r = idx - ch * kSeqCellsPerChain;
+                const uint32_t kind = r >= 1024 ? 2u : (r >> 9);
+                const uint32_t i = r - (kind << 9);
+                const uint32_t lg = (desc[4 * min(ch, 63u) + 3] >> (8 * kind)) & 0xFF;
+                n[u] = 1u << (lg & 31);
+                ok[u] = idx < ncell && lg <= 9 && i < n[u];
+                c6k[u] = kind;
+                e[u] = ok[u] ? fse_entries[desc[4 * min(ch, 63u) + kind] + i] : 0u;  // baseline(16) | nbits(8) | symbol(8)
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const uint32_t baseline = e[u] & 0xFFFF, nb = (e[u] >> 16) & 0xFF, sym = e[u] >> 24;
+                const uint32_t c6 = c6k[u] == 2 ? sym : seq_code6((int)c6k[u], sym);
+                if (ok[u])
+                    cells[idx0 + 256 * u] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n[u]) >> (nb & 31)) | (c6 << 10));
             }
         }
     }
@@ -783,6 +803,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         uint32_t tail_seen = 0;
 #ifdef MZD_PIPE_PROF
         long long prof_wait = 0, prof_t0 = clock64(), prof_r0 = wall_clock64();
+        if (blockIdx.x == 0 && lane == 0) printf("A: staging + init %lld cycles\n", prof_t0 - prof_k0);
 #endif
         auto wait_space = [&](uint32_t at) {  // slot of step `at` is free once at - tail1 < depth
 #ifdef MZD_PIPE_PROF
