@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
     ap.add_argument("--seq-variant", type=int, default=0)
+    ap.add_argument("--host-tables", action="store_true", help="build the FSE tables in the host planner instead of on the device")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--exec-chunk", type=int, default=0)
     ap.add_argument("--huf-min-lds", type=int, default=0)
@@ -191,7 +192,7 @@ def main():
         nseq = np.tile(nseq, reps)[:per]
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    plan = z.Plan()
+    plan = z.Plan(device_tables=not a.host_tables)
     rc = plan.add_frames(blob, off, ln, threads=gen_threads)
     assert rc == 0, f"planner failed: {rc}"
     batch = plan.finalize()
@@ -302,7 +303,10 @@ def main():
                        "exec_chunk": a.exec_chunk or 8192},
             "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok,
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
-            "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 2), "upload": round(t_upload, 2)},
+            "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 3), "upload": round(t_upload, 3),
+                        "fse_tables": "host" if a.host_tables else "device",
+                        "fse_tables_built_on_device": int(stats.n_fse_built),
+                        "k_fse_build_ms": round(float(stats.fse_build_ms), 3)},
         }
         print(json.dumps(line), flush=True)
     rb.free()

@@ -120,11 +120,18 @@ typedef struct mzd_fse_entry {
 
 enum { MZD_FSE_LL = 0, MZD_FSE_OF = 1, MZD_FSE_ML = 2 };
 
+/* A table arrives either BUILT (build == 0: fse_entries[entries_off .. +1<<acc_log) are the decoding-table
+ * cells, what fse.go:136-230 BuildDecodingTable produces) or as its NORMALISED COUNTS
+ * (build == MZD_FSE_FROM_COUNTS | n_symbols): then it occupies only (n_symbols + 1) / 2 cells of
+ * fse_entries[], the counts of fse.go:28-130, two int16 per cell in symbol order (-1 == "less
+ * than one"), and the library builds the decoding table on the device at upload (SURVEY 8f #1:
+ * table construction off the host). */
+#define MZD_FSE_FROM_COUNTS 0x8000u
 typedef struct mzd_fse_table_desc {
     uint32_t entries_off;  /* first cell in fse_entries[] */
     uint8_t acc_log;       /* table has 1<<acc_log cells; 0 == RLE mode */
     uint8_t kind;          /* MZD_FSE_* */
-    uint16_t reserved;
+    uint16_t build;        /* 0, or MZD_FSE_FROM_COUNTS | number of symbols (<= 53) */
 } mzd_fse_table_desc;
 
 /* Huffman decode table cell == huffman.go:30-37 (Symbols[j], NumberOfBits[j]),
@@ -239,8 +246,14 @@ typedef struct mzd_batch_stats {
     uint64_t n_sequences;
     uint64_t n_huf_streams;
     uint64_t n_blocks[3];         /* raw, rle, compressed */
+    uint64_t n_fse_built;         /* FSE tables built on the device from their counts (MZD_FSE_FROM_COUNTS) */
+    double fse_build_ms;          /* duration of that build (k_fse_build, once per upload) */
 } mzd_batch_stats;
 int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st);
+/* Copies the DEVICE decoding table number `table` (1 << acc_log cells, after the device-side build)
+ * back to the host; returns the number of cells or -MZD_ERR_*.  Lets tests compare device-built
+ * tables with the host planner's, cell by cell. */
+int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_fse_entry *out, uint32_t cap);
 
 /* ------------------------------------------------------------------ host planner
  * C++ restatement of the reference's host side, exposed in C so that tests, the
@@ -253,6 +266,10 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st);
  *   FSE tables          fse/fse.go:28-230, fse/predefined.go
  *   table carry-over    framedecompressor.go:283-294 (Repeat / Treeless) */
 mzd_plan *mzd_plan_create(void);
+/* on != 0: FSE tables are emitted as normalised counts and built on the device at upload
+ * (MZD_FSE_FROM_COUNTS); default off: the planner builds the cells on the host.  Survives
+ * mzd_plan_reset. */
+void mzd_plan_set_device_tables(mzd_plan *p, int on);
 void mzd_plan_destroy(mzd_plan *p);
 void mzd_plan_reset(mzd_plan *p);
 /* Parses one frame starting at `frame` (magic number first) and appends it to the

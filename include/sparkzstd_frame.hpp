@@ -50,6 +50,7 @@ inline std::vector<std::vector<uint8_t>> DecodeFrames(const std::vector<std::vec
 {
     if (!ctx) ctx = default_context();
     mzd_plan *plan = mzd_plan_create();
+    mzd_plan_set_device_tables(plan, 1);  // FSE tables travel as normalised counts and are built on the device
     std::vector<int> st(frames.size(), MZD_OK);
     for (size_t i = 0; i < frames.size(); i++)
         st[i] = mzd_plan_add_frame(plan, frames[i].data(), frames[i].size(), nullptr);

@@ -24,9 +24,13 @@ class Plan:
     Mirrors what sparkzstd's Go host code keeps doing (frame.go, block.go, literals.go:67-289,
     sequences.go:228-450, huffman.go:40-190, fse.go:28-230)."""
 
-    def __init__(self):
+    def __init__(self, device_tables: bool = False):
+        """device_tables: emit FSE tables as normalised counts; the library builds them on the device
+        at upload (mzd_plan_set_device_tables)."""
         self._L = _lib.load()
         self._p = self._L.mzd_plan_create()
+        if device_tables:
+            self._L.mzd_plan_set_device_tables(self._p, 1)
         self._keep = []
         self._batch = None
 
@@ -91,6 +95,14 @@ class ResidentBatch:
         if rc:
             raise MzdError(rc, "mzd_batch_download: " + self.ctx.last_error())
         return out, status, out_len
+
+    def read_fse_table(self, table: int) -> np.ndarray:
+        """Device decoding table `table` as uint32 cells (baseline | nbits << 16 | symbol << 24)."""
+        out = np.empty(512, dtype=np.uint32)
+        n = self.ctx._L.mzd_batch_read_fse_table(self.ctx._c, self._h, table, out.ctypes.data, 512)
+        if n < 0:
+            raise MzdError(-n, "mzd_batch_read_fse_table: " + self.ctx.last_error())
+        return out[:n].copy()
 
     def device_out_ptr(self):
         return self.ctx._L.mzd_batch_device_out(self._h)
@@ -192,12 +204,13 @@ def default_context(device: int = 0) -> Context:
     return _default_ctx[device]
 
 
-def decode_frames(frames, ctx: Context = None):
+def decode_frames(frames, ctx: Context = None, device_tables: bool = True):
     """Decodes independent zstd frames (list of bytes) in ONE device batch.
     -> (outputs: list of bytes-or-None, statuses: list of int).  The batched analogue of calling
-    sparkzstd's FrameDecompressor.Decompress() (framedecompressor.go:153) once per frame."""
+    sparkzstd's FrameDecompressor.Decompress() (framedecompressor.go:153) once per frame.
+    device_tables: FSE tables are shipped as normalised counts and built on the device."""
     ctx = ctx or default_context()
-    plan = Plan()
+    plan = Plan(device_tables=device_tables)
     try:
         plan_status = []
         for f in frames:

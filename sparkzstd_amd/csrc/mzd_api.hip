@@ -46,6 +46,9 @@ struct mzd_dbatch {
     HufTask *d_huf_tasks = nullptr;
     SeqTask *d_seq_tasks = nullptr;
     uint32_t *d_fse_entries = nullptr;
+    uint32_t n_fse_entries = 0, n_fse_built = 0;  // device cells; tables built from counts
+    std::vector<uint32_t> fse_dev_off;             // first device cell of every table (+ total)
+    float fse_build_ms = 0;  // k_fse_build at upload (tables that came as normalised counts)
     uint16_t *d_huf_entries = nullptr;
     uint64_t *d_recs = nullptr;
     TileBase *d_tiles = nullptr;
@@ -206,14 +209,48 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         return MZD_ERR_INVALID_ARG;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-
     // ---- validate tables once per table
     std::vector<uint8_t> fse_ok(b->n_fse_tables, 1), huf_ok(b->n_huf_tables, 1);
+    uint32_t n_fse_build = 0;  // tables that arrive as normalised counts (built on the device below)
+    // device layout of the decoding tables: every table gets its full 1 << acc_log cells, whatever form it
+    // arrived in (a count-form table occupies only (n_symbols + 1) / 2 cells of the host array)
+    std::vector<uint32_t> fse_dev_off(b->n_fse_tables + 1, 0);
+    {
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < b->n_fse_tables; i++) {
+            fse_dev_off[i] = (uint32_t)at;
+            at += 1ull << std::min<uint32_t>(b->fse_tables[i].acc_log, 9);
+            if (at > 0xFFFFFFFFull) {
+                ctx->last_error = "more than 2^32 FSE table cells";
+                return MZD_ERR_INVALID_ARG;
+            }
+        }
+        fse_dev_off[b->n_fse_tables] = (uint32_t)at;
+    }
     for (uint32_t i = 0; i < b->n_fse_tables; i++) {
         const mzd_fse_table_desc &d = b->fse_tables[i];
         const uint64_t n = 1ull << d.acc_log;
-        if (d.kind > 2 || d.acc_log > kMaxLog[d.kind] || (uint64_t)d.entries_off + n > b->n_fse_entries) {
+        // cells this table occupies in fse_entries[]: all of them, or just the packed counts
+        const uint64_t host_cells = (d.build & MZD_FSE_FROM_COUNTS) ? ((d.build & 0xFFu) + 1) / 2 : n;
+        if (d.kind > 2 || d.acc_log > kMaxLog[d.kind] || (uint64_t)d.entries_off + host_cells > b->n_fse_entries) {
             fse_ok[i] = 0;
+            continue;
+        }
+        if (d.build & MZD_FSE_FROM_COUNTS) {
+            // normalised counts: they must add up to the table size (then the spread of fse.go:160-190
+            // visits every cell exactly once) and name no symbol beyond the kind's alphabet
+            const uint32_t nsym = d.build & 0xFF;
+            int64_t sum = 0;
+            bool ok = (d.build & ~(MZD_FSE_FROM_COUNTS | 0xFFu)) == 0 && nsym >= 1 && nsym <= (uint32_t)kMaxSym[d.kind] + 1 &&
+                      d.acc_log >= 5;
+            for (uint32_t sidx = 0; ok && sidx < nsym; sidx++) {
+                const mzd_fse_entry &e = b->fse_entries[d.entries_off + (sidx >> 1)];
+                const int16_t c = (sidx & 1) ? (int16_t)((uint16_t)e.nbits | ((uint16_t)e.symbol << 8)) : (int16_t)e.baseline;
+                if (c < -1) ok = false;
+                sum += c < 0 ? 1 : c;
+            }
+            if (!ok || sum != (int64_t)n) fse_ok[i] = 0;
+            else n_fse_build++;
             continue;
         }
         for (uint64_t j = 0; j < n; j++) {
@@ -353,9 +390,9 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                 t.rec_off = rec_total;
                 t.tile_off = (uint32_t)tile_total;
                 t.block = bi;
-                t.ll_off = b->fse_tables[bd.ll_table].entries_off;
-                t.of_off = b->fse_tables[bd.of_table].entries_off;
-                t.ml_off = b->fse_tables[bd.ml_table].entries_off;
+                t.ll_off = fse_dev_off[bd.ll_table];
+                t.of_off = fse_dev_off[bd.of_table];
+                t.ml_off = fse_dev_off[bd.ml_table];
                 t.ll_log = b->fse_tables[bd.ll_table].acc_log;
                 t.of_log = b->fse_tables[bd.of_table].acc_log;
                 t.ml_log = b->fse_tables[bd.ml_table].acc_log;
@@ -428,9 +465,53 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     TRY_OR_FAIL(upload_vec(ctx, huf_tasks, &db->d_huf_tasks));
     TRY_OR_FAIL(upload_vec(ctx, seq_tasks, &db->d_seq_tasks));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_sums, std::max<size_t>(b->n_blocks, 1) * sizeof(BlockSum)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_fse_entries, std::max<size_t>(b->n_fse_entries, 1) * 4));
-    if (b->n_fse_entries)
-        HIP_OR_FAIL(hipMemcpy(db->d_fse_entries, b->fse_entries, (size_t)b->n_fse_entries * 4, hipMemcpyHostToDevice));
+    // ---- FSE tables: the host array (cells or packed counts) goes up as it is; k_fse_build lays the
+    // decoding tables out on the device, copying the ones that came built and building the others
+    // (SURVEY 8f #1).  Once per batch.
+    {
+        const uint32_t n_dev_cells = fse_dev_off[b->n_fse_tables];
+        HIP_OR_FAIL(hipMalloc((void **)&db->d_fse_entries, std::max<size_t>(n_dev_cells, 1) * 4));
+        db->n_fse_entries = n_dev_cells;
+        db->fse_dev_off = fse_dev_off;
+        if (b->n_fse_tables) {
+            std::vector<FseBuildDesc> tabs(b->n_fse_tables);
+            for (uint32_t i = 0; i < b->n_fse_tables; i++) {
+                const mzd_fse_table_desc &d = b->fse_tables[i];
+                tabs[i].src_off = d.entries_off;
+                tabs[i].dst_off = fse_dev_off[i];
+                tabs[i].acc_log = (uint8_t)std::min<uint32_t>(d.acc_log, 9);
+                tabs[i].n_sym = (uint8_t)((d.build & MZD_FSE_FROM_COUNTS) ? (d.build & 0xFF) : 0);
+                tabs[i].ok = fse_ok[i];
+            }
+            FseBuildDesc *d_tabs = nullptr;
+            uint32_t *d_src = nullptr;
+            HIP_OR_FAIL(hipMalloc((void **)&d_tabs, tabs.size() * sizeof(FseBuildDesc)));
+            hipError_t e0 = hipMalloc((void **)&d_src, std::max<size_t>(b->n_fse_entries, 1) * 4);
+            hipError_t e1 = e0 != hipSuccess ? e0 : hipMemcpy(d_tabs, tabs.data(), tabs.size() * sizeof(FseBuildDesc), hipMemcpyHostToDevice);
+            if (e1 == hipSuccess && b->n_fse_entries)
+                e1 = hipMemcpy(d_src, b->fse_entries, (size_t)b->n_fse_entries * 4, hipMemcpyHostToDevice);
+            hipEvent_t t0, t1;
+            (void)hipEventCreate(&t0);
+            (void)hipEventCreate(&t1);
+            (void)hipEventRecord(t0, ctx->stream);
+            if (e1 == hipSuccess)
+                k_fse_build<<<(b->n_fse_tables + 63) / 64, 64, 0, ctx->stream>>>(d_tabs, b->n_fse_tables, d_src, db->d_fse_entries);
+            (void)hipEventRecord(t1, ctx->stream);
+            hipError_t e2 = hipStreamSynchronize(ctx->stream);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, t0, t1);
+            db->fse_build_ms = ms;
+            db->n_fse_built = n_fse_build;
+            (void)hipEventDestroy(t0);
+            (void)hipEventDestroy(t1);
+            (void)hipFree(d_tabs);
+            (void)hipFree(d_src);
+            if (e1 != hipSuccess || e2 != hipSuccess) {
+                ctx->last_error = std::string("k_fse_build failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+                return fail(MZD_ERR_DEVICE);
+            }
+        }
+    }
     HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_entries, std::max<size_t>(b->n_huf_entries, 2) * 2 + 8));
     if (b->n_huf_entries)
         HIP_OR_FAIL(hipMemcpy(db->d_huf_entries, b->huf_entries, (size_t)b->n_huf_entries * 2, hipMemcpyHostToDevice));
@@ -591,6 +672,16 @@ extern "C" int mzd_debug_exec_stats(unsigned long long *out, int reset)
 }
 #endif
 
+int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_fse_entry *out, uint32_t cap)
+{
+    if (!ctx || !db || !out || (size_t)table + 1 >= db->fse_dev_off.size()) return -MZD_ERR_INVALID_ARG;
+    const uint32_t first = db->fse_dev_off[table], n = db->fse_dev_off[table + 1] - first;
+    if (n > cap) return -MZD_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -MZD_ERR_DEVICE;
+    if (n && hipMemcpy(out, db->d_fse_entries + first, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -MZD_ERR_DEVICE;
+    return (int)n;
+}
+
 int mzd_sync(mzd_ctx *ctx)
 {
     if (!ctx) return MZD_ERR_INVALID_ARG;
@@ -679,6 +770,8 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
 {
     if (!db || !st) return MZD_ERR_INVALID_ARG;
     *st = db->stats;
+    st->n_fse_built = db->n_fse_built;
+    st->fse_build_ms = db->fse_build_ms;
     return MZD_OK;
 }
 

@@ -143,6 +143,77 @@ __global__ void k_init(BlockSum *sums, uint32_t n_blocks)
 }
 
 // ------------------------------------------------------------------------------------------
+// k_fse_build: FSE decoding tables from their normalised counts, on the device (SURVEY 8f #1;
+// replaces fse/fse.go:136-230 BuildDecodingTable for tables that arrive as MZD_FSE_FROM_COUNTS).
+// It also lays the tables out on the device (tables that arrive built are copied).  Run once per
+// batch at upload.  One LANE per table: the spread walk and the per-symbol "next"
+// counters are serial within a table and a batch has hundreds of thousands of tables.  The
+// symbols of the table under construction and the counters live in LDS ([index][lane], so the 64
+// lanes of a wavefront hit distinct banks); global memory is read once (the counts) and written
+// once (the finished cells baseline:16 | nbits:8 | symbol:8).
+__global__ __launch_bounds__(64) void k_fse_build(const FseBuildDesc *__restrict__ tabs, uint32_t n_tabs,
+                                                  const uint32_t *__restrict__ src, uint32_t *__restrict__ cells)
+{
+    __shared__ uint8_t sym[512][64];     // cell -> symbol
+    __shared__ int16_t cnt[64][64];      // symbol -> normalised count (-1 == "less than one")
+    __shared__ uint16_t nextv[64][64];   // symbol -> next state value to hand out (fse.go:192-213)
+    const int lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64 + lane;
+    if (t >= n_tabs) return;
+    const FseBuildDesc d = tabs[t];
+    const int lg = d.acc_log, size = 1 << lg;
+    uint32_t *c = cells + d.dst_off;
+    if (!d.ok) {  // rejected at upload: blocks that use it carry a status, nobody reads these cells
+        for (int i = 0; i < size; i++) c[i] = 0;
+        return;
+    }
+    if (d.n_sym == 0) {  // arrived built (predefined, RLE, or a host that builds its own tables): copy
+        for (int i = 0; i < size; i++) c[i] = src[d.src_off + i];
+        return;
+    }
+    const int nsym = min((int)d.n_sym, 64);
+    for (int s = 0; s < nsym; s += 2) {
+        const uint32_t w = src[d.src_off + (s >> 1)];
+        cnt[s][lane] = (int16_t)(w & 0xFFFF);
+        if (s + 1 < nsym) cnt[s + 1][lane] = (int16_t)(w >> 16);
+    }
+    // "less than one" symbols take the top cells (fse.go:146-155)
+    int high = size - 1;
+    for (int s = 0; s < nsym; s++) {
+        const int n = cnt[s][lane];
+        if (n == -1) {
+            sym[max(high, 0)][lane] = (uint8_t)s;
+            high--;
+            nextv[s][lane] = 1;
+        } else {
+            nextv[s][lane] = (uint16_t)n;
+        }
+    }
+    // the others are spread with step size/2 + size/8 + 3 over the cells below (fse.go:160-184); the
+    // upload check guarantees that the counts add up to the table size, so every cell is visited once
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        const int n = cnt[s][lane];
+        for (int i = 0; i < n; i++) {
+            sym[pos][lane] = (uint8_t)s;
+            int guard = 0;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos > high && ++guard <= size);
+        }
+    }
+    // per cell, in index order: nbits = acc_log - highbit(next), baseline = (next << nbits) - size
+    for (int i = 0; i < size; i++) {
+        const uint32_t s = sym[i][lane] & 63;
+        const uint32_t n = nextv[s][lane];
+        nextv[s][lane] = (uint16_t)(n + 1);
+        const uint32_t nb = (uint32_t)lg - (31u - (uint32_t)__builtin_clz(n | 1));
+        c[i] = (((n << nb) - (uint32_t)size) & 0xFFFF) | (nb << 16) | (s << 24);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_huf: Huffman literal streams.  One wavefront per workgroup; lane = stream; 16 table slots.
 //
 // Restates huffman.go:221-264: after the padding marker the stream holds R data bits; each

@@ -271,7 +271,10 @@ struct FrameParser {
     // "previous" tables = last table actually used, per kind (framedecompressor.go:283-294)
     uint32_t prev_huf = MZD_NO_TABLE, prev_ll = MZD_NO_TABLE, prev_of = MZD_NO_TABLE, prev_ml = MZD_NO_TABLE;
 
-    FrameParser(const uint8_t *b, uint64_t off, uint64_t len, FramePart &o) : base(b), begin(off), end(off + len), out(o) {}
+    bool device_tables = false;  // emit FSE tables as normalised counts (MZD_FSE_FROM_COUNTS)
+
+    FrameParser(const uint8_t *b, uint64_t off, uint64_t len, FramePart &o, bool dev = false)
+        : base(b), begin(off), end(off + len), out(o), device_tables(dev) {}
 
     uint32_t add_fse_table(const std::vector<mzd_fse_entry> &cells, int acc_log, int kind)
     {
@@ -310,6 +313,20 @@ struct FrameParser {
             if (nc.acc_log > kMaxLog[kind]) return -MZD_ERR_UNSUPPORTED;
             if ((int)nc.prob.size() > kMaxSym[kind] + 1) return -MZD_ERR_FSE_TABLE;
             std::vector<mzd_fse_entry> cells;
+            if (device_tables) {
+                // counts only: two int16 per cell; read_fse_description has checked that they sum to the
+                // table size, which is all the spread of fse.go:136-190 needs to succeed
+                cells.assign((nc.prob.size() + 1) / 2, mzd_fse_entry{0, 0, 0});
+                for (size_t s = 0; s < nc.prob.size(); s++) {
+                    const uint16_t c = (uint16_t)nc.prob[s];
+                    mzd_fse_entry &e = cells[s >> 1];
+                    if (s & 1) { e.nbits = (uint8_t)(c & 0xFF); e.symbol = (uint8_t)(c >> 8); }
+                    else e.baseline = c;
+                }
+                chosen = prev = add_fse_table(cells, nc.acc_log, kind);
+                out.fse_tables.back().build = (uint16_t)(MZD_FSE_FROM_COUNTS | nc.prob.size());
+                return used;
+            }
             int rc = build_fse_cells(nc, cells);
             if (rc) return -rc;
             chosen = prev = add_fse_table(cells, nc.acc_log, kind);
@@ -535,6 +552,7 @@ struct mzd_plan {
     std::vector<mzd_huf_table_desc> huf_tables;
     std::vector<mzd_huf_entry> huf_entries;
     uint32_t predef[3] = {MZD_NO_TABLE, MZD_NO_TABLE, MZD_NO_TABLE};
+    bool device_tables = false;
     mzd_batch view{};
 
     uint32_t predefined(int kind)
@@ -609,7 +627,13 @@ void mzd_plan_destroy(mzd_plan *p) { delete p; }
 void mzd_plan_reset(mzd_plan *p)
 {
     if (!p) return;
+    const bool dev = p->device_tables;
     *p = mzd_plan();
+    p->device_tables = dev;
+}
+void mzd_plan_set_device_tables(mzd_plan *p, int on)
+{
+    if (p) p->device_tables = on != 0;
 }
 
 int mzd_plan_add_frame(mzd_plan *p, const uint8_t *frame, uint64_t len, uint64_t *consumed)
@@ -618,7 +642,7 @@ int mzd_plan_add_frame(mzd_plan *p, const uint8_t *frame, uint64_t len, uint64_t
     const uint64_t at = p->owned_blob.size();
     // parse in place first, then copy only what the frame used (+ nothing of the checksum)
     FramePart fp;
-    FrameParser(frame, 0, len, fp).run();
+    FrameParser(frame, 0, len, fp, p->device_tables).run();
     const uint64_t keep = fp.status ? 0 : fp.consumed;
     p->owned_blob.insert(p->owned_blob.end(), frame, frame + keep);
     p->merge(fp, at);
@@ -638,9 +662,10 @@ int mzd_plan_add_frames(mzd_plan *p, const uint8_t *blob, const uint64_t *frame_
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
     n_threads = std::min<uint32_t>(n_threads, std::max<uint32_t>(1, n_frames / 64));
     std::vector<FramePart> parts(n_frames);
+    const bool dev = p->device_tables;
     auto work = [&](uint32_t t) {
         for (uint32_t i = t; i < n_frames; i += n_threads)
-            FrameParser(blob, frame_off[i], frame_len[i], parts[i]).run();
+            FrameParser(blob, frame_off[i], frame_len[i], parts[i], dev).run();
     };
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < n_threads; t++) th.emplace_back(work, t);

@@ -235,3 +235,43 @@ def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_var
     # the context survives
     outs2, sts2 = _decode([corpus[3][1]], c)
     assert sts2 == [0]
+
+
+def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
+    """k_fse_build: every FSE table built on the device from its normalised counts is
+    cell-for-cell the table the host planner builds (fse.go:136-230), over the whole corpus plus
+    synthetic config-4 frames; and the batch decodes to the same bytes in both forms."""
+    from sparkzstd_amd import _lib
+    from tools import synth_binding as sb
+    blob, off, ln, ck, ns = sb.make_batch(4, 7, 96, threads=4)
+    frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+    ph, pd = z.Plan(), z.Plan(device_tables=True)
+    for f in frames:
+        assert ph.add_frame(f)[0] == 0 and pd.add_frame(f)[0] == 0
+    bh, bd = ph.finalize(), pd.finalize()
+    assert bh.n_fse_tables == bd.n_fse_tables
+    host = np.ctypeslib.as_array(ctypes.cast(bh.fse_entries, ctypes.POINTER(ctypes.c_uint32)), shape=(bh.n_fse_entries,)).copy()
+    rb = ctx.upload(bd)
+    try:
+        st = rb.stats()
+        n_counts = sum(1 for i in range(bd.n_fse_tables) if bd.fse_tables[i].build & _lib.MZD_FSE_FROM_COUNTS)
+        assert st.n_fse_built == n_counts and n_counts > 2000
+        for ti in range(bd.n_fse_tables):
+            dh = bh.fse_tables[ti]
+            want = host[dh.entries_off:dh.entries_off + (1 << dh.acc_log)]
+            got = rb.read_fse_table(ti)
+            assert got.shape == want.shape and (got == want).all(), (ti, dh.acc_log, dh.kind)
+        rb.run()
+        out_d, status_d, len_d = rb.download()
+    finally:
+        rb.free()
+    rb = ctx.upload(bh)
+    try:
+        rb.run()
+        out_h, status_h, len_h = rb.download()
+    finally:
+        rb.free()
+    assert (status_d == 0).all() and (status_h == 0).all() and (len_d == len_h).all()
+    assert bytes(out_d) == bytes(out_h)
+    ph.close()
+    pd.close()

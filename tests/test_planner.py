@@ -103,3 +103,36 @@ def test_handmade_raw_and_rle_frames():
     assert outs[0] == payload and outs[1] == b"\x5a" * 1000
     assert b.frames[0].content_size == n and b.frames[0].window_size == n
     p.close()
+
+
+def test_count_form_tables_describe_the_same_tables(corpus):
+    """mzd_plan_set_device_tables: every Compressed-mode FSE table is shipped as its normalised counts
+    (two int16 per cell); expanding them with a restatement of fse.go:136-230 gives exactly the cells
+    the host planner builds.  Predefined and RLE tables stay in cell form."""
+    from tests.fse_build_ref import build_cells, counts_of, host_cells
+    frames = [c[1] for c in corpus[:30]]
+    ph, pd = z.Plan(), z.Plan(device_tables=True)
+    for f in frames:
+        assert ph.add_frame(f)[0] == 0 and pd.add_frame(f)[0] == 0
+    bh, bd = ph.finalize(), pd.finalize()
+    assert bh.n_fse_tables == bd.n_fse_tables and bd.n_fse_entries < bh.n_fse_entries // 4  # counts are compact
+    n_counts = 0
+    for ti in range(bd.n_fse_tables):
+        dh, dd = bh.fse_tables[ti], bd.fse_tables[ti]
+        assert (dh.acc_log, dh.kind) == (dd.acc_log, dd.kind) and dh.build == 0
+        if dd.build & _lib.MZD_FSE_FROM_COUNTS:
+            n_counts += 1
+            counts = counts_of(bd, ti)
+            assert sum(1 if c < 0 else c for c in counts) == 1 << dd.acc_log
+            if n_counts <= 40:  # the Python build is slow; the GPU test compares every table
+                assert (build_cells(counts, dd.acc_log) == host_cells(bh, ti)).all()
+        else:
+            assert dd.build == 0 and (host_cells(bd, ti) == host_cells(bh, ti)).all()
+    assert n_counts > 50
+    # the rest of the descriptors is identical
+    for i in range(bh.n_blocks):
+        a, b = bh.blocks[i], bd.blocks[i]
+        assert (a.type, a.n_seq, a.ll_table, a.of_table, a.ml_table, a.seq_off, a.seq_size) == \
+               (b.type, b.n_seq, b.ll_table, b.of_table, b.ml_table, b.seq_off, b.seq_size)
+    ph.close()
+    pd.close()
