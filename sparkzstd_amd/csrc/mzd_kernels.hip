@@ -1397,24 +1397,31 @@ __device__ __forceinline__ void publish(uint32_t *vmap, uint32_t pos, uint32_t n
     const uint64_t m = span_mask(pos & 31, n);
     const uint32_t w = pos >> 5;
     atomicOr(&vmap[w], (uint32_t)m);
-    if ((uint32_t)(m >> 32)) atomicOr(&vmap[w + 1], (uint32_t)(m >> 32));
+    atomicOr(&vmap[w + 1], (uint32_t)(m >> 32));  // mostly zero: cheaper than the exec-mask region a test would cost
 }
 __device__ __forceinline__ uint32_t ld32u_g(const uint8_t *p) { return ((const U32U *)p)->v; }
 __device__ __forceinline__ void st32u_l(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
 
-// stores n (1..16) bytes held in w0..w3 (+ wt = bytes [n-4, n) when n >= 4) to LDS at d
+// stores n (0..16) bytes held in w0..w3 (+ wt = bytes [n-4, n) when n >= 4) to LDS at d.
+// k_exec is bound by the CU's one scalar unit, and what it executes is mostly the exec-mask
+// bookkeeping of conditional stores (s_and_saveexec / s_or / branch per `if`).  So there are TWO
+// size classes instead of a condition per dword: for n >= 4 all four dword stores are issued, the
+// ones past the end collapsing onto the tail dword (position min(4k, n-4), data selected between
+// word k and the tail word); for n < 4 three byte stores at positions 0, n/2, n-1.
 __device__ __forceinline__ void lds_store_upto16(uint8_t *d, uint32_t n, uint32_t w0, uint32_t w1, uint32_t w2,
                                                  uint32_t w3, uint32_t wt)
 {
-    if (n >= 4) st32u_l(d, w0);
-    if (n >= 8) st32u_l(d + 4, w1);
-    if (n >= 12) st32u_l(d + 8, w2);
-    if (n >= 16) st32u_l(d + 12, w3);
-    if (n >= 4 && (n & 3)) st32u_l(d + n - 4, wt);  // overlapped tail dword
-    if (n > 0 && n < 4) {
+    if (n >= 4) {
+        const uint32_t last = n - 4;
+        st32u_l(d, w0);
+        st32u_l(d + min(4u, last), last >= 4 ? w1 : wt);
+        st32u_l(d + min(8u, last), last >= 8 ? w2 : wt);
+        st32u_l(d + min(12u, last), last >= 12 ? w3 : wt);
+    } else if (n) {
+        const uint32_t h = n >> 1, e = n - 1;
         d[0] = (uint8_t)w0;
-        if (n > 1) d[1] = (uint8_t)(w0 >> 8);
-        if (n > 2) d[2] = (uint8_t)(w0 >> 16);
+        d[h] = (uint8_t)(w0 >> (8 * h));
+        d[e] = (uint8_t)(w0 >> (8 * e));
     }
 }
 
@@ -1630,18 +1637,16 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     if (__any(sLL != 0)) {
                         U128U a{rleWord, rleWord, rleWord, rleWord}, c{rleWord, rleWord, rleWord, rleWord};
                         uint32_t wt = rleWord;
-                        if (!litRle && sLL) {
-                            a = *(const U128U *)(lits + srcL);
-                            if (sLL > 16) c = *(const U128U *)(lits + srcL + 16);
-                            if (sLL >= 4) wt = ld32u_g(lits + srcL + sLL - 4);
-                        }
+                        const bool two = __any(sLL > 16);  // wave-uniform: a second 16-byte half exists somewhere
                         if (sLL) {
-                            uint8_t *d = lbuf + dstL;
-                            if (sLL <= 16) lds_store_upto16(d, sLL, a.x, a.y, a.z, a.w, wt);
-                            else {
-                                lds_store_upto16(d, 16, a.x, a.y, a.z, a.w, 0);
-                                lds_store_upto16(d + 16, sLL - 16, c.x, c.y, c.z, c.w, wt);
+                            if (!litRle) {
+                                a = *(const U128U *)(lits + srcL);
+                                if (two) c = *(const U128U *)(lits + srcL + (sLL > 16 ? 16 : 0));
+                                wt = ld32u_g(lits + srcL + (sLL >= 4 ? sLL - 4 : 0));
                             }
+                            uint8_t *d = lbuf + dstL;
+                            lds_store_upto16(d, min(sLL, 16u), a.x, a.y, a.z, a.w, wt);
+                            if (two) lds_store_upto16(d + 16, sLL > 16 ? sLL - 16 : 0, c.x, c.y, c.z, c.w, wt);
                             publish(vmap, dstL, sLL);
                         }
                     }
@@ -1673,18 +1678,14 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         const uint8_t *sp = bout + (int)chunkStart + srcM;  // may point into earlier blocks
                         U128U a{0, 0, 0, 0}, c{0, 0, 0, 0};
                         uint32_t wt = 0;
+                        const bool two = __any(g && ML > 16);
                         if (g) {
                             a = *(const U128U *)sp;
-                            if (ML > 16) c = *(const U128U *)(sp + 16);
-                            if (ML >= 4) wt = ld32u_g(sp + ML - 4);
-                        }
-                        if (g) {
+                            if (two) c = *(const U128U *)(sp + (ML > 16 ? 16 : 0));
+                            wt = ld32u_g(sp + (ML >= 4 ? ML - 4 : 0));
                             uint8_t *d = lbuf + dstM;
-                            if (ML <= 16) lds_store_upto16(d, ML, a.x, a.y, a.z, a.w, wt);
-                            else {
-                                lds_store_upto16(d, 16, a.x, a.y, a.z, a.w, 0);
-                                lds_store_upto16(d + 16, ML - 16, c.x, c.y, c.z, c.w, wt);
-                            }
+                            lds_store_upto16(d, min(ML, 16u), a.x, a.y, a.z, a.w, wt);
+                            if (two) lds_store_upto16(d + 16, ML > 16 ? ML - 16 : 0, c.x, c.y, c.z, c.w, wt);
                             publish(vmap, dstM, ML);
                         }
                         pending = pending && !g;
@@ -1717,30 +1718,30 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         progressed = true;
                         // wave-uniform bound on the dword loop from two ballots (a shuffle reduction costs ~450 cycles)
                         const uint32_t mlc = __any(fast && ML > 16) ? 32u : (__any(fast && ML > 8) ? 16u : 8u);
-                        const uint32_t sbyte = fast ? (mis + (uint32_t)srcM) : 0;
-                        const uint32_t sa = sbyte & 3;
-                        const uint32_t *base = (const uint32_t *)(buf + (sbyte & ~3u));
-                        uint8_t *d = lbuf + dstM;
-                        uint32_t prev = fast ? base[0] : 0;
-                        uint32_t first = 0;
-                        for (uint32_t j = 0; 4 * j < mlc; j++) {
-                            const bool on = fast && 4 * j < ML;
-                            const uint32_t nxt = on ? base[j + 1] : 0;
-                            const uint32_t x = __builtin_amdgcn_alignbyte(nxt, prev, sa);
-                            if (j == 0) first = x;
-                            if (fast && 4 * j + 4 <= ML) st32u_l(d + 4 * j, x);
-                            prev = nxt;
-                        }
                         if (fast) {
-                            if (ML >= 4 && (ML & 3)) {
-                                const uint32_t tb_byte = sbyte + ML - 4;  // tail dword = source bytes [ML-4, ML)
-                                const uint32_t *tp = (const uint32_t *)(buf + (tb_byte & ~3u));
-                                st32u_l(d + ML - 4, __builtin_amdgcn_alignbyte(tp[1], tp[0], tb_byte & 3));
-                            }
-                            if (ML < 4) {
-                                if (ML > 0) d[0] = (uint8_t)first;
-                                if (ML > 1) d[1] = (uint8_t)(first >> 8);
-                                if (ML > 2) d[2] = (uint8_t)(first >> 16);
+                            // one exec region for the whole copy; inside, the two size classes of lds_store_upto16
+                            const uint32_t sbyte = mis + (uint32_t)srcM;
+                            const uint32_t sa = sbyte & 3;
+                            const uint32_t *base = (const uint32_t *)(buf + (sbyte & ~3u));
+                            uint8_t *d = lbuf + dstM;
+                            const uint32_t tb_byte = sbyte + (ML >= 4 ? ML - 4 : 0);  // tail dword = source bytes [ML-4, ML)
+                            const uint32_t *tp = (const uint32_t *)(buf + (tb_byte & ~3u));
+                            const uint32_t xt = __builtin_amdgcn_alignbyte(tp[1], tp[0], tb_byte & 3);
+                            uint32_t prev = base[0];
+                            if (ML >= 4) {
+                                const uint32_t last = ML - 4;
+                                for (uint32_t j = 0; 4 * j < mlc; j++) {
+                                    const uint32_t nxt = base[j + 1];  // past the source: unused (and inside the buffer's slack)
+                                    const uint32_t x = __builtin_amdgcn_alignbyte(nxt, prev, sa);
+                                    st32u_l(d + min(4 * j, last), 4 * j <= last ? x : xt);
+                                    prev = nxt;
+                                }
+                            } else {
+                                const uint32_t first = __builtin_amdgcn_alignbyte(base[1], prev, sa);
+                                const uint32_t h = ML >> 1, e = ML - 1;
+                                d[0] = (uint8_t)first;
+                                d[h] = (uint8_t)(first >> (8 * h));
+                                d[e] = (uint8_t)(first >> (8 * e));
                             }
                             publish(vmap, dstM, ML);
                         }
