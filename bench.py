@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
     ap.add_argument("--seq-variant", type=int, default=0)
-    ap.add_argument("--host-tables", action="store_true", help="build the FSE tables in the host planner instead of on the device")
+    ap.add_argument("--host-tables", action="store_true", help="build the FSE / Huffman decode tables in the host planner instead of on the device")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--exec-chunk", type=int, default=0)
     ap.add_argument("--huf-min-lds", type=int, default=0)
@@ -304,8 +304,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok,
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 3), "upload": round(t_upload, 3),
-                        "fse_tables": "host" if a.host_tables else "device",
+                        "tables": "host" if a.host_tables else "device",
                         "fse_tables_built_on_device": int(stats.n_fse_built),
+                        "huf_tables_built_on_device": int(stats.n_huf_built),
                         "k_fse_build_ms": round(float(stats.fse_build_ms), 3)},
         }
         print(json.dumps(line), flush=True)

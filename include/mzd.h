@@ -141,9 +141,15 @@ typedef struct mzd_huf_entry {
     uint8_t nbits;
 } mzd_huf_entry;
 
+/* Like the FSE tables, a Huffman table arrives either BUILT (1 << max_bits cells) or as its WEIGHTS
+ * (max_bits field = MZD_HUF_FROM_WEIGHTS | n_weights << 8 | max_bits): then it occupies
+ * (n_weights + 1) / 2 cells of huf_entries[], cell i = {symbol: weight[2i], nbits: weight[2i+1]}
+ * (huffman.go:40-107 decoded weights, the last symbol's weight NOT included: huffman.go:126-131
+ * infers it), and the library fills the decode table on the device (huffman.go:112-190). */
+#define MZD_HUF_FROM_WEIGHTS 0x80000000u
 typedef struct mzd_huf_table_desc {
     uint32_t entries_off;  /* first cell in huf_entries[]; even */
-    uint32_t max_bits;     /* 1..11 */
+    uint32_t max_bits;     /* 1..11 [| MZD_HUF_FROM_WEIGHTS | n_weights << 8] */
 } mzd_huf_table_desc;
 
 #define MZD_IN_PAD 64 /* readable slack required before and after `in` when it is a device pointer */
@@ -247,6 +253,7 @@ typedef struct mzd_batch_stats {
     uint64_t n_huf_streams;
     uint64_t n_blocks[3];         /* raw, rle, compressed */
     uint64_t n_fse_built;         /* FSE tables built on the device from their counts (MZD_FSE_FROM_COUNTS) */
+    uint64_t n_huf_built;         /* Huffman tables filled on the device from their weights (MZD_HUF_FROM_WEIGHTS) */
     double fse_build_ms;          /* duration of that build (k_fse_build, once per upload) */
 } mzd_batch_stats;
 int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st);
@@ -254,6 +261,8 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st);
  * back to the host; returns the number of cells or -MZD_ERR_*.  Lets tests compare device-built
  * tables with the host planner's, cell by cell. */
 int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_fse_entry *out, uint32_t cap);
+/* the same for Huffman decode table `table` (1 << max_bits cells) */
+int mzd_batch_read_huf_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_huf_entry *out, uint32_t cap);
 
 /* ------------------------------------------------------------------ host planner
  * C++ restatement of the reference's host side, exposed in C so that tests, the
@@ -266,9 +275,9 @@ int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_f
  *   FSE tables          fse/fse.go:28-230, fse/predefined.go
  *   table carry-over    framedecompressor.go:283-294 (Repeat / Treeless) */
 mzd_plan *mzd_plan_create(void);
-/* on != 0: FSE tables are emitted as normalised counts and built on the device at upload
- * (MZD_FSE_FROM_COUNTS); default off: the planner builds the cells on the host.  Survives
- * mzd_plan_reset. */
+/* on != 0: FSE tables are emitted as normalised counts and Huffman tables as weights, and the
+ * decode tables are built on the device at upload (MZD_FSE_FROM_COUNTS, MZD_HUF_FROM_WEIGHTS);
+ * default off: the planner builds the cells on the host.  Survives mzd_plan_reset. */
 void mzd_plan_set_device_tables(mzd_plan *p, int on);
 void mzd_plan_destroy(mzd_plan *p);
 void mzd_plan_reset(mzd_plan *p);

@@ -21,7 +21,7 @@ EXPORTS = [
     "mzd_batch_device_out", "mzd_batch_device_status", "mzd_batch_device_out_len", "mzd_batch_free",
     "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_timing_reset", "mzd_batch_get_stats", "mzd_plan_create",
     "mzd_plan_destroy", "mzd_plan_reset", "mzd_plan_add_frame", "mzd_plan_add_frames",
-    "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table",
+    "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table", "mzd_batch_read_huf_table",
 ]
 
 
@@ -51,6 +51,7 @@ class FseTableDesc(ctypes.Structure):
 
 
 MZD_FSE_FROM_COUNTS = 0x8000
+MZD_HUF_FROM_WEIGHTS = 0x80000000
 
 
 class HufEntry(ctypes.Structure):
@@ -83,7 +84,8 @@ class BatchStats(ctypes.Structure):
     _fields_ = [("compressed_bytes", ctypes.c_uint64), ("table_bytes", ctypes.c_uint64),
                 ("scratch_bytes", ctypes.c_uint64), ("out_capacity_bytes", ctypes.c_uint64),
                 ("n_sequences", ctypes.c_uint64), ("n_huf_streams", ctypes.c_uint64),
-                ("n_blocks", ctypes.c_uint64 * 3), ("n_fse_built", ctypes.c_uint64), ("fse_build_ms", ctypes.c_double)]
+                ("n_blocks", ctypes.c_uint64 * 3), ("n_fse_built", ctypes.c_uint64), ("n_huf_built", ctypes.c_uint64),
+                ("fse_build_ms", ctypes.c_double)]
 
 
 _lib = None
@@ -123,6 +125,7 @@ def load():
         "mzd_plan_create": (vp, []),
         "mzd_plan_set_device_tables": (None, [vp, i32]),
         "mzd_batch_read_fse_table": (i32, [vp, vp, u32, vp, u32]),
+        "mzd_batch_read_huf_table": (i32, [vp, vp, u32, vp, u32]),
         "mzd_plan_destroy": (None, [vp]),
         "mzd_plan_reset": (None, [vp]),
         "mzd_plan_add_frame": (i32, [vp, vp, u64, ctypes.POINTER(u64)]),

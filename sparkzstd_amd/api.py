@@ -25,8 +25,8 @@ class Plan:
     sequences.go:228-450, huffman.go:40-190, fse.go:28-230)."""
 
     def __init__(self, device_tables: bool = False):
-        """device_tables: emit FSE tables as normalised counts; the library builds them on the device
-        at upload (mzd_plan_set_device_tables)."""
+        """device_tables: emit FSE tables as normalised counts and Huffman tables as weights; the library
+        builds the decode tables on the device at upload (mzd_plan_set_device_tables)."""
         self._L = _lib.load()
         self._p = self._L.mzd_plan_create()
         if device_tables:
@@ -102,6 +102,14 @@ class ResidentBatch:
         n = self.ctx._L.mzd_batch_read_fse_table(self.ctx._c, self._h, table, out.ctypes.data, 512)
         if n < 0:
             raise MzdError(-n, "mzd_batch_read_fse_table: " + self.ctx.last_error())
+        return out[:n].copy()
+
+    def read_huf_table(self, table: int) -> np.ndarray:
+        """Device Huffman decode table `table` as uint16 cells (symbol | nbits << 8)."""
+        out = np.empty(2048, dtype=np.uint16)
+        n = self.ctx._L.mzd_batch_read_huf_table(self.ctx._c, self._h, table, out.ctypes.data, 2048)
+        if n < 0:
+            raise MzdError(-n, "mzd_batch_read_huf_table: " + self.ctx.last_error())
         return out[:n].copy()
 
     def device_out_ptr(self):

@@ -48,6 +48,8 @@ struct mzd_dbatch {
     uint32_t *d_fse_entries = nullptr;
     uint32_t n_fse_entries = 0, n_fse_built = 0;  // device cells; tables built from counts
     std::vector<uint32_t> fse_dev_off;             // first device cell of every table (+ total)
+    std::vector<uint32_t> huf_dev_off;
+    uint32_t n_huf_built = 0;
     float fse_build_ms = 0;  // k_fse_build at upload (tables that came as normalised counts)
     uint16_t *d_huf_entries = nullptr;
     uint64_t *d_recs = nullptr;
@@ -265,22 +267,52 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         }
     }
     uint32_t max_huf_bits = 1;
-    for (uint32_t i = 0; i < b->n_huf_tables; i++) {
-        const mzd_huf_table_desc &d = b->huf_tables[i];
-        if (d.max_bits < 1 || d.max_bits > 11 || (d.entries_off & 1) ||
-            (uint64_t)d.entries_off + (1ull << d.max_bits) > b->n_huf_entries) {
-            huf_ok[i] = 0;
-            continue;
-        }
-        const uint32_t n = 1u << d.max_bits;
-        for (uint32_t j = 0; j < n; j++) {
-            const mzd_huf_entry &e = b->huf_entries[d.entries_off + j];
-            if (e.nbits < 1 || e.nbits > d.max_bits) {
+    // device layout of the Huffman decode tables: 1 << max_bits cells each, whatever form they arrived in
+    std::vector<uint32_t> huf_dev_off(b->n_huf_tables + 1, 0);
+    std::vector<uint8_t> huf_bits(b->n_huf_tables, 1);
+    {
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < b->n_huf_tables; i++) {
+            const mzd_huf_table_desc &d = b->huf_tables[i];
+            const bool from_w = (d.max_bits & MZD_HUF_FROM_WEIGHTS) != 0;
+            const uint32_t mb = d.max_bits & 0xFF, nw = from_w ? (d.max_bits >> 8) & 0xFFFF : 0;
+            huf_dev_off[i] = (uint32_t)at;
+            if (mb < 1 || mb > 11 || (d.entries_off & 1) || (!from_w && (d.max_bits >> 8)) || (from_w && (nw < 1 || nw > 255)) ||
+                (uint64_t)d.entries_off + (from_w ? (nw + 1) / 2 : (1ull << mb)) > b->n_huf_entries) {
                 huf_ok[i] = 0;
-                break;
+                at += 2;
+                continue;
             }
+            huf_bits[i] = (uint8_t)mb;
+            at += 1ull << mb;
+            if (from_w) {
+                // huffman.go:112-131: the weights determine MaxBits and leave a power of two for the last symbol
+                uint32_t sum = 0;
+                for (uint32_t j = 0; j < nw; j++) {
+                    const mzd_huf_entry &e = b->huf_entries[d.entries_off + (j >> 1)];
+                    const uint32_t w = (j & 1) ? e.nbits : e.symbol;
+                    if (w > 11) huf_ok[i] = 0;
+                    else if (w) sum += 1u << (w - 1);
+                }
+                const uint32_t left = (1u << mb) - sum;
+                if (!huf_ok[i] || sum == 0 || sum >= (1u << mb) || (sum >> (mb - 1)) == 0 || (left & (left - 1))) huf_ok[i] = 0;
+            } else {
+                const uint32_t n = 1u << mb;
+                for (uint32_t j = 0; j < n; j++) {
+                    const mzd_huf_entry &e = b->huf_entries[d.entries_off + j];
+                    if (e.nbits < 1 || e.nbits > mb) {
+                        huf_ok[i] = 0;
+                        break;
+                    }
+                }
+            }
+            if (huf_ok[i]) max_huf_bits = std::max(max_huf_bits, mb);
         }
-        if (huf_ok[i]) max_huf_bits = std::max(max_huf_bits, d.max_bits);
+        if (at > 0xFFFFFFFFull) {
+            ctx->last_error = "more than 2^32 Huffman table cells";
+            return MZD_ERR_INVALID_ARG;
+        }
+        huf_dev_off[b->n_huf_tables] = (uint32_t)at;
     }
 
     // ---- derive the device work lists
@@ -342,7 +374,6 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
             } else if (bd.lit_type == MZD_LIT_HUF) {
                 if (bd.huf_table >= b->n_huf_tables) { df.plan_status = MZD_ERR_NO_PREV_TABLE; break; }
                 if (!huf_ok[bd.huf_table]) { df.plan_status = MZD_ERR_HUF_WEIGHTS; break; }
-                const mzd_huf_table_desc &ht = b->huf_tables[bd.huf_table];
                 const int ns = bd.lit_streams == 4 ? 4 : 1;
                 uint64_t csum = 0;
                 for (int s = 0; s < ns; s++) csum += bd.lit_stream_size[s];
@@ -361,8 +392,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                         ioff += t.in_size;
                         st.n_huf_streams++;
                     }
-                    t.table_off = ht.entries_off;
-                    t.max_bits = ht.max_bits;
+                    t.table_off = huf_dev_off[bd.huf_table];
+                    t.max_bits = huf_bits[bd.huf_table];
                     t.block = bi;
                     huf_tasks.push_back(t);
                 }
@@ -512,9 +543,40 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
             }
         }
     }
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_entries, std::max<size_t>(b->n_huf_entries, 2) * 2 + 8));
-    if (b->n_huf_entries)
-        HIP_OR_FAIL(hipMemcpy(db->d_huf_entries, b->huf_entries, (size_t)b->n_huf_entries * 2, hipMemcpyHostToDevice));
+    // ---- Huffman tables: same scheme (k_huf_build copies built tables, fills the ones that came as weights)
+    {
+        const uint32_t n_dev_cells = huf_dev_off[b->n_huf_tables];
+        HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_entries, std::max<size_t>(n_dev_cells, 2) * 2 + 8));
+        db->huf_dev_off = huf_dev_off;
+        if (b->n_huf_tables) {
+            std::vector<HufBuildDesc> tabs(b->n_huf_tables);
+            for (uint32_t i = 0; i < b->n_huf_tables; i++) {
+                const mzd_huf_table_desc &d = b->huf_tables[i];
+                tabs[i].src_off = d.entries_off;
+                tabs[i].dst_off = huf_dev_off[i];
+                tabs[i].max_bits = huf_bits[i];
+                tabs[i].n_weights = (uint8_t)((d.max_bits & MZD_HUF_FROM_WEIGHTS) ? (d.max_bits >> 8) & 0xFF : 0);
+                tabs[i].ok = huf_ok[i];
+                if (tabs[i].ok && tabs[i].n_weights) db->n_huf_built++;
+            }
+            HufBuildDesc *d_tabs = nullptr;
+            uint16_t *d_src = nullptr;
+            HIP_OR_FAIL(hipMalloc((void **)&d_tabs, tabs.size() * sizeof(HufBuildDesc)));
+            hipError_t e0 = hipMalloc((void **)&d_src, std::max<size_t>(b->n_huf_entries, 2) * 2);
+            hipError_t e1 = e0 != hipSuccess ? e0 : hipMemcpy(d_tabs, tabs.data(), tabs.size() * sizeof(HufBuildDesc), hipMemcpyHostToDevice);
+            if (e1 == hipSuccess && b->n_huf_entries)
+                e1 = hipMemcpy(d_src, b->huf_entries, (size_t)b->n_huf_entries * 2, hipMemcpyHostToDevice);
+            if (e1 == hipSuccess)
+                k_huf_build<<<(b->n_huf_tables + 63) / 64, 64, 0, ctx->stream>>>(d_tabs, b->n_huf_tables, d_src, db->d_huf_entries);
+            hipError_t e2 = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(d_tabs);
+            (void)hipFree(d_src);
+            if (e1 != hipSuccess || e2 != hipSuccess) {
+                ctx->last_error = std::string("k_huf_build failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+                return fail(MZD_ERR_DEVICE);
+            }
+        }
+    }
     HIP_OR_FAIL(hipMalloc((void **)&db->d_recs, std::max<uint64_t>(rec_total, 1) * 8));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_tiles, std::max<uint64_t>(tile_total, 1) * sizeof(TileBase)));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
@@ -682,6 +744,16 @@ int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_f
     return (int)n;
 }
 
+int mzd_batch_read_huf_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_huf_entry *out, uint32_t cap)
+{
+    if (!ctx || !db || !out || (size_t)table + 1 >= db->huf_dev_off.size()) return -MZD_ERR_INVALID_ARG;
+    const uint32_t first = db->huf_dev_off[table], n = db->huf_dev_off[table + 1] - first;
+    if (n > cap) return -MZD_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -MZD_ERR_DEVICE;
+    if (n && hipMemcpy(out, db->d_huf_entries + first, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MZD_ERR_DEVICE;
+    return (int)n;
+}
+
 int mzd_sync(mzd_ctx *ctx)
 {
     if (!ctx) return MZD_ERR_INVALID_ARG;
@@ -771,6 +843,7 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
     if (!db || !st) return MZD_ERR_INVALID_ARG;
     *st = db->stats;
     st->n_fse_built = db->n_fse_built;
+    st->n_huf_built = db->n_huf_built;
     st->fse_build_ms = db->fse_build_ms;
     return MZD_OK;
 }

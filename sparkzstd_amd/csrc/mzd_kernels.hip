@@ -214,6 +214,57 @@ __global__ __launch_bounds__(64) void k_fse_build(const FseBuildDesc *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// k_huf_build: Huffman decode tables from their weights, on the device (replaces the table fill
+// of structure/huffman.go:112-190 for tables that arrive as MZD_HUF_FROM_WEIGHTS; the weight
+// decode itself, huffman.go:40-107 / fse.go:307-390, is a serial two-state stream and stays with
+// the host's header parse).  Once per batch at upload, one LANE per table.
+__global__ __launch_bounds__(64) void k_huf_build(const HufBuildDesc *__restrict__ tabs, uint32_t n_tabs,
+                                                  const uint16_t *__restrict__ src, uint16_t *__restrict__ cells)
+{
+    __shared__ uint8_t len[256][64];  // symbol -> code length (0: absent)
+    const int lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64 + lane;
+    if (t >= n_tabs) return;
+    const HufBuildDesc d = tabs[t];
+    const int mb = d.ok ? d.max_bits : 1, size = 1 << mb;
+    uint16_t *c = cells + d.dst_off;
+    if (!d.ok) {  // rejected at upload: blocks that use it carry a status
+        c[0] = 0; c[1] = 0;
+        return;
+    }
+    if (d.n_weights == 0) {  // arrived built: copy
+        for (int i = 0; i < size; i++) c[i] = src[d.src_off + i];
+        return;
+    }
+    // code length = MaxBits + 1 - weight; the last symbol gets what is left of 2^MaxBits (huffman.go:125-131)
+    const int nw = d.n_weights;
+    uint32_t sum = 0;
+    for (int s = 0; s < nw; s += 2) {
+        const uint32_t e = src[d.src_off + (s >> 1)];  // symbol byte (even weight) | nbits byte (odd weight) << 8
+        const uint32_t w0 = e & 0xFF, w1 = e >> 8;
+        len[s][lane] = w0 ? (uint8_t)(mb + 1 - w0) : 0;
+        if (w0) sum += 1u << (w0 - 1);
+        if (s + 1 < nw) {
+            len[s + 1][lane] = w1 ? (uint8_t)(mb + 1 - w1) : 0;
+            if (w1) sum += 1u << (w1 - 1);
+        }
+    }
+    const uint32_t left = (1u << mb) - sum;  // a power of two (checked at upload)
+    len[nw][lane] = (uint8_t)(mb + 1 - (32 - __builtin_clz(left | 1)));
+    // longest codes first from cell 0, ascending symbol inside a length (huffman.go:163-187)
+    int at = 0;
+    for (int l = mb; l >= 1; l--) {
+        const int span = 1 << (mb - l);
+        for (int s = 0; s <= nw; s++) {
+            if (len[s][lane] != l) continue;
+            const uint16_t cell = (uint16_t)(s | (l << 8));  // {symbol, nbits}
+            for (int j = 0; j < span && at + j < size; j++) c[at + j] = cell;
+            at += span;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_huf: Huffman literal streams.  One wavefront per workgroup; lane = stream; 16 table slots.
 //
 // Restates huffman.go:221-264: after the padding marker the stream holds R data bits; each

@@ -215,8 +215,8 @@ int read_huffman_weights(const uint8_t *src, uint64_t len, std::vector<uint8_t> 
     return 1 + header;
 }
 
-// huffman.go:112-190
-int build_huffman_cells(const std::vector<uint8_t> &w, std::vector<mzd_huf_entry> &cells, int &max_bits)
+// huffman.go:112-131: MaxBits from the weights; the checks that make the fill of :163-187 succeed
+int huffman_max_bits(const std::vector<uint8_t> &w, int &max_bits)
 {
     uint32_t sum = 0;
     for (uint8_t x : w) {
@@ -228,6 +228,18 @@ int build_huffman_cells(const std::vector<uint8_t> &w, std::vector<mzd_huf_entry
     const uint32_t left = (1u << max_bits) - sum;
     if (left & (left - 1)) return MZD_ERR_HUF_WEIGHTS;  // huffman.go:128-130
     if (max_bits > 11) return MZD_ERR_UNSUPPORTED;      // format limit; device table slot is 2048 cells
+    return MZD_OK;
+}
+
+// huffman.go:112-190
+int build_huffman_cells(const std::vector<uint8_t> &w, std::vector<mzd_huf_entry> &cells, int &max_bits)
+{
+    int rc0 = huffman_max_bits(w, max_bits);
+    if (rc0) return rc0;
+    uint32_t sum = 0;
+    for (uint8_t x : w)
+        if (x) sum += 1u << (x - 1);
+    const uint32_t left = (1u << max_bits) - sum;
     std::vector<uint8_t> len(w.size() + 1);
     for (size_t i = 0; i < w.size(); i++) len[i] = w[i] ? (uint8_t)(max_bits + 1 - w[i]) : 0;
     len[w.size()] = (uint8_t)(max_bits + 1 - (highbit(left) + 1));
@@ -389,10 +401,24 @@ struct FrameParser {
                 if (used < 0) return -used;
                 std::vector<mzd_huf_entry> cells;
                 int mb = 0;
-                int rc = build_huffman_cells(w, cells, mb);
-                if (rc) return rc;
+                uint32_t form = 0;
+                if (device_tables) {
+                    // weights only (two per cell slot); huffman_max_bits has made the checks under which the
+                    // table fill of huffman.go:163-187 cannot fail
+                    int rc = huffman_max_bits(w, mb);
+                    if (rc) return rc;
+                    cells.assign((w.size() + 1) / 2, mzd_huf_entry{0, 0});
+                    for (size_t i = 0; i < w.size(); i++) {
+                        if (i & 1) cells[i >> 1].nbits = w[i];
+                        else cells[i >> 1].symbol = w[i];
+                    }
+                    form = MZD_HUF_FROM_WEIGHTS | ((uint32_t)w.size() << 8);
+                } else {
+                    int rc = build_huffman_cells(w, cells, mb);
+                    if (rc) return rc;
+                }
                 if (out.huf_entries.size() & 1) out.huf_entries.push_back(mzd_huf_entry{0, 0});
-                mzd_huf_table_desc d{(uint32_t)out.huf_entries.size(), (uint32_t)mb};
+                mzd_huf_table_desc d{(uint32_t)out.huf_entries.size(), (uint32_t)mb | form};
                 out.huf_entries.insert(out.huf_entries.end(), cells.begin(), cells.end());
                 out.huf_tables.push_back(d);
                 prev_huf = (uint32_t)out.huf_tables.size() - 1;

@@ -238,13 +238,16 @@ def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_var
 
 
 def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
-    """k_fse_build: every FSE table built on the device from its normalised counts is
-    cell-for-cell the table the host planner builds (fse.go:136-230), over the whole corpus plus
-    synthetic config-4 frames; and the batch decodes to the same bytes in both forms."""
+    """k_fse_build / k_huf_build: every FSE table built on the device from its normalised
+    counts and every Huffman table filled from its weights is cell-for-cell the table the host planner
+    builds (fse.go:136-230, huffman.go:112-190), over the whole corpus plus synthetic config-3/4
+    frames; and the batch decodes to the same bytes in both forms."""
     from sparkzstd_amd import _lib
     from tools import synth_binding as sb
     blob, off, ln, ck, ns = sb.make_batch(4, 7, 96, threads=4)
-    frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+    blob3, off3, ln3, _, _ = sb.make_batch(3, 11, 32, threads=4)  # MaxBits 11 Huffman tables
+    frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)] + \
+             [bytes(blob3[o:o + l]) for o, l in zip(off3, ln3)]
     ph, pd = z.Plan(), z.Plan(device_tables=True)
     for f in frames:
         assert ph.add_frame(f)[0] == 0 and pd.add_frame(f)[0] == 0
@@ -261,6 +264,15 @@ def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
             want = host[dh.entries_off:dh.entries_off + (1 << dh.acc_log)]
             got = rb.read_fse_table(ti)
             assert got.shape == want.shape and (got == want).all(), (ti, dh.acc_log, dh.kind)
+        # the same for the Huffman decode tables filled from their weights (k_huf_build, huffman.go:112-190)
+        hufh = np.ctypeslib.as_array(ctypes.cast(bh.huf_entries, ctypes.POINTER(ctypes.c_uint16)), shape=(bh.n_huf_entries,)).copy()
+        assert bd.n_huf_tables == bh.n_huf_tables and st.n_huf_built == bd.n_huf_tables > 1000
+        for ti in range(bd.n_huf_tables):
+            dh, dd = bh.huf_tables[ti], bd.huf_tables[ti]
+            assert dd.max_bits & _lib.MZD_HUF_FROM_WEIGHTS and (dd.max_bits & 0xFF) == dh.max_bits
+            want = hufh[dh.entries_off:dh.entries_off + (1 << dh.max_bits)]
+            got = rb.read_huf_table(ti)
+            assert got.shape == want.shape and (got == want).all(), (ti, dh.max_bits)
         rb.run()
         out_d, status_d, len_d = rb.download()
     finally:

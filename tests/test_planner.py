@@ -129,6 +129,26 @@ def test_count_form_tables_describe_the_same_tables(corpus):
         else:
             assert dd.build == 0 and (host_cells(bd, ti) == host_cells(bh, ti)).all()
     assert n_counts > 50
+    # Huffman tables: weight form, same MaxBits, compact
+    assert bd.n_huf_tables == bh.n_huf_tables > 20 and bd.n_huf_entries < bh.n_huf_entries
+    for ti in range(bd.n_huf_tables):
+        dh, dd = bh.huf_tables[ti], bd.huf_tables[ti]
+        assert dd.max_bits & _lib.MZD_HUF_FROM_WEIGHTS and (dd.max_bits & 0xFF) == dh.max_bits
+        nw = (dd.max_bits >> 8) & 0xFFFF
+        ws = []
+        for j in range(nw):
+            e = bd.huf_entries[dd.entries_off + (j >> 1)]
+            ws.append(e.nbits if j & 1 else e.symbol)
+        s_ = sum(1 << (w - 1) for w in ws if w)
+        left = (1 << dh.max_bits) - s_
+        assert s_.bit_length() == dh.max_bits and left > 0 and left & (left - 1) == 0
+        # every symbol's code length in the host-built table is MaxBits + 1 - weight
+        lens = {}
+        for j in range(1 << dh.max_bits):
+            e = bh.huf_entries[dh.entries_off + j]
+            lens[e.symbol] = e.nbits
+        for sym, w in enumerate(ws):
+            assert (lens.get(sym, 0) == dh.max_bits + 1 - w) if w else sym not in lens
     # the rest of the descriptors is identical
     for i in range(bh.n_blocks):
         a, b = bh.blocks[i], bd.blocks[i]
