@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
     ap.add_argument("--seq-variant", type=int, default=0)
+    ap.add_argument("--verify-checksum", action="store_true", help="frames carry the zstd content checksum and the device verifies it after the pass (k_xxh64; an extension, off by default like in the reference)")
     ap.add_argument("--host-tables", action="store_true", help="build the FSE / Huffman decode tables in the host planner instead of on the device")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--exec-chunk", type=int, default=0)
@@ -172,6 +173,7 @@ def main():
     t0 = time.perf_counter()
     gen_threads = a.gen_threads or max(1, usable_cores()[0] // max(1, world))
     # calibrate, then generate as many DISTINCT frames as the time budget allows (normally all of them)
+    sb.set_content_checksum(a.verify_checksum)
     calib = min(per, 8 * gen_threads)
     tc = time.perf_counter()
     sb.make_batch(a.config, first, calib, frame_bytes, threads=gen_threads)
@@ -204,7 +206,8 @@ def main():
     d_in = torch.zeros(blob.size + 2 * pad, dtype=torch.uint8, device="cuda")
     d_in[pad:pad + blob.size].copy_(torch.from_numpy(blob))
     d_out = torch.zeros(batch.out_size, dtype=torch.uint8, device="cuda")
-    ctx = z.Context(local_rank, seq_variant=a.seq_variant, exec_threads=a.exec_threads, exec_chunk=a.exec_chunk, huf_min_lds=a.huf_min_lds, no_split=a.no_split)
+    ctx = z.Context(local_rank, seq_variant=a.seq_variant, exec_threads=a.exec_threads, exec_chunk=a.exec_chunk, huf_min_lds=a.huf_min_lds, no_split=a.no_split,
+                    verify_checksum=a.verify_checksum)
     rb = ctx.upload(batch, device_in_ptr=d_in.data_ptr() + pad, device_out_ptr=d_out.data_ptr())
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t0
@@ -264,6 +267,7 @@ def main():
         c_bytes = int(stats.compressed_bytes)
         alg = c_bytes + per * frame_bytes
         path_ms = kms.pop("path", None) or sum(v for k, v in kms.items() if v > 0)
+        xxh_ms = kms.pop("k_xxh64", None)  # optional extension, reported on its own below
         dom = max(kms, key=lambda k: kms[k]) if kms else None
         achieved = alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else None
         # HBM traffic per launch from the committed PMC passes (profiles/r1_traffic.json): sum over the
@@ -285,6 +289,10 @@ def main():
                 "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
                 "algorithmic_bytes_per_launch": alg,
                 "dominant_kernel_alone_GBs": round(alg / (kms[dom] * 1e-3) / 1e9, 1) if dom else None}
+        if xxh_ms:
+            # k_xxh64 streams the regenerated bytes once: its own HBM roofline (D bytes / its time)
+            roof["k_xxh64"] = {"ms": round(xxh_ms, 4), "achieved_GBs": round(per * frame_bytes / (xxh_ms * 1e-3) / 1e9, 1),
+                               "frac": round(per * frame_bytes / (xxh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         cpu = None
         if a.cpu_seconds > 0:
             cpu = cpu_baseline(blob, off, ln, frame_bytes, a.cpu_seconds)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 1
+#define MZD_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -62,6 +62,8 @@ enum {
     MZD_ERR_DST_FULL = 15,        /* frame output exceeds out_capacity / content size mismatch */
     MZD_ERR_UNSUPPORTED = 16,     /* outside the device path's documented limits */
     MZD_ERR_OUT_OF_BLOCKS = 17,   /* framedecompressor.go:196 ErrOutOfBlocks (host mirror only) */
+    MZD_ERR_CHECKSUM = 18,        /* content checksum mismatch; only with mzd_options.verify_checksum -- the
+                                     reference never reads the checksum (framereader.go:84-94, Readme.md:62) */
     MZD_ERR_DEVICE = 100,         /* HIP runtime error; see mzd_last_error() */
     MZD_ERR_INVALID_ARG = 101,
     MZD_ERR_NO_DEVICE = 102       /* no HIP device: the product has NO CPU fallback */
@@ -86,7 +88,10 @@ typedef struct mzd_frame_desc {
     uint64_t out_capacity;  /* bytes available at out_offset */
     uint64_t content_size;  /* Frame_Content_Size, or MZD_UNKNOWN_SIZE (frame.go:49-61) */
     uint64_t window_size;   /* frame.go:28-36 / framedecompressor.go:358-360; informational + limit check */
+    uint32_t checksum;      /* the 4 bytes after the last block (low half of XXH64(content, 0)) when flags say so */
+    uint32_t flags;         /* MZD_FRAME_* */
 } mzd_frame_desc;
+#define MZD_FRAME_HAS_CHECKSUM 1u /* Content_Checksum_flag set (frame.go:106-108) and the 4 bytes were there */
 
 /* One block (block.go:22-26 BlockHeader + the slices the reference's section
  * parsers produce: literals.go:30-41,283-361, sequences.go:371-433). Offsets are
@@ -202,7 +207,10 @@ typedef struct mzd_options {
     uint32_t huf_min_lds;     /* minimum LDS bytes requested per Huffman workgroup (residency cap) */
     uint32_t no_split;        /* 1: never overlap k_seq(tail) with k_exec(head) on a second stream */
     uint32_t assume_cus;      /* testing: pretend the device has this many CUs when choosing the split */
-    uint32_t reserved[2];
+    uint32_t verify_checksum; /* 1: frames that carry a content checksum are verified on the device after the
+                                 pass (k_xxh64); a mismatch gives MZD_ERR_CHECKSUM.  Default 0:
+                                 the reference never checks it */
+    uint32_t reserved[1];
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

@@ -630,6 +630,63 @@ int orc_ring_string(const orc_ring *rb, uint8_t *out) /* :331-337 */
     return rb->offset;
 }
 
+/* ======================================================================= XXH64 (published spec) */
+
+#define XP1 0x9E3779B185EBCA87ULL
+#define XP2 0xC2B2AE3D27D4EB4FULL
+#define XP3 0x165667B19E3779F9ULL
+#define XP4 0x85EBCA77C2B2AE63ULL
+#define XP5 0x27D4EB2F165667C5ULL
+static uint64_t x_rotl(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+static uint64_t x_rd64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+static uint64_t x_rd32(const uint8_t *p) { return (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24); }
+static uint64_t x_round(uint64_t acc, uint64_t in) { return x_rotl(acc + in * XP2, 31) * XP1; }
+static uint64_t x_merge(uint64_t h, uint64_t v) { return (h ^ x_round(0, v)) * XP1 + XP4; }
+
+uint64_t orc_xxh64(const uint8_t *p, size_t n, uint64_t seed)
+{
+    const uint8_t *end = p + n;
+    uint64_t h;
+    if (n >= 32) { /* spec step 1-2: four accumulators over 32-byte stripes */
+        uint64_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        while ((size_t)(end - p) >= 32) {
+            v1 = x_round(v1, x_rd64(p));
+            v2 = x_round(v2, x_rd64(p + 8));
+            v3 = x_round(v3, x_rd64(p + 16));
+            v4 = x_round(v4, x_rd64(p + 24));
+            p += 32;
+        }
+        h = x_rotl(v1, 1) + x_rotl(v2, 7) + x_rotl(v3, 12) + x_rotl(v4, 18); /* step 3: convergence */
+        h = x_merge(h, v1);
+        h = x_merge(h, v2);
+        h = x_merge(h, v3);
+        h = x_merge(h, v4);
+    } else {
+        h = seed + XP5;
+    }
+    h += (uint64_t)n; /* step 4 */
+    while ((size_t)(end - p) >= 8) { /* step 5: remaining input */
+        h ^= x_round(0, x_rd64(p));
+        h = x_rotl(h, 27) * XP1 + XP4;
+        p += 8;
+    }
+    if ((size_t)(end - p) >= 4) {
+        h ^= x_rd32(p) * XP1;
+        h = x_rotl(h, 23) * XP2 + XP3;
+        p += 4;
+    }
+    while (p < end) {
+        h ^= (uint64_t)(*p++) * XP5;
+        h = x_rotl(h, 11) * XP1;
+    }
+    h ^= h >> 33; /* step 6: avalanche */
+    h *= XP2;
+    h ^= h >> 29;
+    h *= XP3;
+    h ^= h >> 32;
+    return h;
+}
+
 /* ======================================================================= frames */
 
 /* frame.go:23-127, framedecompressor.go:130-150,306-374 */

@@ -165,6 +165,14 @@ typedef struct {
 /* frame.go:23-127 + framedecompressor.go:130-150,306-374 ; src starts at magic */
 int orc_parse_frame_header(const uint8_t *src, size_t n, orc_frame_header *h);
 
+/* Content checksum (zstd frame format: low 32 bits of XXH64(content, seed 0), little endian, after
+ * the last block).  The REFERENCE never reads it (framereader.go:84-94, Readme.md:62: "checksum
+ * is not checked"); xxHash is third-party to it and absent from /root/reference, so this is a
+ * restatement of the published XXH64 specification (xxHash 0.8 doc/xxhash_spec.md), pinned on the
+ * 100 checksums that the decodecorpus frames carry.  Used to check the device-side verification
+ * (SURVEY 8f #3). */
+uint64_t orc_xxh64(const uint8_t *p, size_t n, uint64_t seed);
+
 /* optional per-block trace used by the tests to compare intermediates */
 typedef struct {
     int block_type;        /* 0 raw 1 rle 2 compressed */

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 1
+MZD_ABI_VERSION = 2
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -28,7 +28,12 @@ EXPORTS = [
 class FrameDesc(ctypes.Structure):
     _fields_ = [("first_block", ctypes.c_uint32), ("n_blocks", ctypes.c_uint32),
                 ("out_offset", ctypes.c_uint64), ("out_capacity", ctypes.c_uint64),
-                ("content_size", ctypes.c_uint64), ("window_size", ctypes.c_uint64)]
+                ("content_size", ctypes.c_uint64), ("window_size", ctypes.c_uint64),
+                ("checksum", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
+MZD_FRAME_HAS_CHECKSUM = 1
+MZD_ERR_CHECKSUM = 18
 
 
 class BlockDesc(ctypes.Structure):
@@ -77,7 +82,7 @@ class Batch(ctypes.Structure):
 class Options(ctypes.Structure):
     _fields_ = [("seq_variant", ctypes.c_uint32), ("exec_threads", ctypes.c_uint32),
                 ("exec_chunk", ctypes.c_uint32), ("huf_min_lds", ctypes.c_uint32), ("no_split", ctypes.c_uint32),
-                ("assume_cus", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 2)]
+                ("assume_cus", ctypes.c_uint32), ("verify_checksum", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
 
 
 class BatchStats(ctypes.Structure):

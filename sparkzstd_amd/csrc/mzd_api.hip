@@ -67,7 +67,7 @@ struct mzd_dbatch {
 
 namespace {
 
-constexpr size_t kEvPerRun = 10;
+constexpr size_t kEvPerRun = 12;
 thread_local std::string g_create_error;
 
 #define HIP_TRY(ctx, expr)                                                                    \
@@ -122,6 +122,7 @@ const char *mzd_strerror(int code)
     case MZD_ERR_DST_FULL: return "frame output does not fit its slab / content size mismatch";
     case MZD_ERR_UNSUPPORTED: return "outside the device path's limits";
     case MZD_ERR_OUT_OF_BLOCKS: return "No blocks left in frame";
+    case MZD_ERR_CHECKSUM: return "Content checksum mismatch";
     case MZD_ERR_DEVICE: return "HIP runtime error";
     case MZD_ERR_INVALID_ARG: return "invalid argument";
     case MZD_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
@@ -334,6 +335,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         df.first_block = fd.first_block;
         df.n_blocks = fd.n_blocks;
         df.plan_status = MZD_OK;
+        df.checksum = fd.checksum;
+        df.has_checksum = (fd.flags & MZD_FRAME_HAS_CHECKSUM) ? 1 : 0;
         df.pad = 0;
         if ((uint64_t)fd.first_block + fd.n_blocks > b->n_blocks || (fd.out_offset & 15) ||
             fd.out_offset > b->out_size || fd.out_capacity > b->out_size - fd.out_offset) {
@@ -678,6 +681,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                                      db->d_recs, db->d_tiles, db->d_litbuf, db->d_status + first,
                                                      db->d_out_len + first, exec_cap);
     };
+    // optional integrity check of the regenerated frames (extension: the reference never verifies it)
+    auto launch_verify = [&](hipStream_t st, uint32_t first, uint32_t count) {
+        if (!count || !ctx->opt.verify_checksum) return;
+        k_xxh64<<<(count + 15) / 16, 64, 0, st>>>(db->d_out, db->d_frames + first, count, db->d_status + first,
+                                                  db->d_out_len + first);
+    };
     // Stream plan.  k_huf only feeds k_exec, so it runs on the second stream, in the shadow of k_seq
     // (k_seq keeps ~2.7 KiB of LDS free per CU: a k_huf workgroup with small tables is co-resident):
     //   s  : k_init -> k_seq(head) -> k_seq(tail) -> [wait huf] k_exec(tail) -> [wait head done]
@@ -704,18 +713,24 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[6], s2));
         launch_exec(s2, 0, fA);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[7], s2));
+        launch_verify(s2, 0, fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[10], s2));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s2));
         launch_seq(tA, db->n_seq_tasks - tA);
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
         launch_exec(s, fA, db->n_frames - fA);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
+        launch_verify(s, fA, db->n_frames - fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[11], s));
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_head_done, 0));  // the caller's stream sees the whole batch done
     } else {
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
         launch_exec(s, 0, db->n_frames);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
+        launch_verify(s, 0, db->n_frames);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[11], s));
     }
     if (ev) {
         HIP_TRY(ctx, hipEventRecord(ev[8], s));
@@ -805,9 +820,9 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
 {
     // k_seq / k_exec: sum of their launches (head + tail of a split batch; those overlap in time);
     // "path": first event to last completion of the whole hot path (what the roofline divides by)
-    static const char *kNames[5] = {"k_init", "k_huf", "k_seq", "k_exec", "path"};
+    static const char *kNames[6] = {"k_init", "k_huf", "k_seq", "k_exec", "path", "k_xxh64"};
     if (!ctx || ctx->runs == 0) return 0;
-    double acc[5] = {0, 0, 0, 0, 0};
+    double acc[6] = {0, 0, 0, 0, 0, 0};
     size_t cnt = 0;
     auto el = [](hipEvent_t a, hipEvent_t b) {
         float t = 0;
@@ -821,10 +836,11 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
         acc[2] += el(e[1], e[3]) + (split ? el(e[3], e[4]) : 0.0);          // k_seq head (+ tail, incl. its wait for k_huf)
         acc[3] += el(e[4], e[5]) + (split ? el(e[6], e[7]) : 0.0);
         acc[4] += el(e[0], e[8]);
+        if (ctx->opt.verify_checksum) acc[5] += el(e[5], e[11]) + (split ? el(e[7], e[10]) : 0.0);
         cnt++;
     }
     int n = 0;
-    for (int i = 0; i < 5 && n < cap; i++, n++) {
+    for (int i = 0; i < (ctx->opt.verify_checksum ? 6 : 5) && n < cap; i++, n++) {
         if (names) names[n] = kNames[i];
         if (ms) ms[n] = (float)(acc[i] / cnt);
     }

@@ -1925,4 +1925,77 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
 
 
 
+// ------------------------------------------------------------------------------------------
+// k_xxh64: content checksum of the regenerated frames (zstd frame format: the 4
+// bytes after the last block are the low half of XXH64(content, seed 0)).  An EXTENSION: the
+// reference never reads the checksum (framereader.go:84-94, Readme.md:62), so this runs only with
+// mzd_options.verify_checksum.  Pure streaming read of the output: HBM-bound.
+// XXH64 keeps four accumulators, accumulator k eats bytes [32 s + 8 k, +8) of stripe s: FOUR LANES
+// per frame, one accumulator each (16 frames per wavefront), four stripes = one 128-byte line per
+// quad in flight; lane 0 of the quad merges and finishes the < 32 tail bytes.
+__device__ __forceinline__ uint64_t xxh_rotl(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+constexpr uint64_t kXP1 = 0x9E3779B185EBCA87ull, kXP2 = 0xC2B2AE3D27D4EB4Full, kXP3 = 0x165667B19E3779F9ull,
+                   kXP4 = 0x85EBCA77C2B2AE63ull, kXP5 = 0x27D4EB2F165667C5ull;
+__device__ __forceinline__ uint64_t xxh_round(uint64_t acc, uint64_t in) { return xxh_rotl(acc + in * kXP2, 31) * kXP1; }
+__device__ __forceinline__ uint64_t xxh_merge(uint64_t h, uint64_t v) { return (h ^ xxh_round(0, v)) * kXP1 + kXP4; }
+
+__global__ __launch_bounds__(64) void k_xxh64(const uint8_t *__restrict__ out_blob, const DFrame *__restrict__ frames,
+                                              uint32_t n_frames, int32_t *frame_status, const uint64_t *__restrict__ frame_out_len)
+{
+    const int lane = threadIdx.x, q = lane & 3;
+    const uint32_t f = blockIdx.x * 16 + (lane >> 2);
+    const bool in_range = f < n_frames;
+    DFrame fr{};
+    if (in_range) fr = frames[f];
+    // only frames that carry a checksum and decoded without error
+    const bool check = in_range && fr.has_checksum && frame_status[f] == MZD_OK;
+    const uint64_t n = check ? frame_out_len[f] : 0;
+    const uint8_t *p = out_blob + fr.out_offset;  // slabs are 256-byte aligned
+    const uint64_t stripes = n >> 5;
+    uint64_t v = q == 0 ? kXP1 + kXP2 : (q == 1 ? kXP2 : (q == 2 ? 0ull : 0ull - kXP1));
+    const uint64_t *pp = (const uint64_t *)p + q;
+    uint64_t s = 0;
+    if (stripes >= 4) {
+        uint64_t a0 = pp[0], a1 = pp[4], a2 = pp[8], a3 = pp[12];
+        for (; s + 8 <= stripes; s += 4) {
+            const uint64_t *nx = pp + 4 * (s + 4);  // next line in flight while this one is mixed in
+            const uint64_t b0 = nx[0], b1 = nx[4], b2 = nx[8], b3 = nx[12];
+            v = xxh_round(v, a0); v = xxh_round(v, a1); v = xxh_round(v, a2); v = xxh_round(v, a3);
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        }
+        v = xxh_round(v, a0); v = xxh_round(v, a1); v = xxh_round(v, a2); v = xxh_round(v, a3);
+        s += 4;
+    }
+    for (; s < stripes; s++) v = xxh_round(v, pp[4 * s]);
+    // convergence on lane 0 of the quad
+    const int q0 = lane & ~3;
+    const uint64_t v1 = __shfl(v, q0, 64), v2 = __shfl(v, q0 + 1, 64), v3 = __shfl(v, q0 + 2, 64), v4 = __shfl(v, q0 + 3, 64);
+    if (q != 0 || !check) return;
+    uint64_t h;
+    if (n >= 32) {
+        h = xxh_rotl(v1, 1) + xxh_rotl(v2, 7) + xxh_rotl(v3, 12) + xxh_rotl(v4, 18);
+        h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+    } else {
+        h = kXP5;  // seed 0
+    }
+    h += n;
+    const uint8_t *t = p + (stripes << 5), *end = p + n;
+    while (end - t >= 8) {
+        h ^= xxh_round(0, ld64u(t));
+        h = xxh_rotl(h, 27) * kXP1 + kXP4;
+        t += 8;
+    }
+    if (end - t >= 4) {
+        h ^= (uint64_t)((const U32U *)t)->v * kXP1;
+        h = xxh_rotl(h, 23) * kXP2 + kXP3;
+        t += 4;
+    }
+    while (t < end) {
+        h ^= (uint64_t)(*t++) * kXP5;
+        h = xxh_rotl(h, 11) * kXP1;
+    }
+    h ^= h >> 33; h *= kXP2; h ^= h >> 29; h *= kXP3; h ^= h >> 32;
+    if ((uint32_t)h != fr.checksum) frame_status[f] = MZD_ERR_CHECKSUM;
+}
+
 }  // namespace mzd

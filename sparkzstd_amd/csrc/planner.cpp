@@ -268,6 +268,7 @@ struct FramePart {
     uint64_t consumed = 0;
     uint64_t content_size = MZD_UNKNOWN_SIZE;
     uint64_t window_size = 0;
+    uint32_t checksum = 0, flags = 0;  // content checksum after the last block, MZD_FRAME_*
     uint64_t out_bound = 0;  // upper bound of the regenerated size
     std::vector<mzd_block_desc> blocks;
     std::vector<mzd_fse_table_desc> fse_tables;
@@ -558,6 +559,12 @@ struct FrameParser {
             out.blocks.push_back(bd);
         }
         out.consumed = p - begin;
+        // the content checksum is not part of what the reference consumes (framereader.go:84-94); it is
+        // recorded for the optional device-side verification
+        if (((fhd >> 2) & 1) && end - p >= 4) {
+            out.checksum = base[p] | ((uint32_t)base[p + 1] << 8) | ((uint32_t)base[p + 2] << 16) | ((uint32_t)base[p + 3] << 24);
+            out.flags |= MZD_FRAME_HAS_CHECKSUM;
+        }
         // never more than the blocks can regenerate: a (corrupt) header may declare any content size
         out.out_bound = out.content_size != MZD_UNKNOWN_SIZE ? std::min<uint64_t>(out.content_size, bound) : bound;
     }
@@ -628,6 +635,8 @@ struct mzd_plan {
         fd.n_blocks = (uint32_t)fp.blocks.size();
         fd.content_size = fp.content_size;
         fd.window_size = fp.window_size;
+        fd.checksum = fp.checksum;
+        fd.flags = fp.status ? 0 : fp.flags;
         for (auto b : fp.blocks) {
             b.src_off += rebase;
             b.lit_off += rebase;

@@ -74,6 +74,8 @@ class Oracle:
         L.orc_ring_string.argtypes = [ctypes.POINTER(Ring), ctypes.c_char_p]
         L.orc_trace_free.argtypes = [ctypes.POINTER(Trace)]
         L.orc_strerror.restype = ctypes.c_char_p
+        L.orc_xxh64.restype = ctypes.c_uint64
+        L.orc_xxh64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
         L.orc_decode_frames.restype = ctypes.c_int
         L.orc_decode_frames.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 5
 
@@ -99,6 +101,9 @@ class Oracle:
             }
             self.lib.orc_trace_free(ctypes.byref(tr))
         return rc, out, cons.value, trace
+
+    def xxh64(self, data: bytes, seed: int = 0) -> int:
+        return int(self.lib.orc_xxh64(data, len(data), seed))
 
     def strerror(self, rc):
         return self.lib.orc_strerror(rc).decode()

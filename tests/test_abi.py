@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_struct_layouts_match_header():
     # sizes the header implies (natural alignment, little endian)
-    assert ctypes.sizeof(_lib.FrameDesc) == 40
+    assert ctypes.sizeof(_lib.FrameDesc) == 48
     assert ctypes.sizeof(_lib.BlockDesc) == 80
     assert ctypes.sizeof(_lib.FseEntry) == 4
     assert ctypes.sizeof(_lib.FseTableDesc) == 8
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
 
 def test_identity_and_errors():
     L = _lib.load()
-    assert L.mzd_abi_version() == 1
+    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 2
     assert L.mzd_backend() == b"hip-gfx950"
     assert b"Magicnum" in L.mzd_strerror(2)
     assert L.mzd_device_count() >= 0

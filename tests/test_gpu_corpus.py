@@ -287,3 +287,39 @@ def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
     assert bytes(out_d) == bytes(out_h)
     ph.close()
     pd.close()
+
+
+def test_content_checksum_verification_on_device(corpus):
+    """k_xxh64 (an extension: the reference never reads the checksum): with
+    verify_checksum the 100 corpus frames (all carry one) pass, a frame whose stored checksum is
+    altered is reported as MZD_ERR_CHECKSUM (and still decodes without the option), synthetic
+    frames with and without checksums mix in one batch."""
+    from sparkzstd_amd import _lib
+    from tools import synth_binding as sb
+    c = z.Context(0, verify_checksum=True)
+    frames = [comp for _, comp, *_ in corpus]
+    outs, sts = _decode(frames, c)
+    assert sts == [0] * len(frames)
+    for (name, comp, length, sha, exp), got in zip(corpus, outs):
+        check_expected(name, got, length, sha, exp)
+    bad = []
+    for k in (3, 17, 42, 99):
+        f = bytearray(frames[k])
+        f[-1 - (k % 4)] ^= 0x40
+        bad.append(bytes(f))
+    data = [sb.generate(sb.TEXT, 100 + i, 131072 - 37 * i) for i in range(6)]  # lengths with every tail branch
+    try:
+        sb.set_content_checksum(True)
+        with_ck = [sb.compress(d)[0] for d in data]
+    finally:
+        sb.set_content_checksum(False)
+    without = [sb.compress(d)[0] for d in data[:2]]
+    broken = bytearray(with_ck[0]); broken[-2] ^= 1
+    batch = bad + with_ck + without + [bytes(broken)]
+    outs, sts = _decode(batch, c)
+    assert sts[:4] == [_lib.MZD_ERR_CHECKSUM] * 4
+    assert sts[4:4 + 6 + 2] == [0] * 8 and outs[4:10] == data and outs[10:12] == data[:2]
+    assert sts[-1] == _lib.MZD_ERR_CHECKSUM
+    # without the option nothing is verified (the reference's behaviour)
+    outs2, sts2 = _decode(bad, z.Context(0))
+    assert sts2 == [0] * 4

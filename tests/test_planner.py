@@ -156,3 +156,19 @@ def test_count_form_tables_describe_the_same_tables(corpus):
                (b.type, b.n_seq, b.ll_table, b.of_table, b.ml_table, b.seq_off, b.seq_size)
     ph.close()
     pd.close()
+
+
+def test_planner_records_content_checksums(corpus, oracle):
+    """Frame descriptor carries the 4 bytes after the last block when Content_Checksum_flag is set;
+    they are the low half of XXH64 of the original (oracle restatement of the published algorithm)."""
+    p = z.Plan()
+    for name, comp, *_ in corpus[:20]:
+        assert p.add_frame(comp)[0] == 0
+    b = p.finalize()
+    for i, (name, comp, length, sha, exp) in enumerate(corpus[:20]):
+        fd = b.frames[i]
+        assert fd.flags & _lib.MZD_FRAME_HAS_CHECKSUM
+        assert fd.checksum == int.from_bytes(comp[-4:], "little")
+        if exp is not None:
+            assert fd.checksum == oracle.xxh64(exp) & 0xFFFFFFFF
+    p.close()

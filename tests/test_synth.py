@@ -94,3 +94,19 @@ def test_add_frames_adopts_blob_and_is_thread_safe():
     for i in range(b1.n_blocks):
         assert bytes(b1.blocks[i]) == bytes(b2.blocks[i])
     p1.close(); p2.close()
+
+
+def test_synth_content_checksum_is_xxh64_of_the_content(oracle):
+    """Optional content checksum of the synthetic frames == oracle XXH64 (low 32 bits, little endian)."""
+    from tools import synth_binding as sb
+    data = sb.generate(sb.TEXT, 5, 70000)
+    try:
+        sb.set_content_checksum(True)
+        frame, _ = sb.compress(data)
+    finally:
+        sb.set_content_checksum(False)
+    plain, _ = sb.compress(data)
+    assert frame[4] == 0xA4 and plain[4] == 0xA0 and len(frame) == len(plain) + 4 and frame[5:-4] == plain[5:]
+    assert int.from_bytes(frame[-4:], "little") == oracle.xxh64(data) & 0xFFFFFFFF
+    rc, out, consumed, _ = oracle.decode_frame(frame, cap=len(data) + 64)
+    assert rc == 0 and out == data and consumed == len(frame) - 4

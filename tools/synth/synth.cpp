@@ -763,10 +763,39 @@ void find_sequences(const uint8_t *src, size_t n, std::vector<Seq> &seqs, std::v
 
 // ------------------------------------------------------------------ frames
 
+// Optional content checksum (zstd frame format: low 32 bits of XXH64(content, 0) after the last
+// block; xxHash specification).  Off by default: BASELINE's frame definitions carry none.
+static bool g_content_checksum = false;
+static uint64_t xrotl(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+static uint64_t xrd(const uint8_t *p, int n) { uint64_t v = 0; for (int i = n - 1; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+static uint64_t xxh64(const uint8_t *p, size_t n)
+{
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                   P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    auto round = [&](uint64_t a, uint64_t in) { return xrotl(a + in * P2, 31) * P1; };
+    const uint8_t *end = p + n;
+    uint64_t h;
+    if (n >= 32) {
+        uint64_t v[4] = {P1 + P2, P2, 0, 0 - P1};
+        for (; end - p >= 32; p += 32)
+            for (int k = 0; k < 4; k++) v[k] = round(v[k], xrd(p + 8 * k, 8));
+        h = xrotl(v[0], 1) + xrotl(v[1], 7) + xrotl(v[2], 12) + xrotl(v[3], 18);
+        for (int k = 0; k < 4; k++) h = (h ^ round(0, v[k])) * P1 + P4;
+    } else {
+        h = P5;
+    }
+    h += n;
+    for (; end - p >= 8; p += 8) { h ^= round(0, xrd(p, 8)); h = xrotl(h, 27) * P1 + P4; }
+    if (end - p >= 4) { h ^= xrd(p, 4) * P1; h = xrotl(h, 23) * P2 + P3; p += 4; }
+    for (; p < end; p++) { h ^= *p * P5; h = xrotl(h, 11) * P1; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
 void put_frame_header(std::vector<uint8_t> &out, uint32_t content_size)
 {
-    // magic, FHD 0xA0 = single segment + 4-byte content size, no checksum, no dictionary
-    const uint8_t h[9] = {0x28, 0xB5, 0x2F, 0xFD, 0xA0, (uint8_t)content_size, (uint8_t)(content_size >> 8),
+    // magic, FHD 0xA0 = single segment + 4-byte content size, no dictionary (+ 0x04 with a content checksum)
+    const uint8_t h[9] = {0x28, 0xB5, 0x2F, 0xFD, (uint8_t)(g_content_checksum ? 0xA4 : 0xA0), (uint8_t)content_size, (uint8_t)(content_size >> 8),
                           (uint8_t)(content_size >> 16), (uint8_t)(content_size >> 24)};
     out.insert(out.end(), h, h + 9);
 }
@@ -779,7 +808,16 @@ void put_block_header(std::vector<uint8_t> &out, uint32_t size, int type, bool l
 }
 
 // mode 0: full compressed block; 1: literals only (0 sequences); 2: raw block; 3: rle block
+void encode_frame_body(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &out, uint32_t *n_seq_out, int min_match);
 void encode_frame(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &out, uint32_t *n_seq_out, int min_match = 5)
+{
+    encode_frame_body(src, n, mode, out, n_seq_out, min_match);
+    if (g_content_checksum) {
+        const uint32_t c = (uint32_t)xxh64(src, n);
+        for (int i = 0; i < 4; i++) out.push_back((uint8_t)(c >> (8 * i)));
+    }
+}
+void encode_frame_body(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &out, uint32_t *n_seq_out, int min_match)
 {
     put_frame_header(out, (uint32_t)n);
     if (n_seq_out) *n_seq_out = 0;
@@ -825,6 +863,9 @@ void encode_frame(const uint8_t *src, size_t n, int mode, std::vector<uint8_t> &
 }  // namespace
 
 extern "C" {
+
+// frames produced from now on carry a content checksum (FHD bit 2 + 4 bytes after the last block)
+void synth_set_content_checksum(int on) { g_content_checksum = on != 0; }
 
 // kinds of content
 enum { SYNTH_TEXT = 0, SYNTH_EXP = 1, SYNTH_RANDOM = 2, SYNTH_ZERO = 3 };

@@ -29,8 +29,15 @@ def lib():
         L.synth_compress.restype = u64
         L.synth_make_batch.argtypes = [i32, u64, u32, u32, vp, u64, vp, vp, vp, vp, u32]
         L.synth_make_batch.restype = u64
+        L.synth_set_content_checksum.argtypes = [i32]
+        L.synth_set_content_checksum.restype = None
         _lib = L
     return _lib
+
+
+def set_content_checksum(on: bool):
+    """Frames produced from now on carry the zstd content checksum (low half of XXH64(content, 0))."""
+    lib().synth_set_content_checksum(1 if on else 0)
 
 
 def generate(kind: int, seed: int, n: int) -> bytes:
