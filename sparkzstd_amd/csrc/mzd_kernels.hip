@@ -1933,6 +1933,9 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
 // XXH64 keeps four accumulators, accumulator k eats bytes [32 s + 8 k, +8) of stripe s: FOUR LANES
 // per frame, one accumulator each (16 frames per wavefront), four stripes = one 128-byte line per
 // quad in flight; lane 0 of the quad merges and finishes the < 32 tail bytes.
+#ifndef MZD_XXH_UNROLL
+#define MZD_XXH_UNROLL 8
+#endif
 __device__ __forceinline__ uint64_t xxh_rotl(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
 constexpr uint64_t kXP1 = 0x9E3779B185EBCA87ull, kXP2 = 0xC2B2AE3D27D4EB4Full, kXP3 = 0x165667B19E3779F9ull,
                    kXP4 = 0x85EBCA77C2B2AE63ull, kXP5 = 0x27D4EB2F165667C5ull;
@@ -1955,16 +1958,24 @@ __global__ __launch_bounds__(64) void k_xxh64(const uint8_t *__restrict__ out_bl
     uint64_t v = q == 0 ? kXP1 + kXP2 : (q == 1 ? kXP2 : (q == 2 ? 0ull : 0ull - kXP1));
     const uint64_t *pp = (const uint64_t *)p + q;
     uint64_t s = 0;
-    if (stripes >= 4) {
-        uint64_t a0 = pp[0], a1 = pp[4], a2 = pp[8], a3 = pp[12];
-        for (; s + 8 <= stripes; s += 4) {
-            const uint64_t *nx = pp + 4 * (s + 4);  // next line in flight while this one is mixed in
-            const uint64_t b0 = nx[0], b1 = nx[4], b2 = nx[8], b3 = nx[12];
-            v = xxh_round(v, a0); v = xxh_round(v, a1); v = xxh_round(v, a2); v = xxh_round(v, a3);
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+    constexpr int U = MZD_XXH_UNROLL;  // stripes per batch: U loads of 8 bytes per lane in flight while U are mixed in
+    if (stripes >= U) {
+        uint64_t a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = pp[4 * u];
+        for (; s + 2 * U <= stripes; s += U) {
+            const uint64_t *nx = pp + 4 * (s + U);
+            uint64_t b[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) b[u] = nx[4 * u];
+#pragma unroll
+            for (int u = 0; u < U; u++) v = xxh_round(v, a[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) a[u] = b[u];
         }
-        v = xxh_round(v, a0); v = xxh_round(v, a1); v = xxh_round(v, a2); v = xxh_round(v, a3);
-        s += 4;
+#pragma unroll
+        for (int u = 0; u < U; u++) v = xxh_round(v, a[u]);
+        s += U;
     }
     for (; s < stripes; s++) v = xxh_round(v, pp[4 * s]);
     // convergence on lane 0 of the quad
