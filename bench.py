@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, help="SURVEY 8d config: 2 raw/rle, 3 huffman only, 4 full")
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="default: 65536 (config 4) / 4096 (configs 2, 3)")
+    ap.add_argument("--frame-bytes", type=int, default=131072, help="regenerated size of every frame (multiple of 256); above 128 KiB a frame has several blocks with cross-block matches and repeat-offset history")
     ap.add_argument("--strong", action="store_true",
                     help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
     ap.add_argument("--seq-variant", type=int, default=0)
@@ -160,7 +161,8 @@ def main():
     import sparkzstd_amd as z
     from tools import synth_binding as sb
 
-    frame_bytes = 131072
+    frame_bytes = a.frame_bytes
+    assert frame_bytes % 256 == 0 and frame_bytes > 0
     base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
     if a.strong:
         per = base // world
