@@ -323,3 +323,34 @@ def test_content_checksum_verification_on_device(corpus):
     # without the option nothing is verified (the reference's behaviour)
     outs2, sts2 = _decode(bad, z.Context(0))
     assert sts2 == [0] * 4
+
+
+@pytest.mark.parametrize("seq_variant", [0, 1])
+def test_escape_codes_long_literal_runs_and_long_matches(oracle, seq_variant):
+    """k_seq_pipe keeps literal-length codes >= 32 (runs >= 8192 bytes) and match-length codes >= 45
+    (>= 1027 bytes) out of its 2-byte LDS cell ("escape": next = 0) and serves them in the general
+    step from the host cell.  Frames built to hit exactly those: incompressible stretches of 8 KiB
+    to 70 KiB between repeated text (long literal runs), and long repeats (long matches), several
+    of each per block so that escapes meet ordinary sequences in one wavefront."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(7)
+    frames, want = [], []
+    for i in range(24):
+        text = sb.generate(sb.TEXT, 300 + i, 40000)
+        parts = []
+        for j in range(3):
+            noise = sb.generate(sb.RANDOM, 1000 * i + j, int(rng.integers(8192, 70000)))
+            rep_len = int(rng.integers(1027, 30000))
+            parts += [text[:int(rng.integers(2000, 12000))], noise, text[:rep_len], text[:rep_len]]
+        data = b"".join(parts)[:3 * 131072]
+        f, nseq = sb.compress(data)
+        rc, ref, _, tr = oracle.decode_frame(f, cap=len(data) + 64, want_trace=True)
+        assert rc == 0 and ref == data
+        lls = [s[0] for s in tr["seqs"]]
+        mls = [s[1] for s in tr["seqs"]]
+        assert max(lls) >= 8192 and max(mls) >= 1027, (max(lls), max(mls))  # the generator really produced escapes
+        frames.append(f)
+        want.append(data)
+    outs, sts = _decode(frames, z.Context(0, seq_variant=seq_variant))
+    assert sts == [0] * len(frames)
+    assert outs == want
