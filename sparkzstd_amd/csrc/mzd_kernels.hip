@@ -1448,7 +1448,7 @@ __device__ __forceinline__ void publish(uint32_t *vmap, uint32_t pos, uint32_t n
     const uint64_t m = span_mask(pos & 31, n);
     const uint32_t w = pos >> 5;
     atomicOr(&vmap[w], (uint32_t)m);
-    atomicOr(&vmap[w + 1], (uint32_t)(m >> 32));  // mostly zero: cheaper than the exec-mask region a test would cost
+    if ((uint32_t)(m >> 32)) atomicOr(&vmap[w + 1], (uint32_t)(m >> 32));
 }
 __device__ __forceinline__ uint32_t ld32u_g(const uint8_t *p) { return ((const U32U *)p)->v; }
 __device__ __forceinline__ void st32u_l(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
@@ -1463,11 +1463,15 @@ __device__ __forceinline__ void lds_store_upto16(uint8_t *d, uint32_t n, uint32_
                                                  uint32_t w3, uint32_t wt)
 {
     if (n >= 4) {
+        // a byte-misaligned LDS dword store costs the LDS pipe one cycle per active lane (tools/ubench), and
+        // the pipe is what k_exec fills most (SQ_LDS_IDX_ACTIVE): n <= 8 -- the common case -- stops at two
         const uint32_t last = n - 4;
         st32u_l(d, w0);
         st32u_l(d + min(4u, last), last >= 4 ? w1 : wt);
-        st32u_l(d + min(8u, last), last >= 8 ? w2 : wt);
-        st32u_l(d + min(12u, last), last >= 12 ? w3 : wt);
+        if (n > 8) {
+            st32u_l(d + min(8u, last), last >= 8 ? w2 : wt);
+            st32u_l(d + min(12u, last), last >= 12 ? w3 : wt);
+        }
     } else if (n) {
         const uint32_t h = n >> 1, e = n - 1;
         d[0] = (uint8_t)w0;
@@ -1784,7 +1788,8 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                                 for (uint32_t j = 0; 4 * j < mlc; j++) {
                                     const uint32_t nxt = base[j + 1];  // past the source: unused (and inside the buffer's slack)
                                     const uint32_t x = __builtin_amdgcn_alignbyte(nxt, prev, sa);
-                                    st32u_l(d + min(4 * j, last), 4 * j <= last ? x : xt);
+                                    // lanes whose copy is complete drop out pairwise (LDS time is per active lane)
+                                    if (j < 2 || 4 * (j & ~1u) < ML) st32u_l(d + min(4 * j, last), 4 * j <= last ? x : xt);
                                     prev = nxt;
                                 }
                             } else {
