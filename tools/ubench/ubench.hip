@@ -132,6 +132,21 @@ __global__ void k_pred(uint64_t *res, uint32_t *sink, int nact, int iters)
         for (int u = 0; u < 8; u++) {
             if (MODE == 0) {
                 if (active) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(acc), "n"(0) : "memory");
+            } else if (MODE == 3) {  // exec mask, dword-ALIGNED scattered addresses
+                if (active) asm volatile("ds_write_b32 %0, %1" ::"v"(addr & ~3u), "v"(acc) : "memory");
+            } else if (MODE == 4) {  // exec mask, atomic OR (no return) on aligned scattered words
+                if (active) asm volatile("ds_or_b32 %0, %1" ::"v"(addr & ~3u), "v"(acc) : "memory");
+            } else if (MODE == 5) {  // exec mask, byte stores
+                if (active) asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(acc) : "memory");
+            } else if (MODE == 7) {  // exec mask, byte-misaligned 8-byte stores
+                if (active) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"((uint64_t)acc) : "memory");
+            } else if (MODE == 8) {  // exec mask, 2-byte stores at odd addresses
+                if (active) asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(acc) : "memory");
+            } else if (MODE == 9) {  // exec mask, 8-byte stores at 4-byte (not 8-byte) aligned addresses
+                if (active) asm volatile("ds_write_b64 %0, %1" ::"v"((addr & ~3u) | 4u), "v"((uint64_t)acc) : "memory");
+            } else if (MODE == 6) {  // exec mask, aligned dword READS
+                uint32_t r_;
+                if (active) { asm volatile("ds_read_b32 %0, %1" : "=v"(r_) : "v"(addr & ~3u) : "memory"); }
             } else {
                 asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(acc) : "memory");
             }
@@ -277,6 +292,13 @@ int main()
         runp(k_pred<0>, "exec mask");
         runp(k_pred<1>, "dump slot");
         runp(k_pred<2>, "out of range");
+        runp(k_pred<3>, "aligned b32");
+        runp(k_pred<4>, "atomic or b32");
+        runp(k_pred<5>, "write b8");
+        runp(k_pred<6>, "aligned read");
+        runp(k_pred<7>, "misaligned b64");
+        runp(k_pred<8>, "odd b16");
+        runp(k_pred<9>, "b64 at 4 mod 8");
     }
     k_scan<<<1, 64>>>(d_sink, d_res, 10000);
     CHECK(hipDeviceSynchronize());
