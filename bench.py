@@ -39,6 +39,7 @@ def parse():
                     help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
     ap.add_argument("--seq-variant", type=int, default=0)
     ap.add_argument("--verify-checksum", action="store_true", help="frames carry the zstd content checksum and the device verifies it after the pass (k_xxh64; an extension, off by default like in the reference)")
+    ap.add_argument("--device-plan", action="store_true", help="parse the frame / block / section headers on the device too (mzd_batch_upload_frames) instead of in the host planner")
     ap.add_argument("--host-tables", action="store_true", help="build the FSE / Huffman decode tables in the host planner instead of on the device")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--exec-chunk", type=int, default=0)
@@ -214,6 +215,18 @@ def main():
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t0
     stats = rb.stats()
+    t_dplan = None
+    if a.device_plan:
+        # the same batch planned ON THE DEVICE: the host planner's batch above only serves as the cross-check
+        host_stats = stats
+        rb.free()
+        t0 = time.perf_counter()
+        rb = ctx.upload_frames(int(blob.size), off, ln, device_in_ptr=d_in.data_ptr() + pad, device_out_ptr=d_out.data_ptr(),
+                               device_out_size=int(d_out.numel()))
+        t_dplan = time.perf_counter() - t0
+        stats = rb.stats()
+        assert rb.out_size == batch.out_size and stats.compressed_bytes == host_stats.compressed_bytes
+        assert stats.n_sequences == host_stats.n_sequences
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -315,6 +328,9 @@ def main():
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 3), "upload": round(t_upload, 3),
                         "tables": "host" if a.host_tables else "device",
+                        "headers": "device" if a.device_plan else "host",
+                        "device_plan_s": round(t_dplan, 4) if t_dplan is not None else None,
+                        "k_parse_ms": round(float(stats.parse_ms), 3) if a.device_plan else None,
                         "fse_tables_built_on_device": int(stats.n_fse_built),
                         "huf_tables_built_on_device": int(stats.n_huf_built),
                         "k_fse_build_ms": round(float(stats.fse_build_ms), 3)},

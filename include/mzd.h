@@ -222,6 +222,24 @@ const char *mzd_last_error(mzd_ctx *ctx);
  * (literal buffer, sequence records) and, if batch->out is NULL or host memory, the
  * device output blob.  Replaces nothing in the reference (which has no device). */
 int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *batch, mzd_dbatch **out);
+/* Planning ON THE DEVICE: the same residency as mzd_batch_upload, but from the frames
+ * themselves -- no host planner, no descriptor arrays.  `in` holds whole zstd frames (magic number first) at
+ * frame_off[i] .. +frame_len[i]; with flags = MZD_BATCH_IN_ON_DEVICE it is a device pointer (MZD_IN_PAD slack
+ * both sides), else host memory that is copied up.  One lane per frame walks frame / block / section headers
+ * (frame.go, block.go, literals.go:67-289, sequences.go:228-433), reads the FSE table descriptions
+ * (fse.go:28-130) and Huffman weights (huffman.go:40-131) and writes the work lists; k_fse_build / k_huf_build
+ * then build every table.  The host only turns the per-frame counts into offsets.  The output blob is
+ * library-owned unless flags has MZD_BATCH_OUT_ON_DEVICE: then `out_dev` (out_dev_size bytes of device
+ * memory) is used, and MZD_ERR_DST_FULL is returned if the frames need more (sum of the frames' bounds, each
+ * rounded up to 256, + 256).  mzd_batch_out_size / mzd_batch_frame_layout tell where every frame's slab is.
+ * A frame that fails to parse gets the same status the host planner gives it (mzd_plan_frame_status),
+ * reported through mzd_batch_download like a decode error. */
+int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, uint32_t flags,
+                            const uint64_t *frame_off, const uint64_t *frame_len, uint32_t n_frames,
+                            uint8_t *out_dev, uint64_t out_dev_size, mzd_dbatch **out);
+/* size of the resident batch's output blob, and the slab (offset, capacity) of every frame in it */
+uint64_t mzd_batch_out_size(mzd_dbatch *db);
+int mzd_batch_frame_layout(mzd_dbatch *db, uint64_t *out_offset, uint64_t *out_capacity);
 /* The hot path: launches the kernels for every frame of the batch on `stream`
  * (a hipStream_t, or NULL for the context's stream). Asynchronous.
  * Replaces huffman.go:221, sequences.go:126, sequence_execution.go:14 and the
@@ -263,6 +281,7 @@ typedef struct mzd_batch_stats {
     uint64_t n_fse_built;         /* FSE tables built on the device from their counts (MZD_FSE_FROM_COUNTS) */
     uint64_t n_huf_built;         /* Huffman tables filled on the device from their weights (MZD_HUF_FROM_WEIGHTS) */
     double fse_build_ms;          /* duration of that build (k_fse_build, once per upload) */
+    double parse_ms;              /* mzd_batch_upload_frames only: the two planning passes on the device (k_parse) */
 } mzd_batch_stats;
 int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st);
 /* Copies the DEVICE decoding table number `table` (1 << acc_log cells, after the device-side build)

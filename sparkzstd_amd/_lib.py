@@ -22,6 +22,7 @@ EXPORTS = [
     "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_timing_reset", "mzd_batch_get_stats", "mzd_plan_create",
     "mzd_plan_destroy", "mzd_plan_reset", "mzd_plan_add_frame", "mzd_plan_add_frames",
     "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table", "mzd_batch_read_huf_table",
+    "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
 ]
 
 
@@ -90,7 +91,7 @@ class BatchStats(ctypes.Structure):
                 ("scratch_bytes", ctypes.c_uint64), ("out_capacity_bytes", ctypes.c_uint64),
                 ("n_sequences", ctypes.c_uint64), ("n_huf_streams", ctypes.c_uint64),
                 ("n_blocks", ctypes.c_uint64 * 3), ("n_fse_built", ctypes.c_uint64), ("n_huf_built", ctypes.c_uint64),
-                ("fse_build_ms", ctypes.c_double)]
+                ("fse_build_ms", ctypes.c_double), ("parse_ms", ctypes.c_double)]
 
 
 _lib = None
@@ -131,6 +132,9 @@ def load():
         "mzd_plan_set_device_tables": (None, [vp, i32]),
         "mzd_batch_read_fse_table": (i32, [vp, vp, u32, vp, u32]),
         "mzd_batch_read_huf_table": (i32, [vp, vp, u32, vp, u32]),
+        "mzd_batch_upload_frames": (i32, [vp, vp, u64, u32, vp, vp, u32, vp, u64, ctypes.POINTER(vp)]),
+        "mzd_batch_out_size": (u64, [vp]),
+        "mzd_batch_frame_layout": (i32, [vp, vp, vp]),
         "mzd_plan_destroy": (None, [vp]),
         "mzd_plan_reset": (None, [vp]),
         "mzd_plan_add_frame": (i32, [vp, vp, u64, ctypes.POINTER(u64)]),

@@ -70,14 +70,29 @@ class Plan:
 
 
 class ResidentBatch:
-    def __init__(self, ctx, handle, batch: Batch):
+    def __init__(self, ctx, handle, batch: Batch = None, n_frames: int = 0):
         self.ctx = ctx
         self._h = handle
-        self.n_frames = batch.n_frames
-        self.out_size = batch.out_size
-        self.frame_out_offset = np.array([batch.frames[i].out_offset for i in range(batch.n_frames)], dtype=np.uint64) \
-            if batch.n_frames <= 4096 else None
+        if batch is not None:
+            self.n_frames = batch.n_frames
+            self.out_size = batch.out_size
+            self.frame_out_offset = np.array([batch.frames[i].out_offset for i in range(batch.n_frames)], dtype=np.uint64) \
+                if batch.n_frames <= 4096 else None
+        else:  # planned on the device (Context.upload_frames): the library knows the layout
+            self.n_frames = n_frames
+            self.out_size = int(ctx._L.mzd_batch_out_size(handle))
+            self.frame_out_offset = self.frame_layout()[0]
         self._batch = batch
+
+    def frame_layout(self):
+        """-> (out_offset uint64[n], out_capacity uint64[n]) of every frame's slab in the output blob"""
+        off = np.zeros(self.n_frames, dtype=np.uint64)
+        cap = np.zeros(self.n_frames, dtype=np.uint64)
+        rc = self.ctx._L.mzd_batch_frame_layout(self._h, off.ctypes.data if self.n_frames else None,
+                                                cap.ctypes.data if self.n_frames else None)
+        if rc:
+            raise MzdError(rc, "mzd_batch_frame_layout")
+        return off, cap
 
     def run(self, stream=None):
         rc = self.ctx._L.mzd_batch_run(self.ctx._c, self._h, stream)
@@ -177,6 +192,29 @@ class Context:
             raise MzdError(rc, "mzd_batch_upload: " + self.last_error())
         return ResidentBatch(self, h, batch)
 
+    def upload_frames(self, blob, frame_off, frame_len, device_in_ptr=None, device_out_ptr=None, device_out_size=0) -> ResidentBatch:
+        """Planning on the device (mzd_batch_upload_frames): whole zstd frames in, no host
+        planner.  blob: bytes-like / np.uint8 array (host), or pass device_in_ptr (with MZD_IN_PAD slack) and
+        blob = its size in bytes.  device_out_ptr / device_out_size: caller-owned device output blob."""
+        off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+        ln = np.ascontiguousarray(frame_len, dtype=np.uint64)
+        assert off.shape == ln.shape
+        h = ctypes.c_void_p()
+        if device_in_ptr is not None:
+            ptr, size, flags = device_in_ptr, int(blob), _lib.MZD_BATCH_IN_ON_DEVICE
+        else:
+            arr = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else np.ascontiguousarray(blob, dtype=np.uint8)
+            self._keep = arr
+            ptr, size, flags = (arr.ctypes.data if arr.size else None), arr.size, 0
+        if device_out_ptr is not None:
+            flags |= _lib.MZD_BATCH_OUT_ON_DEVICE
+        rc = self._L.mzd_batch_upload_frames(self._c, ptr, size, flags, off.ctypes.data if off.size else None,
+                                             ln.ctypes.data if ln.size else None, off.size, device_out_ptr, device_out_size,
+                                             ctypes.byref(h))
+        if rc:
+            raise MzdError(rc, "mzd_batch_upload_frames: " + self.last_error())
+        return ResidentBatch(self, h, None, n_frames=off.size)
+
     def sync(self):
         rc = self._L.mzd_sync(self._c)
         if rc:
@@ -213,12 +251,31 @@ def default_context(device: int = 0) -> Context:
     return _default_ctx[device]
 
 
-def decode_frames(frames, ctx: Context = None, device_tables: bool = True):
+def decode_frames(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):
     """Decodes independent zstd frames (list of bytes) in ONE device batch.
     -> (outputs: list of bytes-or-None, statuses: list of int).  The batched analogue of calling
     sparkzstd's FrameDecompressor.Decompress() (framedecompressor.go:153) once per frame.
-    device_tables: FSE tables are shipped as normalised counts and built on the device."""
+    device_tables: FSE tables are shipped as normalised counts and built on the device.
+    device_plan: no host planner at all -- headers are parsed on the device too (Context.upload_frames)."""
     ctx = ctx or default_context()
+    if device_plan:
+        frames = [bytes(f) for f in frames]
+        ln = np.array([len(f) for f in frames], dtype=np.uint64)
+        off = np.zeros(len(frames), dtype=np.uint64)
+        if len(frames) > 1:
+            off[1:] = np.cumsum(ln)[:-1]
+        rb = ctx.upload_frames(b"".join(frames), off, ln)
+        try:
+            rb.run()
+            out, status, out_len = rb.download()
+            lay = rb.frame_out_offset
+        finally:
+            rb.free()
+        outs, sts = [], [int(x) for x in status]
+        for i in range(len(frames)):
+            o = int(lay[i])
+            outs.append(out[o:o + int(out_len[i])].tobytes() if sts[i] == 0 else None)
+        return outs, sts
     plan = Plan(device_tables=device_tables)
     try:
         plan_status = []

@@ -14,6 +14,7 @@
 
 // unity build: the kernels live in their own file but are compiled in this translation unit
 #include "mzd_kernels.hip"
+#include "mzd_parse.hip"
 
 using namespace mzd;
 
@@ -61,6 +62,8 @@ struct mzd_dbatch {
     uint32_t n_frames = 0, n_blocks = 0, n_huf_tasks = 0, n_seq_tasks = 0;
     uint32_t huf_slot_cells = 2;
     std::vector<uint32_t> frame_seq_task;  // host: index of the first SeqTask of every frame (+ total)
+    std::vector<uint64_t> frame_out_off, frame_out_cap;  // host: output slab of every frame
+    float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
     uint64_t out_size = 0;
     mzd_batch_stats stats{};
 };
@@ -456,6 +459,12 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->n_seq_tasks = (uint32_t)seq_tasks.size();
     db->huf_slot_cells = 1u << max_huf_bits;
     db->frame_seq_task = std::move(frame_seq_task);
+    db->frame_out_off.resize(b->n_frames);
+    db->frame_out_cap.resize(b->n_frames);
+    for (uint32_t f = 0; f < b->n_frames; f++) {
+        db->frame_out_off[f] = b->frames[f].out_offset;
+        db->frame_out_cap[f] = b->frames[f].out_capacity;
+    }
     db->out_size = b->out_size;
     db->stats = st;
     int rc = MZD_OK;
@@ -590,6 +599,252 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
 #undef TRY_OR_FAIL
 #undef HIP_OR_FAIL
     *out = db;
+    return MZD_OK;
+}
+
+// ---- planning on the device: see mzd_parse.hip
+int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, uint32_t flags, const uint64_t *frame_off,
+                            const uint64_t *frame_len, uint32_t n_frames, uint8_t *out_dev, uint64_t out_dev_size, mzd_dbatch **out)
+{
+    if (!ctx || !out || (!in && in_size) || ((!frame_off || !frame_len) && n_frames) ||
+        (flags & ~(uint32_t)(MZD_BATCH_IN_ON_DEVICE | MZD_BATCH_OUT_ON_DEVICE)) || ((flags & MZD_BATCH_OUT_ON_DEVICE) && !out_dev))
+        return MZD_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mzd_dbatch *db = new mzd_dbatch();
+    // temporaries of the planning pass
+    uint64_t *d_foff = nullptr, *d_flen = nullptr;
+    ParseScratch *d_scratch = nullptr;
+    FrameCount *d_counts = nullptr;
+    FrameBase *d_bases = nullptr;
+    FseBuildDesc *d_fse_tabs = nullptr;
+    uint32_t *d_fse_src = nullptr;
+    HufBuildDesc *d_huf_tabs = nullptr;
+    uint16_t *d_huf_src = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr, t4 = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_foff);
+        (void)hipFree(d_flen);
+        (void)hipFree(d_scratch);
+        (void)hipFree(d_counts);
+        (void)hipFree(d_bases);
+        (void)hipFree(d_fse_tabs);
+        (void)hipFree(d_fse_src);
+        (void)hipFree(d_huf_tabs);
+        (void)hipFree(d_huf_src);
+        for (hipEvent_t e : {t0, t1, t2, t3, t4})
+            if (e) (void)hipEventDestroy(e);
+    };
+    auto fail = [&](int code) {
+        cleanup();
+        mzd_batch_free(ctx, db);
+        return code;
+    };
+#define HIP_OR_FAIL(expr)                                                             \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            ctx->last_error = std::string(#expr " failed: ") + hipGetErrorString(e_); \
+            return fail(MZD_ERR_DEVICE);                                              \
+        }                                                                             \
+    } while (0)
+    hipStream_t s = ctx->stream;
+    for (hipEvent_t *e : {&t0, &t1, &t2, &t3, &t4}) HIP_OR_FAIL(hipEventCreate(e));
+    // ---- the compressed frames
+    if (flags & MZD_BATCH_IN_ON_DEVICE) {
+        db->d_in = in;
+    } else {
+        HIP_OR_FAIL(hipMalloc((void **)&db->d_in_alloc, in_size + 2 * MZD_IN_PAD));
+        HIP_OR_FAIL(hipMemset(db->d_in_alloc, 0, MZD_IN_PAD));
+        HIP_OR_FAIL(hipMemset(db->d_in_alloc + MZD_IN_PAD + in_size, 0, MZD_IN_PAD));
+        if (in_size) HIP_OR_FAIL(hipMemcpy(db->d_in_alloc + MZD_IN_PAD, in, in_size, hipMemcpyHostToDevice));
+        db->d_in = db->d_in_alloc + MZD_IN_PAD;
+    }
+    db->in_size = in_size;
+    db->n_frames = n_frames;
+    const size_t nf1 = std::max<size_t>(n_frames, 1);
+    HIP_OR_FAIL(hipMalloc((void **)&d_foff, nf1 * 8));
+    HIP_OR_FAIL(hipMalloc((void **)&d_flen, nf1 * 8));
+    if (n_frames) {
+        HIP_OR_FAIL(hipMemcpy(d_foff, frame_off, (size_t)n_frames * 8, hipMemcpyHostToDevice));
+        HIP_OR_FAIL(hipMemcpy(d_flen, frame_len, (size_t)n_frames * 8, hipMemcpyHostToDevice));
+    }
+    // one lane per frame, grid-stride; every lane owns a ParseScratch
+    const uint32_t max_wg = (uint32_t)std::max(ctx->num_cus, 1) * 2;
+    const uint32_t n_wg = std::max<uint32_t>(1, std::min<uint32_t>((n_frames + 63) / 64, max_wg));
+    HIP_OR_FAIL(hipMalloc((void **)&d_scratch, (size_t)n_wg * 64 * sizeof(ParseScratch)));
+    HIP_OR_FAIL(hipMalloc((void **)&d_counts, nf1 * sizeof(FrameCount)));
+    HIP_OR_FAIL(hipMalloc((void **)&d_bases, nf1 * sizeof(FrameBase)));
+    ParseOut po{};
+    // ---- pass 0: what does every frame need?
+    HIP_OR_FAIL(hipEventRecord(t0, s));
+    if (n_frames) k_parse<0><<<n_wg, 64, 0, s>>>(db->d_in, in_size, d_foff, d_flen, n_frames, d_scratch, d_counts, d_bases, po);
+    HIP_OR_FAIL(hipEventRecord(t1, s));
+    std::vector<FrameCount> counts(n_frames);
+    HIP_OR_FAIL(hipStreamSynchronize(s));
+    if (n_frames) HIP_OR_FAIL(hipMemcpy(counts.data(), d_counts, (size_t)n_frames * sizeof(FrameCount), hipMemcpyDeviceToHost));
+    // ---- offsets (exclusive prefix sums).  Tables 0..2 are the predefined ones (predefined.go), kept as
+    // their normalised counts and built by k_fse_build like every other table.
+    static const int16_t kDef[3][53] = {
+        {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1},
+        {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1},
+        {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1,  1,  1,  1,  1,  1,  1,  1,  1,  1, 1,
+         1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1}};
+    static const int kDefN[3] = {36, 29, 53}, kDefLog[3] = {6, 5, 6};  // by MZD_FSE_*: LL, OF, ML
+    std::vector<FrameBase> bases(n_frames);
+    std::vector<uint32_t> frame_seq_task(n_frames + 1, 0);
+    db->frame_out_off.resize(n_frames);
+    db->frame_out_cap.resize(n_frames);
+    uint64_t n_blocks = 0, n_seq = 0, n_hufb = 0, n_fse_tab = 3, n_fse_src = 0, n_fse_dev = 0, n_huf_tab = 0, n_huf_src = 0, n_huf_dev = 0,
+             n_tile = 0, n_rec = 0, lit_total = 0, out_at = 0;
+    uint32_t predef_src[3];
+    for (int k = 0; k < 3; k++) {
+        po.predef_off[k] = (uint32_t)n_fse_dev;
+        predef_src[k] = (uint32_t)n_fse_src;
+        n_fse_dev += 1u << kDefLog[k];
+        n_fse_src += (uint32_t)(kDefN[k] + 1) / 2;
+    }
+    uint32_t max_huf_bits = 1;
+    mzd_batch_stats st{};
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const FrameCount &c = counts[f];
+        FrameBase &fb = bases[f];
+        fb.block0 = (uint32_t)n_blocks;
+        fb.seq0 = (uint32_t)n_seq;
+        fb.hufb0 = (uint32_t)n_hufb;
+        fb.fse_tab0 = (uint32_t)n_fse_tab;
+        fb.fse_src0 = (uint32_t)n_fse_src;
+        fb.fse_dev0 = (uint32_t)n_fse_dev;
+        fb.huf_tab0 = (uint32_t)n_huf_tab;
+        fb.huf_src0 = (uint32_t)n_huf_src;
+        fb.huf_dev0 = (uint32_t)n_huf_dev;
+        fb.tile0 = (uint32_t)n_tile;
+        fb.rec0 = n_rec;
+        fb.lit0 = lit_total;
+        fb.out_off = out_at;
+        fb.out_cap = c.status == MZD_OK ? c.out_bound : 0;
+        frame_seq_task[f] = (uint32_t)n_seq;
+        db->frame_out_off[f] = fb.out_off;
+        db->frame_out_cap[f] = fb.out_cap;
+        out_at += (fb.out_cap + 255) & ~255ull;
+        n_blocks += c.n_blocks;
+        n_seq += c.n_seq;
+        n_hufb += c.n_hufb;
+        n_fse_tab += c.n_fse_tab;
+        n_fse_src += c.n_fse_src;
+        n_fse_dev += c.n_fse_dev;
+        n_huf_tab += c.n_huf_tab;
+        n_huf_src += c.n_huf_src;
+        n_huf_dev += c.n_huf_dev;
+        n_tile += c.n_tile;
+        n_rec += c.n_rec;
+        lit_total += c.lit_bytes;
+        max_huf_bits = std::max(max_huf_bits, c.max_huf_bits);
+        st.compressed_bytes += c.comp_bytes;
+        st.out_capacity_bytes += fb.out_cap;
+        st.n_sequences += c.n_rec;
+        st.n_huf_streams += c.n_huf_streams;
+        st.n_blocks[0] += c.n_raw;
+        st.n_blocks[1] += c.n_rle;
+        st.n_blocks[2] += c.n_comp;
+    }
+    out_at += 256;  // tail slack: the execution kernel's 16-byte source loads may run past the last slab
+    frame_seq_task[n_frames] = (uint32_t)n_seq;
+    const uint64_t lim32 = 0xFFFFFFFFull;
+    if (n_blocks > lim32 || n_seq > lim32 || 4 * n_hufb > lim32 || n_fse_dev > lim32 || n_huf_dev > lim32 || n_tile > lim32) {
+        ctx->last_error = "batch too large for 32-bit work-list indices";
+        return fail(MZD_ERR_UNSUPPORTED);
+    }
+    st.table_bytes = n_fse_src * 4 + n_huf_src * 2;
+    st.scratch_bytes = n_rec * 8 + n_tile * 8 + lit_total;
+    db->n_blocks = (uint32_t)n_blocks;
+    db->n_huf_tasks = (uint32_t)(4 * n_hufb);
+    db->n_seq_tasks = (uint32_t)n_seq;
+    db->huf_slot_cells = 1u << max_huf_bits;
+    db->frame_seq_task = std::move(frame_seq_task);
+    db->out_size = out_at;
+    db->stats = st;
+    // ---- everything the hot path needs, sized by the counts
+    if (flags & MZD_BATCH_OUT_ON_DEVICE) {
+        if (out_dev_size < out_at) {
+            ctx->last_error = "output blob too small: the frames need " + std::to_string(out_at) + " bytes";
+            return fail(MZD_ERR_DST_FULL);
+        }
+        db->d_out = out_dev;
+    } else {
+        HIP_OR_FAIL(hipMalloc((void **)&db->d_out, std::max<uint64_t>(out_at, 16)));
+        db->own_out = true;
+    }
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_frames, nf1 * sizeof(DFrame)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_blocks, std::max<uint64_t>(n_blocks, 1) * sizeof(DBlock)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_sums, std::max<uint64_t>(n_blocks, 1) * sizeof(BlockSum)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_tasks, std::max<uint64_t>(4 * n_hufb, 1) * sizeof(HufTask)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_seq_tasks, std::max<uint64_t>(n_seq, 1) * sizeof(SeqTask)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_fse_entries, std::max<uint64_t>(n_fse_dev, 1) * 4));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_entries, std::max<uint64_t>(n_huf_dev, 2) * 2 + 8));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_recs, std::max<uint64_t>(n_rec, 1) * 8));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_tiles, std::max<uint64_t>(n_tile, 1) * sizeof(TileBase)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_status, nf1 * sizeof(int32_t)));
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_out_len, nf1 * sizeof(uint64_t)));
+    HIP_OR_FAIL(hipMemset(db->d_status, 0xFF, nf1 * sizeof(int32_t)));
+    HIP_OR_FAIL(hipMemset(db->d_out_len, 0, nf1 * sizeof(uint64_t)));
+    HIP_OR_FAIL(hipMalloc((void **)&d_fse_tabs, n_fse_tab * sizeof(FseBuildDesc)));
+    HIP_OR_FAIL(hipMalloc((void **)&d_fse_src, n_fse_src * 4));
+    HIP_OR_FAIL(hipMalloc((void **)&d_huf_tabs, std::max<uint64_t>(n_huf_tab, 1) * sizeof(HufBuildDesc)));
+    HIP_OR_FAIL(hipMalloc((void **)&d_huf_src, std::max<uint64_t>(n_huf_src, 1) * 2));
+    {  // the predefined tables' counts
+        FseBuildDesc pd[3];
+        std::vector<uint32_t> src(predef_src[2] + (kDefN[2] + 1) / 2, 0);
+        for (int k = 0; k < 3; k++) {
+            pd[k] = FseBuildDesc{predef_src[k], po.predef_off[k], (uint8_t)kDefLog[k], (uint8_t)kDefN[k], 1, 0};
+            for (int i = 0; i < kDefN[k]; i++) src[predef_src[k] + i / 2] |= (uint32_t)(uint16_t)kDef[k][i] << (16 * (i & 1));
+        }
+        HIP_OR_FAIL(hipMemcpy(d_fse_tabs, pd, sizeof pd, hipMemcpyHostToDevice));
+        HIP_OR_FAIL(hipMemcpy(d_fse_src, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (n_frames) HIP_OR_FAIL(hipMemcpy(d_bases, bases.data(), (size_t)n_frames * sizeof(FrameBase), hipMemcpyHostToDevice));
+    po.frames = db->d_frames;
+    po.blocks = db->d_blocks;
+    po.huf_tasks = db->d_huf_tasks;
+    po.seq_tasks = db->d_seq_tasks;
+    po.fse_tabs = d_fse_tabs;
+    po.fse_src = d_fse_src;
+    po.huf_tabs = d_huf_tabs;
+    po.huf_src = d_huf_src;
+    // ---- pass 1: write the work lists and the table build descriptors; then build the tables
+    HIP_OR_FAIL(hipEventRecord(t2, s));
+    if (n_frames) k_parse<1><<<n_wg, 64, 0, s>>>(db->d_in, in_size, d_foff, d_flen, n_frames, d_scratch, d_counts, d_bases, po);
+    HIP_OR_FAIL(hipEventRecord(t3, s));
+    k_fse_build<<<(uint32_t)((n_fse_tab + 63) / 64), 64, 0, s>>>(d_fse_tabs, (uint32_t)n_fse_tab, d_fse_src, db->d_fse_entries);
+    HIP_OR_FAIL(hipEventRecord(t4, s));
+    if (n_huf_tab) k_huf_build<<<(uint32_t)((n_huf_tab + 63) / 64), 64, 0, s>>>(d_huf_tabs, (uint32_t)n_huf_tab, d_huf_src, db->d_huf_entries);
+    HIP_OR_FAIL(hipGetLastError());
+    HIP_OR_FAIL(hipStreamSynchronize(s));
+    float a = 0, b2 = 0, c2 = 0;
+    (void)hipEventElapsedTime(&a, t0, t1);
+    (void)hipEventElapsedTime(&b2, t2, t3);
+    (void)hipEventElapsedTime(&c2, t3, t4);
+    db->parse_ms = a + b2;
+    db->fse_build_ms = c2;
+    db->n_fse_built = (uint32_t)n_fse_tab;
+    db->n_huf_built = (uint32_t)n_huf_tab;
+    db->n_fse_entries = (uint32_t)n_fse_dev;
+#undef HIP_OR_FAIL
+    cleanup();
+    *out = db;
+    return MZD_OK;
+}
+
+uint64_t mzd_batch_out_size(mzd_dbatch *db) { return db ? db->out_size : 0; }
+
+int mzd_batch_frame_layout(mzd_dbatch *db, uint64_t *out_offset, uint64_t *out_capacity)
+{
+    if (!db) return MZD_ERR_INVALID_ARG;
+    for (uint32_t f = 0; f < db->n_frames && f < db->frame_out_off.size(); f++) {
+        if (out_offset) out_offset[f] = db->frame_out_off[f];
+        if (out_capacity) out_capacity[f] = db->frame_out_cap[f];
+    }
     return MZD_OK;
 }
 
@@ -861,6 +1116,7 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
     st->n_fse_built = db->n_fse_built;
     st->n_huf_built = db->n_huf_built;
     st->fse_build_ms = db->fse_build_ms;
+    st->parse_ms = db->parse_ms;
     return MZD_OK;
 }
 

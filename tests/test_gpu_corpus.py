@@ -354,3 +354,132 @@ def test_escape_codes_long_literal_runs_and_long_matches(oracle, seq_variant):
     outs, sts = _decode(frames, z.Context(0, seq_variant=seq_variant))
     assert sts == [0] * len(frames)
     assert outs == want
+
+
+# ---- planning on the device: k_parse instead of the host planner
+
+def _both_plans(frames, ctx):
+    outs_h, sts_h = z.decode_frames(frames, ctx)
+    outs_d, sts_d = z.decode_frames(frames, ctx, device_plan=True)
+    return outs_h, sts_h, outs_d, sts_d
+
+
+def test_device_planner_corpus_bit_exact(corpus, ctx):
+    """The whole golden corpus, headers parsed on the device: same bytes as the corpus says."""
+    outs, sts = z.decode_frames([comp for _, comp, *_ in corpus], ctx, device_plan=True)
+    assert all(s == 0 for s in sts), [(corpus[i][0], s) for i, s in enumerate(sts) if s]
+    for (name, comp, length, sha, exp), got in zip(corpus, outs):
+        check_expected(name, got, length, sha, exp)
+
+
+def test_device_planner_equals_host_planner_layout_and_stats(corpus, ctx):
+    """Same slabs, same work: the device-planned batch has the host-planned batch's output layout and
+    byte / sequence / stream counts (the roofline accounting does not depend on who planned)."""
+    from tools import synth_binding as sb
+    blob, off, ln, _, _ = sb.make_batch(4, 5, 64, threads=4)
+    frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+    p = z.Plan(device_tables=True)
+    for f in frames:
+        assert p.add_frame(f)[0] == 0
+    b = p.finalize()
+    rh = ctx.upload(b)
+    lens = np.array([len(f) for f in frames], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    rd = ctx.upload_frames(b"".join(frames), offs, lens)
+    try:
+        assert rd.out_size == rh.out_size
+        lo, lc = rd.frame_layout()
+        assert [int(x) for x in lo] == [int(b.frames[i].out_offset) for i in range(b.n_frames)]
+        assert [int(x) for x in lc] == [int(b.frames[i].out_capacity) for i in range(b.n_frames)]
+        sh, sd = rh.stats(), rd.stats()
+        for k in ("compressed_bytes", "scratch_bytes", "out_capacity_bytes", "n_sequences", "n_huf_streams"):
+            assert getattr(sh, k) == getattr(sd, k), k
+        assert list(sh.n_blocks) == list(sd.n_blocks)
+        assert sd.n_huf_built == sh.n_huf_built and sd.n_fse_built >= sh.n_fse_built
+        assert sd.parse_ms > 0
+        rd.run()
+        rh.run()
+        od, std, ld = rd.download()
+        oh, sth, lh = rh.download()
+        assert (std == 0).all() and (sth == 0).all() and (ld == lh).all()
+        for i in range(len(frames)):
+            o, n = int(lo[i]), int(ld[i])
+            assert (od[o:o + n] == oh[o:o + n]).all(), i
+    finally:
+        rd.free()
+        rh.free()
+        p.close()
+
+
+def test_device_planner_synthetic_and_multiblock(ctx, oracle):
+    from tools import synth_binding as sb
+    frames = []
+    for cfg, seed, n in [(1, 3, 24), (2, 4, 24), (3, 5, 16), (4, 6, 48)]:
+        blob, off, ln, _, _ = sb.make_batch(cfg, seed, n, threads=4)
+        frames += [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+    sb.set_content_checksum(True)
+    try:
+        blob, off, ln, _, _ = sb.make_batch(4, 9, 16, threads=2)
+        frames += [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+    finally:
+        sb.set_content_checksum(False)
+    outs_h, sts_h, outs_d, sts_d = _both_plans(frames, ctx)
+    assert sts_d == sts_h == [0] * len(frames)
+    assert outs_d == outs_h
+    for f, o in list(zip(frames, outs_d))[::7]:
+        rc, want, _, _ = oracle.decode_frame(f, cap=8 << 20)
+        assert rc == 0 and o == want
+
+
+def test_device_planner_checksum_verification(corpus):
+    """Checksums captured by the device parser feed k_xxh64 like the host planner's."""
+    c = z.Context(0, verify_checksum=True)
+    frames = [comp for _, comp, *_ in corpus]
+    bad = bytearray(frames[5])
+    bad[-1] ^= 0x40  # the last byte of a corpus frame is its checksum
+    frames.append(bytes(bad))
+    outs_h, sts_h, outs_d, sts_d = _both_plans(frames, c)
+    assert sts_d == sts_h
+    assert sts_d[-1] == 18 and all(s == 0 for s in sts_d[:-1])
+    c.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_device_planner_fuzz_agrees_with_host_planner(corpus, seed):
+    """Mutated and truncated frames (headers included): the device parser reports, frame for frame, the
+    status the host planner + upload report, and decodes the same bytes when both succeed."""
+    rng = np.random.default_rng(977 + seed)
+    frames = []
+    for _, comp, *_ in corpus:
+        for k in range(8):
+            b = bytearray(comp)
+            if k == 6:
+                b = b[:int(rng.integers(0, len(b)))]  # truncated anywhere, header included
+            elif k == 7:
+                b[int(rng.integers(0, min(len(b), 12)))] ^= int(rng.integers(1, 256))  # header damage
+            else:
+                for pos in rng.integers(4, len(b), size=1 + k % 3):
+                    b[int(pos)] ^= int(rng.integers(1, 256))
+            frames.append(bytes(b))
+    c = z.Context(0)
+    outs_h, sts_h, outs_d, sts_d = _both_plans(frames, c)
+    diff = [(i, sts_h[i], sts_d[i]) for i in range(len(frames)) if sts_h[i] != sts_d[i]]
+    assert not diff, diff[:20]
+    assert outs_h == outs_d
+    assert 0 < sum(1 for s in sts_d if s == 0) < len(frames)
+    c.close()
+
+
+def test_device_planner_edge_batches(ctx):
+    """Empty batch, empty frame, frame range outside the blob."""
+    rb = ctx.upload_frames(b"", [], [])
+    rb.run()
+    out, st, ln = rb.download()
+    assert len(st) == 0
+    rb.free()
+    one = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00])  # single segment, size 0, empty raw last block
+    rb = ctx.upload_frames(one + one, [0, 9, 4, 1000], [9, 9, 0, 9])
+    rb.run()
+    out, st, ln = rb.download()
+    assert [int(x) for x in st] == [0, 0, 1, 1] and [int(x) for x in ln[:2]] == [0, 0]
+    rb.free()
