@@ -138,7 +138,8 @@ __global__ void k_init(BlockSum *sums, uint32_t n_blocks)
     b.hist[1] = -2;
     b.hist[2] = -3;
     b.status = MZD_OK;
-    b.pad[0] = b.pad[1] = 0;
+    b.huf_err = 0xFFFFFFFFu;
+    b.pad = 0;
     sums[i] = b;
 }
 
@@ -343,10 +344,16 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
             br.k += nb;
             rem -= nb;
         }
-        if (rem != 0) status = MZD_ERR_HUF_BITS;         // huffman.go:257-261
-        else if (cnt != want) status = MZD_ERR_HUF_LENGTH;  // literals.go:320,332,349,366
+        // over-read: huffman.go:257-261.  Bits left over once the stream's share of the literals is full: the
+        // reference decodes on until the bits run out (huffman.go:248-255), i.e. past the length
+        // literals.go:320,332,349,366 expects -- the same sentinel as a stream that comes up short
+        if (rem < 0) status = MZD_ERR_HUF_BITS;
+        else if (rem > 0 || cnt != want) status = MZD_ERR_HUF_LENGTH;
     }
-    if (status != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, status);
+    // the reference decodes the streams of a section one after the other and stops at the first error
+    // (literals.go:299-361), and the literals before the sequences: lowest stream index wins, and
+    // k_exec lets a literals error win over the sequence stage's status
+    if (status != MZD_OK) atomicMin(&sums[t.block].huf_err, ((tid & 3u) << 8) | (uint32_t)status);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
             bs->hist[2] = h2;
             if (status != MZD_OK) atomicCAS(&bs->status, MZD_OK, status);
         }
-        if (sink == 0x9E3779B9u && lane == 77) sums[0].pad[0] = sink;  // keeps the touches alive; never true
+        if (sink == 0x9E3779B9u && lane == 77) sums[0].pad = sink;  // keeps the touches alive; never true
         return;
     }
 
@@ -1573,7 +1580,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
 
         const BlockSum bsum = sums[fr.first_block + bi];
         const uint32_t litTotal = bsum.lit_total, seqOut = bsum.out_total;
-        int err = bsum.status;
+        int err = bsum.huf_err != 0xFFFFFFFFu ? (int)(bsum.huf_err & 0xFF) : bsum.status;
         if (err == MZD_OK && litTotal > b.lit_regen) err = MZD_ERR_LITERALS;  // sequence_execution.go:27-29
         const uint32_t blockOut = seqOut + (b.lit_regen - min(litTotal, b.lit_regen));
         if (err == MZD_OK && blockOut > kBlockMax) err = MZD_ERR_CORRUPT_SIZES;
