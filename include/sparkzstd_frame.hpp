@@ -44,14 +44,48 @@ inline mzd_ctx *default_context()
     return ctx;
 }
 
+// Where the frame / block / section headers are parsed: false (default) = host planner (mzd_plan_*),
+// true = on the device (mzd_batch_upload_frames, k_parse).  Same statuses and bytes either way.
+inline bool &DevicePlanning()
+{
+    static bool on = false;
+    return on;
+}
+
 // DecodeFrames([][]byte) ([][]byte, []error): many independent frames in one device batch.
 inline std::vector<std::vector<uint8_t>> DecodeFrames(const std::vector<std::vector<uint8_t>> &frames,
                                                       std::vector<int> *status = nullptr, mzd_ctx *ctx = nullptr)
 {
     if (!ctx) ctx = default_context();
+    std::vector<std::vector<uint8_t>> res(frames.size());
+    std::vector<int> st(frames.size(), MZD_OK);
+    if (DevicePlanning()) {
+        std::vector<uint8_t> blob;
+        std::vector<uint64_t> off(frames.size()), ln(frames.size());
+        for (size_t i = 0; i < frames.size(); i++) {
+            off[i] = blob.size();
+            ln[i] = frames[i].size();
+            blob.insert(blob.end(), frames[i].begin(), frames[i].end());
+        }
+        mzd_dbatch *db = nullptr;
+        int rc = mzd_batch_upload_frames(ctx, blob.data(), blob.size(), 0, off.data(), ln.data(), (uint32_t)frames.size(), nullptr, 0, &db);
+        if (rc == MZD_OK) rc = mzd_batch_run(ctx, db, nullptr);
+        std::vector<uint8_t> out(db ? mzd_batch_out_size(db) : 0);
+        std::vector<int32_t> dst(frames.size());
+        std::vector<uint64_t> len(frames.size()), slab(frames.size());
+        if (rc == MZD_OK) rc = mzd_batch_download(ctx, db, out.data(), dst.data(), len.data());
+        if (rc == MZD_OK) rc = mzd_batch_frame_layout(db, slab.data(), nullptr);
+        mzd_batch_free(ctx, db);
+        if (rc != MZD_OK) throw Error(rc, std::string("mzd_batch_upload_frames (") + mzd_last_error(ctx) + ")");
+        for (size_t i = 0; i < frames.size(); i++) {
+            st[i] = dst[i];
+            if (st[i] == MZD_OK) res[i].assign(out.data() + slab[i], out.data() + slab[i] + len[i]);
+        }
+        if (status) *status = st;
+        return res;
+    }
     mzd_plan *plan = mzd_plan_create();
     mzd_plan_set_device_tables(plan, 1);  // FSE tables travel as normalised counts and are built on the device
-    std::vector<int> st(frames.size(), MZD_OK);
     for (size_t i = 0; i < frames.size(); i++)
         st[i] = mzd_plan_add_frame(plan, frames[i].data(), frames[i].size(), nullptr);
     const mzd_batch *b = mzd_plan_finalize(plan);
@@ -65,7 +99,6 @@ inline std::vector<std::vector<uint8_t>> DecodeFrames(const std::vector<std::vec
         mzd_plan_destroy(plan);
         throw Error(rc, std::string("mzd_decode_batch (") + mzd_last_error(ctx) + ")");
     }
-    std::vector<std::vector<uint8_t>> res(frames.size());
     for (size_t i = 0; i < frames.size(); i++) {
         if (st[i] == MZD_OK) st[i] = dst[i];
         if (st[i] == MZD_OK) {

@@ -148,7 +148,8 @@ def test_frame_reader_mirror(corpus, ctx):
     check_expected(name, sink.getvalue(), length, sha, exp)
 
 
-def test_cpp_frame_reader_verify_cli(corpus):
+@pytest.mark.parametrize("flags", [[], ["--device-plan"]])
+def test_cpp_frame_reader_verify_cli(corpus, flags):
     """The C++ mirror of FrameReader (include/sparkzstd_frame.hpp) driven like the reference's own
     harness cmd/sparkzstd/main.go: decode x.zst, compare byte for byte with x."""
     import os
@@ -160,7 +161,7 @@ def test_cpp_frame_reader_verify_cli(corpus):
     d = os.path.join(root, "tests", "golden", "decodecorpus")
     files = [os.path.join(d, name + ".zst") for name, _, _, _, exp in corpus if exp is not None]
     assert len(files) >= 30
-    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe] + flags + files, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Found no diffs in any files" in r.stdout and "Found no unexpected errors" in r.stdout
 

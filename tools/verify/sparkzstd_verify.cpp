@@ -1,6 +1,7 @@
 // sparkzstd_verify -- the reference's test harness (cmd/sparkzstd/main.go:113-195) on the device
 // path: every argument is a .zst file; the output of FrameReader is compared byte for byte with the
 // file of the same name minus ".zst" (main.go:46-111) and an average speed is printed (:177-191).
+// A first argument --device-plan parses the headers on the device too (k_parse) instead of in the host planner.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -15,7 +16,12 @@ int main(int argc, char **argv)
     sparkzstd::FrameReader comp;  // one shared reader, Reset per file (main.go:126,59)
     double seconds = 0;
     uint64_t bytes = 0;
-    for (int i = 1; i < argc; i++) {
+    int first = 1;
+    if (argc > 1 && std::string(argv[1]) == "--device-plan") {
+        sparkzstd::DevicePlanning() = true;
+        first = 2;
+    }
+    for (int i = first; i < argc; i++) {
         const std::string path = argv[i];
         const std::string original = path.substr(0, path.size() - 4);
         std::ifstream z(path, std::ios::binary), o(original, std::ios::binary);
