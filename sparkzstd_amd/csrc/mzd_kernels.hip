@@ -1062,28 +1062,39 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
 #else
             {
                 // The same step, hand-scheduled: as a lone wavefront pays ~4.4 cycles per instruction of any
-                // kind, the instruction count IS the step latency (~85 here; hipcc's version of the C++
+                // kind, the instruction count IS the step latency (~70 here; hipcc's version of the C++
                 // statement above: ~110).  The refill load of a step is issued FIRST and merged into the
                 // window one step later, after that step's cell decode: a 59-line gather takes ~450
-                // cycles to come back.  Two D registers alternate, so the loop body is the step twice.
-                // Temporaries are fixed registers v200..v231 / s[86:93].
+                // cycles to come back.  Two D registers alternate.  The loop body is the step EIGHT times,
+                // one instance per queue slot: the slot addresses are immediates, queue space is checked and
+                // the cursor published to wave P once per batch of four (stage B consumes whole batches),
+                // head1 is published and nmax checked at the end of a batch (so i may overshoot nmax by up
+                // to 3 steps of parked lanes, inside a batch whose slots are known to be free).  The last
+                // sequence of a lane is a "no go" through the per-lane countdown `left`.
+                // Temporaries are fixed registers v200..v231 / s86.
+                static_assert(kPipeDepth == 8 && kPipeBatch == 4, "the unrolled loop assumes 2 batches of 4 slots");
                 const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
                 const uint32_t sel1 = 0x0c0c0501u, sel2 = 0x0c050100u;
                 uint64_t D2 = 0;
-#define MZD_PIPE_STEP(DM, DL, TAG)                                                                          \
+                if (i & 1) D2 = D;  // odd slots take their bytes from D2
+                uint32_t left = last_i - i;  // steps before the lane's last sequence (parked lane: huge)
+                uint32_t rem1 = (uint32_t)rem + 1u;
+#define MZD_PIPE_CHECK(TAG)                                                                                 \
     "L_pipe_top" TAG "_%=:\n\t"                                                                             \
     "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
-    "s_cmp_lt_u32 s86, %[depth]\n\t"                                                                        \
+    "s_cmp_lt_u32 s86, 5\n\t" /* i + 3 - tail1 < depth */                                                   \
     "s_cbranch_scc1 L_pipe_go" TAG "_%=\n"                                                                  \
     "L_pipe_poll" TAG "_%=:\n\t"                                                                            \
     "ds_read_b32 v200, %[vzero] offset:%[o_tail1]\n\t"                                                      \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_readfirstlane_b32 %[tail], v200\n\t"                                                                 \
     "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
-    "s_cmp_lt_u32 s86, %[depth]\n\t"                                                                        \
+    "s_cmp_lt_u32 s86, 5\n\t"                                                                               \
     "s_cbranch_scc1 L_pipe_go" TAG "_%=\n\t"                                                                \
     "s_sleep 1\n\t"                                                                                         \
-    "s_branch L_pipe_poll" TAG "_%=\n"                                                                      \
+    "s_branch L_pipe_poll" TAG "_%=\n"
+#define MZD_PIPE_PROG "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"
+#define MZD_PIPE_STEP(DM, DL, TAG, PROG, QT, QP, OUT)                                                       \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
     /* next refill load first: off -= k >> 3; DL = 8 bytes at off.  Independent instructions are      */  \
     /* interleaved throughout: a dependent VALU pair costs about twice an independent one.            */  \
@@ -1096,13 +1107,13 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
     "global_load_dwordx2 " DL ", %[off], %[inb]\n\t"                                                        \
     "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
-    "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"                                                    \
+    PROG                                                                                                    \
     /* C <<= 8 * (k >> 3); k &= 7 (the bytes that come in from DM are merged below) */                      \
     "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
     "v_sub_u32 v208, 63, v206\n\t"                                                                          \
     "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
-    "v_sub_u32 v228, 63, %[k]\n\t"                                                                          \
+    "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
@@ -1119,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_add_u32 v221, v221, %[nbM0]\n\t"     /* nbM */                                                       \
     "v_add_u32 v222, v222, %[nbO0]\n\t"     /* nbO */                                                       \
     "v_add3_u32 v223, v214, v216, v215\n\t" /* o3 = exO + exM + exL */                                      \
-    "v_min_i32 v228, v228, %[rem]\n\t"      /* limit = min(63 - k, rem) */                                  \
+    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
     "v_add_u32 v225, v220, v221\n\t"        /* nbL + nbM */                                                 \
     "v_sub_u32 v224, 32, v220\n\t"          /* field positions in X: 32 - nbL, ... */                       \
     "v_add_u32 v229, v223, %[k]\n\t"        /* k + o3 */                                                    \
@@ -1127,80 +1138,111 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_sub_u32 v225, 32, v225\n\t"                                                                          \
     "v_add_u32 v230, v223, v226\n\t"        /* total */                                                     \
     "v_sub_u32 v226, 32, v226\n\t"                                                                          \
-    "v_cmp_eq_u32_e64 s[88:89], %[i], %[last]\n\t"      /* last sequence of the lane */                     \
+    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
     "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
     /* merge the bytes of the load issued one step ago: C += (DM >> 1) >> (63 - 8nb) */                     \
     "s_waitcnt vmcnt(1)\n\t"                                                                                \
     "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
-    "v_cmp_le_u32 vcc, v227, v228\n\t"                  /* go */                                            \
+    "v_cmp_lt_u32 vcc, v227, v228\n\t"                  /* go (= advance; never at the last sequence) */    \
     "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
-    "s_andn2_b64 s[90:91], vcc, s[88:89]\n\t"           /* adv = go & ~last */                              \
-    "s_andn2_b64 s[92:93], %[live], vcc\n\t"                                                                \
+    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
     "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
-    "s_or_b64 %[smask], s[92:93], s[88:89]\n\t"         /* special = last | (live & ~go) */                 \
-    "v_cndmask_b32_e64 v230, 0, v230, s[90:91]\n\t"                                                         \
+    "s_andn2_b64 %[smask], %[live], vcc\n\t"            /* special = live & ~go */                          \
+    "v_cndmask_b32 v230, 0, v230, vcc\n\t"                                                                  \
     "v_lshlrev_b64 v[210:211], v229, %[C]\n\t"          /* X = C << (k + o3): state bits from bit 63 */     \
     "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T = C << k */                                    \
-    "v_sub_u32 %[rem], %[rem], v230\n\t"                                                                    \
+    "v_sub_u32 %[rem1], %[rem1], v230\n\t"                                                                  \
     "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
-    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
+    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"                                                              \
     "v_bfe_u32 v224, v211, v224, v220\n\t" /* aL */                                                         \
     "v_bfe_u32 v225, v211, v225, v221\n\t" /* aM */                                                         \
     "v_bfe_u32 v226, v211, v226, v222\n\t" /* aO */                                                         \
-    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"                                                              \
+    "ds_write_b64 %[lane8], v[212:213] offset:" QT "\n\t"                                                   \
     "v_lshl_add_u32 v224, v217, v220, v224\n\t"                                                             \
     "v_lshl_add_u32 v225, v218, v221, v225\n\t"                                                             \
     "v_lshl_add_u32 v226, v219, v222, v226\n\t"                                                             \
-    "s_and_b32 s86, %[i], %[depthm1]\n\t"                                                                   \
-    "v_cndmask_b32_e64 %[sL], %[sL], v224, s[90:91]\n\t"                                                    \
-    "v_cndmask_b32_e64 %[sM], %[sM], v225, s[90:91]\n\t"                                                    \
-    "v_cndmask_b32_e64 %[sO], %[sO], v226, s[90:91]\n\t"                                                    \
-    "s_lshl_b32 s87, s86, 9\n\t"                                                                            \
-    "v_add_u32 v200, s87, %[lane8]\n\t"                                                                     \
-    "s_lshl_b32 s87, s86, 8\n\t"                                                                            \
-    "v_add_u32 v201, s87, %[lane4]\n\t"                                                                     \
-    "ds_write_b64 v200, v[212:213] offset:%[o_q1t]\n\t"                                                     \
-    "ds_write_b32 v201, v231 offset:%[o_q1p]\n\t"                                                           \
+    "ds_write_b32 %[lane4], v231 offset:" QP "\n\t"                                                         \
+    "v_cndmask_b32 %[sL], %[sL], v224, vcc\n\t"                                                             \
+    "v_cndmask_b32 %[sM], %[sM], v225, vcc\n\t"                                                             \
+    "v_cndmask_b32 %[sO], %[sO], v226, vcc\n\t"                                                             \
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
-    "s_cbranch_scc1 L_pipe_out" TAG "_%=\n\t"                                                               \
+    "s_cbranch_scc1 " OUT "\n\t"
+#define MZD_PIPE_PUBLISH(OUT)                                                                               \
     "v_mov_b32 v202, %[i]\n\t"                                                                              \
     "ds_write_b32 %[vzero], v202 offset:%[o_head1]\n\t"                                                     \
-    "s_cmp_lt_u32 %[i], %[nmax]\n\t"
+    "s_cmp_lt_u32 %[i], %[nmax]\n\t"                                                                        \
+    "s_cbranch_scc0 " OUT "\n\t"
+#define MZD_OUTE "L_pipe_oute_%="
+#define MZD_OUTO "L_pipe_outo_%="
                 asm volatile(
-                    // entry: %[D] holds the bytes below the window (valid), %[D2] is free
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "a")
-                    "s_cbranch_scc0 L_pipe_outa_%=\n\t"
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "b")
-                    "s_cbranch_scc1 L_pipe_topa_%=\n\t"
-                    "s_branch L_pipe_outb_%=\n"
-                    "L_pipe_outa_%=:\n\t"  // left after the first half: the current lookahead is in D2
+                    // entry: the instance of slot i % 8; the valid lookahead bytes are in D (even) / D2 (odd)
+                    "s_and_b32 s86, %[i], 7\n\t"
+                    "s_cmp_eq_u32 s86, 0\n\t"
+                    "s_cbranch_scc1 L_pipe_top0_%=\n\t"
+                    "s_cmp_eq_u32 s86, 1\n\t"
+                    "s_cbranch_scc1 L_pipe_go1_%=\n\t"
+                    "s_cmp_eq_u32 s86, 2\n\t"
+                    "s_cbranch_scc1 L_pipe_go2_%=\n\t"
+                    "s_cmp_eq_u32 s86, 3\n\t"
+                    "s_cbranch_scc1 L_pipe_go3_%=\n\t"
+                    "s_cmp_eq_u32 s86, 4\n\t"
+                    "s_cbranch_scc1 L_pipe_top4_%=\n\t"
+                    "s_cmp_eq_u32 s86, 5\n\t"
+                    "s_cbranch_scc1 L_pipe_go5_%=\n\t"
+                    "s_cmp_eq_u32 s86, 6\n\t"
+                    "s_cbranch_scc1 L_pipe_go6_%=\n\t"
+                    "s_branch L_pipe_go7_%=\n"
+                    MZD_PIPE_CHECK("0")
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "0", MZD_PIPE_PROG, "%[qt0]", "%[qp0]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "1", "", "%[qt1]", "%[qp1]", MZD_OUTO)
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "2", "", "%[qt2]", "%[qp2]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "3", "", "%[qt3]", "%[qp3]", MZD_OUTO)
+                    MZD_PIPE_PUBLISH(MZD_OUTO)
+                    MZD_PIPE_CHECK("4")
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "4", MZD_PIPE_PROG, "%[qt4]", "%[qp4]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "5", "", "%[qt5]", "%[qp5]", MZD_OUTO)
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "6", "", "%[qt6]", "%[qp6]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "7", "", "%[qt7]", "%[qp7]", MZD_OUTO)
+                    MZD_PIPE_PUBLISH(MZD_OUTO)
+                    "s_branch L_pipe_top0_%=\n"
+                    "L_pipe_oute_%=:\n\t"  // left after an even slot: the current lookahead is in D2
                     "s_waitcnt vmcnt(0)\n\t"
                     "v_lshlrev_b64 %[D], 0, %[D2]\n\t"
-                    "L_pipe_outb_%=:\n\t"
+                    "L_pipe_outo_%=:\n\t"
                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-                    : [sL] "+v"(sL), [sM] "+v"(sM), [sO] "+v"(sO), [k] "+v"(k), [rem] "+v"(rem), [off] "+v"(off),
+                    : [sL] "+v"(sL), [sM] "+v"(sM), [sO] "+v"(sO), [k] "+v"(k), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(off),
                       [C] "+v"(C), [D] "+v"(D), [D2] "+v"(D2), [i] "+s"(i), [tail] "+s"(tail_seen), [smask] "=&s"(smask)
                     : [cbL] "v"(cbL), [cbM] "v"(cbM), [cbO] "v"(cbO), [nbL0] "v"(nbL0), [nbM0] "v"(nbM0), [nbO0] "v"(nbO0),
-                      [last] "v"(last_i), [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [nmax] "s"(nmax),
+                      [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [nmax] "s"(nmax),
                       [live] "s"(livemask), [inb] "s"(inb), [sel1] "s"(sel1), [sel2] "s"(sel2),
-                      [depth] "n"(kPipeDepth), [depthm1] "n"(kPipeDepth - 1),
                       [o_tail1] "n"(512 + offsetof(PipeShared, tail1)), [o_head1] "n"(512 + offsetof(PipeShared, head1)),
-                      [o_prog] "n"(512 + offsetof(PipeShared, progress)), [o_q1t] "n"(512 + offsetof(PipeShared, q1t)),
-                      [o_q1p] "n"(512 + offsetof(PipeShared, q1p))
-                    : "memory", "vcc", "scc", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+                      [o_prog] "n"(512 + offsetof(PipeShared, progress)),
+#define MZD_QT(S) (512 + offsetof(PipeShared, q1t) + (S) * 512)
+#define MZD_QP(S) (512 + offsetof(PipeShared, q1p) + (S) * 256)
+                      [qt0] "n"(MZD_QT(0)), [qt1] "n"(MZD_QT(1)), [qt2] "n"(MZD_QT(2)), [qt3] "n"(MZD_QT(3)),
+                      [qt4] "n"(MZD_QT(4)), [qt5] "n"(MZD_QT(5)), [qt6] "n"(MZD_QT(6)), [qt7] "n"(MZD_QT(7)),
+                      [qp0] "n"(MZD_QP(0)), [qp1] "n"(MZD_QP(1)), [qp2] "n"(MZD_QP(2)), [qp3] "n"(MZD_QP(3)),
+                      [qp4] "n"(MZD_QP(4)), [qp5] "n"(MZD_QP(5)), [qp6] "n"(MZD_QP(6)), [qp7] "n"(MZD_QP(7))
+                    : "memory", "vcc", "scc", "s86",
                       "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v210", "v211", "v212", "v213",
                       "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
                       "v227", "v228", "v229", "v230", "v231");
 #undef MZD_PIPE_STEP
+#undef MZD_PIPE_CHECK
+#undef MZD_PIPE_PUBLISH
+#undef MZD_PIPE_PROG
+#undef MZD_OUTE
+#undef MZD_OUTO
+#undef MZD_QT
+#undef MZD_QP
+                rem = (int)(rem1 - 1u);
             }
 #endif
-            if (smask) {
-                // i has moved past the step; lanes in smask have not done it yet
-                general_step(i - 1, ((smask >> lane) & 1) != 0);
-                asm volatile("" ::: "memory");
-                __hip_atomic_store(&shs->head1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            // i has moved past the step; lanes in smask have not done it yet
+            if (smask) general_step(i - 1, ((smask >> lane) & 1) != 0);
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->head1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 #ifdef MZD_PIPE_PROF
         if (blockIdx.x == 0 && lane == 0)
