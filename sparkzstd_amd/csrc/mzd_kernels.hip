@@ -1076,7 +1076,8 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                 const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
                 const uint32_t sel1 = 0x0c0c0501u, sel2 = 0x0c050100u;
                 uint64_t D2 = 0;
-                if (i & 1) D2 = D;  // odd slots take their bytes from D2
+                uint32_t sLb = sL, sMb = sM, sOb = sO;  // the states alternate between two register sets
+                if (i & 1) D2 = D;  // odd slots take their bytes from D2 (and their states from set b)
                 uint32_t left = last_i - i;  // steps before the lane's last sequence (parked lane: huge)
                 uint32_t rem1 = (uint32_t)rem + 1u;
 #define MZD_PIPE_CHECK(TAG)                                                                                 \
@@ -1094,15 +1095,15 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_pipe_poll" TAG "_%=\n"
 #define MZD_PIPE_PROG "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"
-#define MZD_PIPE_STEP(DM, DL, TAG, PROG, QT, QP, OUT)                                                       \
+#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, PROG, QT, QP, OUT)                                                      \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
     /* next refill load first: off -= k >> 3; DL = 8 bytes at off.  Independent instructions are      */  \
     /* interleaved throughout: a dependent VALU pair costs about twice an independent one.            */  \
     "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
-    "v_lshl_add_u32 v200, %[sL], 1, %[cbL]\n\t"                                                             \
-    "v_lshl_add_u32 v201, %[sM], 1, %[cbM]\n\t"                                                             \
+    "v_lshl_add_u32 v200, %[sL" SA "], 1, %[cbL]\n\t"                                                       \
+    "v_lshl_add_u32 v201, %[sM" SA "], 1, %[cbM]\n\t"                                                       \
     "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
-    "v_lshl_add_u32 v202, %[sO], 1, %[cbO]\n\t"                                                             \
+    "v_lshl_add_u32 v202, %[sO" SA "], 1, %[cbO]\n\t"                                                       \
     "ds_read_u16 v203, v200\n\t" /* xl */                                                                   \
     "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
     "global_load_dwordx2 " DL ", %[off], %[inb]\n\t"                                                        \
@@ -1158,13 +1159,12 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_bfe_u32 v225, v211, v225, v221\n\t" /* aM */                                                         \
     "v_bfe_u32 v226, v211, v226, v222\n\t" /* aO */                                                         \
     "ds_write_b64 %[lane8], v[212:213] offset:" QT "\n\t"                                                   \
-    "v_lshl_add_u32 v224, v217, v220, v224\n\t"                                                             \
-    "v_lshl_add_u32 v225, v218, v221, v225\n\t"                                                             \
-    "v_lshl_add_u32 v226, v219, v222, v226\n\t"                                                             \
+    /* the new states go to the OTHER register set (a lane that does not advance is special: the exit     */ \
+    /* code picks per lane; a parked lane's state is never used)                                          */ \
+    "v_lshl_add_u32 %[sL" SB "], v217, v220, v224\n\t"                                                      \
+    "v_lshl_add_u32 %[sM" SB "], v218, v221, v225\n\t"                                                      \
+    "v_lshl_add_u32 %[sO" SB "], v219, v222, v226\n\t"                                                      \
     "ds_write_b32 %[lane4], v231 offset:" QP "\n\t"                                                         \
-    "v_cndmask_b32 %[sL], %[sL], v224, vcc\n\t"                                                             \
-    "v_cndmask_b32 %[sM], %[sM], v225, vcc\n\t"                                                             \
-    "v_cndmask_b32 %[sO], %[sO], v226, vcc\n\t"                                                             \
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
     "s_cbranch_scc1 " OUT "\n\t"
@@ -1194,24 +1194,32 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "s_cbranch_scc1 L_pipe_go6_%=\n\t"
                     "s_branch L_pipe_go7_%=\n"
                     MZD_PIPE_CHECK("0")
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "0", MZD_PIPE_PROG, "%[qt0]", "%[qp0]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "1", "", "%[qt1]", "%[qp1]", MZD_OUTO)
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "2", "", "%[qt2]", "%[qp2]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "3", "", "%[qt3]", "%[qp3]", MZD_OUTO)
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "0", MZD_PIPE_PROG, "%[qt0]", "%[qp0]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "1", "", "%[qt1]", "%[qp1]", MZD_OUTO)
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "2", "", "%[qt2]", "%[qp2]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "3", "", "%[qt3]", "%[qp3]", MZD_OUTO)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     MZD_PIPE_CHECK("4")
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "4", MZD_PIPE_PROG, "%[qt4]", "%[qp4]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "5", "", "%[qt5]", "%[qp5]", MZD_OUTO)
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "6", "", "%[qt6]", "%[qp6]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "7", "", "%[qt7]", "%[qp7]", MZD_OUTO)
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "4", MZD_PIPE_PROG, "%[qt4]", "%[qp4]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "5", "", "%[qt5]", "%[qp5]", MZD_OUTO)
+                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "6", "", "%[qt6]", "%[qp6]", MZD_OUTE)
+                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "7", "", "%[qt7]", "%[qp7]", MZD_OUTO)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     "s_branch L_pipe_top0_%=\n"
-                    "L_pipe_oute_%=:\n\t"  // left after an even slot: the current lookahead is in D2
+                    "L_pipe_oute_%=:\n\t"  // left after an even slot: the current lookahead is in D2, the new states in set b
                     "s_waitcnt vmcnt(0)\n\t"
                     "v_lshlrev_b64 %[D], 0, %[D2]\n\t"
-                    "L_pipe_outo_%=:\n\t"
+                    "v_cndmask_b32 %[sLa], %[sLa], %[sLb], vcc\n\t"  // vcc is still the last step's "go"
+                    "v_cndmask_b32 %[sMa], %[sMa], %[sMb], vcc\n\t"
+                    "v_cndmask_b32 %[sOa], %[sOa], %[sOb], vcc\n\t"
+                    "s_branch L_pipe_done_%=\n"
+                    "L_pipe_outo_%=:\n\t"  // after an odd slot: old states in set b, new ones in set a
+                    "v_cndmask_b32 %[sLa], %[sLb], %[sLa], vcc\n\t"
+                    "v_cndmask_b32 %[sMa], %[sMb], %[sMa], vcc\n\t"
+                    "v_cndmask_b32 %[sOa], %[sOb], %[sOa], vcc\n"
+                    "L_pipe_done_%=:\n\t"
                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-                    : [sL] "+v"(sL), [sM] "+v"(sM), [sO] "+v"(sO), [k] "+v"(k), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(off),
+                    : [sLa] "+v"(sL), [sMa] "+v"(sM), [sOa] "+v"(sO), [sLb] "+v"(sLb), [sMb] "+v"(sMb), [sOb] "+v"(sOb), [k] "+v"(k), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(off),
                       [C] "+v"(C), [D] "+v"(D), [D2] "+v"(D2), [i] "+s"(i), [tail] "+s"(tail_seen), [smask] "=&s"(smask)
                     : [cbL] "v"(cbL), [cbM] "v"(cbM), [cbO] "v"(cbO), [nbL0] "v"(nbL0), [nbM0] "v"(nbM0), [nbO0] "v"(nbO0),
                       [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [nmax] "s"(nmax),
