@@ -1115,6 +1115,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_sub_u32 v208, 63, v206\n\t"                                                                          \
     "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
     "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
+    /* in the shadow of the cell reads: the step limit */                                                   \
+    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
+    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
@@ -1131,7 +1134,6 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_add_u32 v221, v221, %[nbM0]\n\t"     /* nbM */                                                       \
     "v_add_u32 v222, v222, %[nbO0]\n\t"     /* nbO */                                                       \
     "v_add3_u32 v223, v214, v216, v215\n\t" /* o3 = exO + exM + exL */                                      \
-    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
     "v_add_u32 v225, v220, v221\n\t"        /* nbL + nbM */                                                 \
     "v_sub_u32 v224, 32, v220\n\t"          /* field positions in X: 32 - nbL, ... */                       \
     "v_add_u32 v229, v223, %[k]\n\t"        /* k + o3 */                                                    \
@@ -1139,9 +1141,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_sub_u32 v225, 32, v225\n\t"                                                                          \
     "v_add_u32 v230, v223, v226\n\t"        /* total */                                                     \
     "v_sub_u32 v226, 32, v226\n\t"                                                                          \
-    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
     "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
-    /* merge the bytes of the load issued one step ago: C += (DM >> 1) >> (63 - 8nb) */                     \
+    /* merge the bytes of the load issued one step ago (as late as possible: a 59-line gather takes       */ \
+    /* ~450 cycles): C += (DM >> 1) >> (63 - 8nb)                                                         */ \
     "s_waitcnt vmcnt(1)\n\t"                                                                                \
     "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
     "v_cmp_lt_u32 vcc, v227, v228\n\t"                  /* go (= advance; never at the last sequence) */    \
