@@ -240,6 +240,40 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
 /* size of the resident batch's output blob, and the slab (offset, capacity) of every frame in it */
 uint64_t mzd_batch_out_size(mzd_dbatch *db);
 int mzd_batch_frame_layout(mzd_dbatch *db, uint64_t *out_offset, uint64_t *out_capacity);
+/* ------------------------------------------------------------------ streaming
+ * Batches of frames pipelined through `depth` recycled device slots on three HIP streams: while batch k
+ * decodes, batch k+1 is copied in and planned (k_parse) and batch k-1 is copied out.  The slots' device
+ * buffers only grow, so a steady stream allocates nothing.  This is what a streaming consumer of
+ * sparkzstd's io.Reader API (framereader.go:51-109) sits on when it has many frames to read: the Go shim's
+ * DecodeFrames becomes submit ... wait.  Host buffers should be pinned (mzd_host_alloc) -- with pageable
+ * memory the copies are staged by the runtime and do not overlap.  PCIe, not HBM, bounds this path. */
+typedef struct mzd_stream mzd_stream;
+mzd_stream *mzd_stream_create(mzd_ctx *ctx, uint32_t depth /* 1..8; 2 = double buffering */, int *err);
+void mzd_stream_destroy(mzd_stream *s);
+/* Enqueues one batch (arguments as mzd_batch_upload_frames, host memory).  The regenerated frames are written
+ * to out_host (out_cap bytes; each frame's slab is its bound rounded up to 256 -- MZD_ERR_DST_FULL if the
+ * batch needs more).  `in`, the offset arrays and out_host must stay valid until the ticket is collected.
+ * Returns MZD_ERR_INVALID_ARG when all `depth` slots hold uncollected tickets. */
+int mzd_stream_submit(mzd_stream *s, const uint8_t *in, uint64_t in_size, const uint64_t *frame_off,
+                      const uint64_t *frame_len, uint32_t n_frames, uint8_t *out_host, uint64_t out_cap,
+                      uint64_t *ticket);
+/* Blocks until batch `ticket` is in out_host; per frame: status, regenerated length, offset in out_host
+ * (any of the three may be NULL).  Tickets may be collected in any order. */
+int mzd_stream_wait(mzd_stream *s, uint64_t ticket, int32_t *status, uint64_t *out_len, uint64_t *out_offset);
+/* pinned host memory for the stream's buffers */
+void *mzd_host_alloc(uint64_t bytes);
+void mzd_host_free(void *p);
+
+/* Frame boundaries of a buffer of concatenated frames (multi-frame files, skippable frames: the reference
+ * reads one frame per reader and stops, framereader.go:84-94).  Host code, header walk only (magic, frame
+ * header, block headers).  Fills frame_off / frame_len / out_bound (upper bound of the regenerated size: the
+ * declared content size capped by what the blocks can produce) for up to `cap` frames; *n_frames = frames
+ * found (may exceed cap: call again); *out_total = bytes of output blob the frames need (bounds rounded up
+ * to 256) -- what mzd_stream_submit / a caller-owned output of mzd_batch_upload_frames must provide.
+ * Returns MZD_OK, or the defect that ended the walk (frames before it are reported). */
+int mzd_split_frames(const uint8_t *blob, uint64_t size, uint64_t *frame_off, uint64_t *frame_len,
+                     uint64_t *out_bound, uint32_t cap, uint32_t *n_frames, uint64_t *out_total);
+
 /* The hot path: launches the kernels for every frame of the batch on `stream`
  * (a hipStream_t, or NULL for the context's stream). Asynchronous.
  * Replaces huffman.go:221, sequences.go:126, sequence_execution.go:14 and the

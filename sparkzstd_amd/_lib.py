@@ -23,6 +23,7 @@ EXPORTS = [
     "mzd_plan_destroy", "mzd_plan_reset", "mzd_plan_add_frame", "mzd_plan_add_frames",
     "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table", "mzd_batch_read_huf_table",
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
+    "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
 ]
 
 
@@ -133,6 +134,13 @@ def load():
         "mzd_batch_read_fse_table": (i32, [vp, vp, u32, vp, u32]),
         "mzd_batch_read_huf_table": (i32, [vp, vp, u32, vp, u32]),
         "mzd_batch_upload_frames": (i32, [vp, vp, u64, u32, vp, vp, u32, vp, u64, ctypes.POINTER(vp)]),
+        "mzd_stream_create": (vp, [vp, u32, ctypes.POINTER(i32)]),
+        "mzd_stream_destroy": (None, [vp]),
+        "mzd_stream_submit": (i32, [vp, vp, u64, vp, vp, u32, vp, u64, ctypes.POINTER(u64)]),
+        "mzd_stream_wait": (i32, [vp, u64, vp, vp, vp]),
+        "mzd_host_alloc": (vp, [u64]),
+        "mzd_host_free": (None, [vp]),
+        "mzd_split_frames": (i32, [vp, u64, vp, vp, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u64)]),
         "mzd_batch_out_size": (u64, [vp]),
         "mzd_batch_frame_layout": (i32, [vp, vp, vp]),
         "mzd_plan_destroy": (None, [vp]),

@@ -251,6 +251,96 @@ def default_context(device: int = 0) -> Context:
     return _default_ctx[device]
 
 
+def split_frames(blob):
+    """Frame boundaries of a buffer of concatenated (and skippable) frames, by header walk on the host
+    (mzd_split_frames).  -> (rc, frame_off uint64[n], frame_len uint64[n], out_bound uint64[n], out_total)"""
+    L = _lib.load()
+    arr = blob if isinstance(blob, np.ndarray) else np.frombuffer(blob, dtype=np.uint8)
+    n, total = ctypes.c_uint32(), ctypes.c_uint64()
+    cap = 1024
+    while True:
+        off, ln, ob = (np.zeros(cap, dtype=np.uint64) for _ in range(3))
+        rc = L.mzd_split_frames(arr.ctypes.data if arr.size else None, arr.size, off.ctypes.data, ln.ctypes.data, ob.ctypes.data,
+                                cap, ctypes.byref(n), ctypes.byref(total))
+        if n.value <= cap:
+            return rc, off[:n.value].copy(), ln[:n.value].copy(), ob[:n.value].copy(), int(total.value)
+        cap = n.value
+
+
+class PinnedBuffer:
+    """Pinned host memory (mzd_host_alloc) as a numpy uint8 array `.a`; free() or garbage collection releases it."""
+
+    def __init__(self, nbytes: int):
+        self._L = _lib.load()
+        self._p = self._L.mzd_host_alloc(max(int(nbytes), 1))
+        if not self._p:
+            raise MemoryError("mzd_host_alloc failed")
+        self.a = np.ctypeslib.as_array((ctypes.c_uint8 * max(int(nbytes), 1)).from_address(self._p))[:int(nbytes)]
+
+    def free(self):
+        if self._p:
+            self.a = None
+            self._L.mzd_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """Batches of frames pipelined through `depth` device slots (mzd_stream_*): copy-in +
+    device planning of batch k+1 and copy-out of batch k-1 overlap the decode of batch k."""
+
+    def __init__(self, ctx: Context, depth: int = 2):
+        self.ctx = ctx
+        err = ctypes.c_int()
+        self._s = ctx._L.mzd_stream_create(ctx._c, depth, ctypes.byref(err))
+        if not self._s:
+            raise MzdError(err.value, "mzd_stream_create")
+        self._keep = {}
+
+    def submit(self, blob: np.ndarray, frame_off, frame_len, out: np.ndarray) -> int:
+        """blob / out: uint8 arrays (pinned for real overlap: PinnedBuffer(...).a).  -> ticket"""
+        off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+        ln = np.ascontiguousarray(frame_len, dtype=np.uint64)
+        t = ctypes.c_uint64()
+        rc = self.ctx._L.mzd_stream_submit(self._s, blob.ctypes.data if blob.size else None, blob.size,
+                                           off.ctypes.data if off.size else None, ln.ctypes.data if ln.size else None, off.size,
+                                           out.ctypes.data if out.size else None, out.size, ctypes.byref(t))
+        if rc:
+            raise MzdError(rc, "mzd_stream_submit: " + self.ctx.last_error())
+        self._keep[t.value] = (blob, off, ln, out)
+        return t.value
+
+    def wait(self, ticket: int):
+        """-> (status int32[n], out_len uint64[n], out_offset uint64[n]) of the batch; its bytes are in `out`"""
+        blob, off, ln, out = self._keep[ticket]
+        n = off.size
+        st = np.zeros(n, dtype=np.int32)
+        ol = np.zeros(n, dtype=np.uint64)
+        oo = np.zeros(n, dtype=np.uint64)
+        rc = self.ctx._L.mzd_stream_wait(self._s, ticket, st.ctypes.data if n else None, ol.ctypes.data if n else None,
+                                         oo.ctypes.data if n else None)
+        if rc:
+            raise MzdError(rc, "mzd_stream_wait: " + self.ctx.last_error())
+        del self._keep[ticket]
+        return st, ol, oo
+
+    def close(self):
+        if self._s:
+            self.ctx._L.mzd_stream_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def decode_frames(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):
     """Decodes independent zstd frames (list of bytes) in ONE device batch.
     -> (outputs: list of bytes-or-None, statuses: list of int).  The batched analogue of calling

@@ -34,7 +34,40 @@ struct mzd_ctx {
     bool attr_set = false;
 };
 
+// temporaries of the device-side planning pass (kept by a streaming slot, freed at once otherwise)
+struct ParseTemps {
+    uint64_t *d_foff = nullptr, *d_flen = nullptr;
+    mzd::ParseScratch *d_scratch = nullptr;
+    mzd::FrameCount *d_counts = nullptr;
+    mzd::FrameBase *d_bases = nullptr;
+    mzd::FseBuildDesc *d_fse_tabs = nullptr;
+    uint32_t *d_fse_src = nullptr;
+    mzd::HufBuildDesc *d_huf_tabs = nullptr;
+    uint16_t *d_huf_src = nullptr;
+    size_t cap_foff = 0, cap_flen = 0, cap_scratch = 0, cap_counts = 0, cap_bases = 0, cap_fse_tabs = 0, cap_fse_src = 0,
+           cap_huf_tabs = 0, cap_huf_src = 0;
+};
+static void free_parse_temps(ParseTemps &t)
+{
+    (void)hipFree(t.d_foff);
+    (void)hipFree(t.d_flen);
+    (void)hipFree(t.d_scratch);
+    (void)hipFree(t.d_counts);
+    (void)hipFree(t.d_bases);
+    (void)hipFree(t.d_fse_tabs);
+    (void)hipFree(t.d_fse_src);
+    (void)hipFree(t.d_huf_tabs);
+    (void)hipFree(t.d_huf_src);
+    t = ParseTemps();
+}
+struct DevCaps {  // bytes allocated behind the pointers of a recycled batch (0 = exact / unknown)
+    size_t in = 0, out = 0, frames = 0, blocks = 0, sums = 0, huf_tasks = 0, seq_tasks = 0, fse = 0, huf = 0, recs = 0, tiles = 0,
+           lit = 0, status = 0, out_len = 0;
+};
+
 struct mzd_dbatch {
+    ParseTemps tmp;
+    DevCaps cap;
     // device memory
     uint8_t *d_in_alloc = nullptr;  // owned input allocation (with padding) or null when adopted
     const uint8_t *d_in = nullptr;
@@ -203,6 +236,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_litbuf);
     (void)hipFree(db->d_status);
     (void)hipFree(db->d_out_len);
+    free_parse_temps(db->tmp);
     delete db;
 }
 
@@ -602,42 +636,25 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     return MZD_OK;
 }
 
-// ---- planning on the device: see mzd_parse.hip
-int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, uint32_t flags, const uint64_t *frame_off,
-                            const uint64_t *frame_len, uint32_t n_frames, uint8_t *out_dev, uint64_t out_dev_size, mzd_dbatch **out)
+// ---- planning on the device: see mzd_parse.hip.  `reuse` (streaming): a batch whose device
+// buffers are recycled -- they only grow -- so that a steady stream of batches allocates nothing; all
+// device work goes to `s`, and the host only waits for `s` (other streams keep decoding).
+static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, uint32_t flags, const uint64_t *frame_off,
+                              const uint64_t *frame_len, uint32_t n_frames, uint8_t *out_dev, uint64_t out_dev_size,
+                              mzd_dbatch *reuse, hipStream_t s, mzd_dbatch **out)
 {
-    if (!ctx || !out || (!in && in_size) || ((!frame_off || !frame_len) && n_frames) ||
-        (flags & ~(uint32_t)(MZD_BATCH_IN_ON_DEVICE | MZD_BATCH_OUT_ON_DEVICE)) || ((flags & MZD_BATCH_OUT_ON_DEVICE) && !out_dev))
-        return MZD_ERR_INVALID_ARG;
-    *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    mzd_dbatch *db = new mzd_dbatch();
-    // temporaries of the planning pass
-    uint64_t *d_foff = nullptr, *d_flen = nullptr;
-    ParseScratch *d_scratch = nullptr;
-    FrameCount *d_counts = nullptr;
-    FrameBase *d_bases = nullptr;
-    FseBuildDesc *d_fse_tabs = nullptr;
-    uint32_t *d_fse_src = nullptr;
-    HufBuildDesc *d_huf_tabs = nullptr;
-    uint16_t *d_huf_src = nullptr;
+    mzd_dbatch *db = reuse ? reuse : new mzd_dbatch();
+    ParseTemps &tp = db->tmp;
     hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr, t4 = nullptr;
     auto cleanup = [&]() {
-        (void)hipFree(d_foff);
-        (void)hipFree(d_flen);
-        (void)hipFree(d_scratch);
-        (void)hipFree(d_counts);
-        (void)hipFree(d_bases);
-        (void)hipFree(d_fse_tabs);
-        (void)hipFree(d_fse_src);
-        (void)hipFree(d_huf_tabs);
-        (void)hipFree(d_huf_src);
         for (hipEvent_t e : {t0, t1, t2, t3, t4})
             if (e) (void)hipEventDestroy(e);
+        if (!reuse) free_parse_temps(tp);
     };
     auto fail = [&](int code) {
         cleanup();
-        mzd_batch_free(ctx, db);
+        if (!reuse) mzd_batch_free(ctx, db);
         return code;
     };
 #define HIP_OR_FAIL(expr)                                                             \
@@ -648,41 +665,55 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
             return fail(MZD_ERR_DEVICE);                                              \
         }                                                                             \
     } while (0)
-    hipStream_t s = ctx->stream;
+    // grow-only device buffer: (pointer, capacity in bytes) pairs live in the batch
+#define ENSURE(ptr, cap, bytes)                                                        \
+    do {                                                                               \
+        const size_t need_ = (size_t)(bytes);                                          \
+        if ((cap) < need_ || !(ptr)) {                                                 \
+            if (ptr) (void)hipFree((void *)(ptr));                                     \
+            (ptr) = nullptr;                                                           \
+            (cap) = 0;                                                                 \
+            const size_t get_ = reuse ? need_ + need_ / 4 + 256 : need_;               \
+            HIP_OR_FAIL(hipMalloc((void **)&(ptr), get_));                             \
+            (cap) = get_;                                                              \
+        }                                                                              \
+    } while (0)
     for (hipEvent_t *e : {&t0, &t1, &t2, &t3, &t4}) HIP_OR_FAIL(hipEventCreate(e));
     // ---- the compressed frames
     if (flags & MZD_BATCH_IN_ON_DEVICE) {
         db->d_in = in;
     } else {
-        HIP_OR_FAIL(hipMalloc((void **)&db->d_in_alloc, in_size + 2 * MZD_IN_PAD));
-        HIP_OR_FAIL(hipMemset(db->d_in_alloc, 0, MZD_IN_PAD));
-        HIP_OR_FAIL(hipMemset(db->d_in_alloc + MZD_IN_PAD + in_size, 0, MZD_IN_PAD));
-        if (in_size) HIP_OR_FAIL(hipMemcpy(db->d_in_alloc + MZD_IN_PAD, in, in_size, hipMemcpyHostToDevice));
+        ENSURE(db->d_in_alloc, db->cap.in, in_size + 2 * MZD_IN_PAD);
+        HIP_OR_FAIL(hipMemsetAsync(db->d_in_alloc, 0, MZD_IN_PAD, s));
+        HIP_OR_FAIL(hipMemsetAsync(db->d_in_alloc + MZD_IN_PAD + in_size, 0, MZD_IN_PAD, s));
+        if (in_size) HIP_OR_FAIL(hipMemcpyAsync(db->d_in_alloc + MZD_IN_PAD, in, in_size, hipMemcpyHostToDevice, s));
         db->d_in = db->d_in_alloc + MZD_IN_PAD;
     }
     db->in_size = in_size;
     db->n_frames = n_frames;
     const size_t nf1 = std::max<size_t>(n_frames, 1);
-    HIP_OR_FAIL(hipMalloc((void **)&d_foff, nf1 * 8));
-    HIP_OR_FAIL(hipMalloc((void **)&d_flen, nf1 * 8));
+    ENSURE(tp.d_foff, tp.cap_foff, nf1 * 8);
+    ENSURE(tp.d_flen, tp.cap_flen, nf1 * 8);
     if (n_frames) {
-        HIP_OR_FAIL(hipMemcpy(d_foff, frame_off, (size_t)n_frames * 8, hipMemcpyHostToDevice));
-        HIP_OR_FAIL(hipMemcpy(d_flen, frame_len, (size_t)n_frames * 8, hipMemcpyHostToDevice));
+        HIP_OR_FAIL(hipMemcpyAsync(tp.d_foff, frame_off, (size_t)n_frames * 8, hipMemcpyHostToDevice, s));
+        HIP_OR_FAIL(hipMemcpyAsync(tp.d_flen, frame_len, (size_t)n_frames * 8, hipMemcpyHostToDevice, s));
     }
     // one lane per frame, grid-stride; every lane owns a ParseScratch
     const uint32_t max_wg = (uint32_t)std::max(ctx->num_cus, 1) * 2;
     const uint32_t n_wg = std::max<uint32_t>(1, std::min<uint32_t>((n_frames + 63) / 64, max_wg));
-    HIP_OR_FAIL(hipMalloc((void **)&d_scratch, (size_t)n_wg * 64 * sizeof(ParseScratch)));
-    HIP_OR_FAIL(hipMalloc((void **)&d_counts, nf1 * sizeof(FrameCount)));
-    HIP_OR_FAIL(hipMalloc((void **)&d_bases, nf1 * sizeof(FrameBase)));
+    ENSURE(tp.d_scratch, tp.cap_scratch, (size_t)n_wg * 64 * sizeof(ParseScratch));
+    ENSURE(tp.d_counts, tp.cap_counts, nf1 * sizeof(FrameCount));
+    ENSURE(tp.d_bases, tp.cap_bases, nf1 * sizeof(FrameBase));
     ParseOut po{};
     // ---- pass 0: what does every frame need?
     HIP_OR_FAIL(hipEventRecord(t0, s));
-    if (n_frames) k_parse<0><<<n_wg, 64, 0, s>>>(db->d_in, in_size, d_foff, d_flen, n_frames, d_scratch, d_counts, d_bases, po);
+    if (n_frames)
+        k_parse<0><<<n_wg, 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, n_frames, tp.d_scratch, tp.d_counts, tp.d_bases, po);
     HIP_OR_FAIL(hipEventRecord(t1, s));
     std::vector<FrameCount> counts(n_frames);
+    if (n_frames)
+        HIP_OR_FAIL(hipMemcpyAsync(counts.data(), tp.d_counts, (size_t)n_frames * sizeof(FrameCount), hipMemcpyDeviceToHost, s));
     HIP_OR_FAIL(hipStreamSynchronize(s));
-    if (n_frames) HIP_OR_FAIL(hipMemcpy(counts.data(), d_counts, (size_t)n_frames * sizeof(FrameCount), hipMemcpyDeviceToHost));
     // ---- offsets (exclusive prefix sums).  Tables 0..2 are the predefined ones (predefined.go), kept as
     // their normalised counts and built by k_fse_build like every other table.
     static const int16_t kDef[3][53] = {
@@ -693,8 +724,8 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
     static const int kDefN[3] = {36, 29, 53}, kDefLog[3] = {6, 5, 6};  // by MZD_FSE_*: LL, OF, ML
     std::vector<FrameBase> bases(n_frames);
     std::vector<uint32_t> frame_seq_task(n_frames + 1, 0);
-    db->frame_out_off.resize(n_frames);
-    db->frame_out_cap.resize(n_frames);
+    db->frame_out_off.assign(n_frames, 0);
+    db->frame_out_cap.assign(n_frames, 0);
     uint64_t n_blocks = 0, n_seq = 0, n_hufb = 0, n_fse_tab = 3, n_fse_src = 0, n_fse_dev = 0, n_huf_tab = 0, n_huf_src = 0, n_huf_dev = 0,
              n_tile = 0, n_rec = 0, lit_total = 0, out_at = 0;
     uint32_t predef_src[3];
@@ -772,53 +803,55 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
         }
         db->d_out = out_dev;
     } else {
-        HIP_OR_FAIL(hipMalloc((void **)&db->d_out, std::max<uint64_t>(out_at, 16)));
+        if (!db->own_out) { db->d_out = nullptr; db->cap.out = 0; }
+        ENSURE(db->d_out, db->cap.out, std::max<uint64_t>(out_at, 16));
         db->own_out = true;
     }
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_frames, nf1 * sizeof(DFrame)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_blocks, std::max<uint64_t>(n_blocks, 1) * sizeof(DBlock)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_sums, std::max<uint64_t>(n_blocks, 1) * sizeof(BlockSum)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_tasks, std::max<uint64_t>(4 * n_hufb, 1) * sizeof(HufTask)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_seq_tasks, std::max<uint64_t>(n_seq, 1) * sizeof(SeqTask)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_fse_entries, std::max<uint64_t>(n_fse_dev, 1) * 4));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_huf_entries, std::max<uint64_t>(n_huf_dev, 2) * 2 + 8));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_recs, std::max<uint64_t>(n_rec, 1) * 8));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_tiles, std::max<uint64_t>(n_tile, 1) * sizeof(TileBase)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_status, nf1 * sizeof(int32_t)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_out_len, nf1 * sizeof(uint64_t)));
-    HIP_OR_FAIL(hipMemset(db->d_status, 0xFF, nf1 * sizeof(int32_t)));
-    HIP_OR_FAIL(hipMemset(db->d_out_len, 0, nf1 * sizeof(uint64_t)));
-    HIP_OR_FAIL(hipMalloc((void **)&d_fse_tabs, n_fse_tab * sizeof(FseBuildDesc)));
-    HIP_OR_FAIL(hipMalloc((void **)&d_fse_src, n_fse_src * 4));
-    HIP_OR_FAIL(hipMalloc((void **)&d_huf_tabs, std::max<uint64_t>(n_huf_tab, 1) * sizeof(HufBuildDesc)));
-    HIP_OR_FAIL(hipMalloc((void **)&d_huf_src, std::max<uint64_t>(n_huf_src, 1) * 2));
-    {  // the predefined tables' counts
-        FseBuildDesc pd[3];
-        std::vector<uint32_t> src(predef_src[2] + (kDefN[2] + 1) / 2, 0);
-        for (int k = 0; k < 3; k++) {
-            pd[k] = FseBuildDesc{predef_src[k], po.predef_off[k], (uint8_t)kDefLog[k], (uint8_t)kDefN[k], 1, 0};
-            for (int i = 0; i < kDefN[k]; i++) src[predef_src[k] + i / 2] |= (uint32_t)(uint16_t)kDef[k][i] << (16 * (i & 1));
-        }
-        HIP_OR_FAIL(hipMemcpy(d_fse_tabs, pd, sizeof pd, hipMemcpyHostToDevice));
-        HIP_OR_FAIL(hipMemcpy(d_fse_src, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    ENSURE(db->d_frames, db->cap.frames, nf1 * sizeof(DFrame));
+    ENSURE(db->d_blocks, db->cap.blocks, std::max<uint64_t>(n_blocks, 1) * sizeof(DBlock));
+    ENSURE(db->d_sums, db->cap.sums, std::max<uint64_t>(n_blocks, 1) * sizeof(BlockSum));
+    ENSURE(db->d_huf_tasks, db->cap.huf_tasks, std::max<uint64_t>(4 * n_hufb, 1) * sizeof(HufTask));
+    ENSURE(db->d_seq_tasks, db->cap.seq_tasks, std::max<uint64_t>(n_seq, 1) * sizeof(SeqTask));
+    ENSURE(db->d_fse_entries, db->cap.fse, std::max<uint64_t>(n_fse_dev, 1) * 4);
+    ENSURE(db->d_huf_entries, db->cap.huf, std::max<uint64_t>(n_huf_dev, 2) * 2 + 8);
+    ENSURE(db->d_recs, db->cap.recs, std::max<uint64_t>(n_rec, 1) * 8);
+    ENSURE(db->d_tiles, db->cap.tiles, std::max<uint64_t>(n_tile, 1) * sizeof(TileBase));
+    ENSURE(db->d_litbuf, db->cap.lit, lit_total + 64);
+    ENSURE(db->d_status, db->cap.status, nf1 * sizeof(int32_t));
+    ENSURE(db->d_out_len, db->cap.out_len, nf1 * sizeof(uint64_t));
+    HIP_OR_FAIL(hipMemsetAsync(db->d_status, 0xFF, nf1 * sizeof(int32_t), s));
+    HIP_OR_FAIL(hipMemsetAsync(db->d_out_len, 0, nf1 * sizeof(uint64_t), s));
+    ENSURE(tp.d_fse_tabs, tp.cap_fse_tabs, n_fse_tab * sizeof(FseBuildDesc));
+    ENSURE(tp.d_fse_src, tp.cap_fse_src, n_fse_src * 4);
+    ENSURE(tp.d_huf_tabs, tp.cap_huf_tabs, std::max<uint64_t>(n_huf_tab, 1) * sizeof(HufBuildDesc));
+    ENSURE(tp.d_huf_src, tp.cap_huf_src, std::max<uint64_t>(n_huf_src, 1) * 2);
+    // the predefined tables' counts (host arrays must outlive the async copies: synchronised below)
+    FseBuildDesc pd[3];
+    std::vector<uint32_t> psrc(predef_src[2] + (kDefN[2] + 1) / 2, 0);
+    for (int k = 0; k < 3; k++) {
+        pd[k] = FseBuildDesc{predef_src[k], po.predef_off[k], (uint8_t)kDefLog[k], (uint8_t)kDefN[k], 1, 0};
+        for (int i = 0; i < kDefN[k]; i++) psrc[predef_src[k] + i / 2] |= (uint32_t)(uint16_t)kDef[k][i] << (16 * (i & 1));
     }
-    if (n_frames) HIP_OR_FAIL(hipMemcpy(d_bases, bases.data(), (size_t)n_frames * sizeof(FrameBase), hipMemcpyHostToDevice));
+    HIP_OR_FAIL(hipMemcpyAsync(tp.d_fse_tabs, pd, sizeof pd, hipMemcpyHostToDevice, s));
+    HIP_OR_FAIL(hipMemcpyAsync(tp.d_fse_src, psrc.data(), psrc.size() * 4, hipMemcpyHostToDevice, s));
+    if (n_frames) HIP_OR_FAIL(hipMemcpyAsync(tp.d_bases, bases.data(), (size_t)n_frames * sizeof(FrameBase), hipMemcpyHostToDevice, s));
     po.frames = db->d_frames;
     po.blocks = db->d_blocks;
     po.huf_tasks = db->d_huf_tasks;
     po.seq_tasks = db->d_seq_tasks;
-    po.fse_tabs = d_fse_tabs;
-    po.fse_src = d_fse_src;
-    po.huf_tabs = d_huf_tabs;
-    po.huf_src = d_huf_src;
+    po.fse_tabs = tp.d_fse_tabs;
+    po.fse_src = tp.d_fse_src;
+    po.huf_tabs = tp.d_huf_tabs;
+    po.huf_src = tp.d_huf_src;
     // ---- pass 1: write the work lists and the table build descriptors; then build the tables
     HIP_OR_FAIL(hipEventRecord(t2, s));
-    if (n_frames) k_parse<1><<<n_wg, 64, 0, s>>>(db->d_in, in_size, d_foff, d_flen, n_frames, d_scratch, d_counts, d_bases, po);
+    if (n_frames)
+        k_parse<1><<<n_wg, 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, n_frames, tp.d_scratch, tp.d_counts, tp.d_bases, po);
     HIP_OR_FAIL(hipEventRecord(t3, s));
-    k_fse_build<<<(uint32_t)((n_fse_tab + 63) / 64), 64, 0, s>>>(d_fse_tabs, (uint32_t)n_fse_tab, d_fse_src, db->d_fse_entries);
+    k_fse_build<<<(uint32_t)((n_fse_tab + 63) / 64), 64, 0, s>>>(tp.d_fse_tabs, (uint32_t)n_fse_tab, tp.d_fse_src, db->d_fse_entries);
     HIP_OR_FAIL(hipEventRecord(t4, s));
-    if (n_huf_tab) k_huf_build<<<(uint32_t)((n_huf_tab + 63) / 64), 64, 0, s>>>(d_huf_tabs, (uint32_t)n_huf_tab, d_huf_src, db->d_huf_entries);
+    if (n_huf_tab)
+        k_huf_build<<<(uint32_t)((n_huf_tab + 63) / 64), 64, 0, s>>>(tp.d_huf_tabs, (uint32_t)n_huf_tab, tp.d_huf_src, db->d_huf_entries);
     HIP_OR_FAIL(hipGetLastError());
     HIP_OR_FAIL(hipStreamSynchronize(s));
     float a = 0, b2 = 0, c2 = 0;
@@ -830,11 +863,166 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
     db->n_fse_built = (uint32_t)n_fse_tab;
     db->n_huf_built = (uint32_t)n_huf_tab;
     db->n_fse_entries = (uint32_t)n_fse_dev;
+    db->fse_dev_off.clear();  // table read-back (mzd_batch_read_*_table) is a host-planned-batch facility
+    db->huf_dev_off.clear();
 #undef HIP_OR_FAIL
+#undef ENSURE
     cleanup();
     *out = db;
     return MZD_OK;
 }
+
+int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, uint32_t flags, const uint64_t *frame_off,
+                            const uint64_t *frame_len, uint32_t n_frames, uint8_t *out_dev, uint64_t out_dev_size, mzd_dbatch **out)
+{
+    if (!ctx || !out || (!in && in_size) || ((!frame_off || !frame_len) && n_frames) ||
+        (flags & ~(uint32_t)(MZD_BATCH_IN_ON_DEVICE | MZD_BATCH_OUT_ON_DEVICE)) || ((flags & MZD_BATCH_OUT_ON_DEVICE) && !out_dev))
+        return MZD_ERR_INVALID_ARG;
+    *out = nullptr;
+    return upload_frames_impl(ctx, in, in_size, flags, frame_off, frame_len, n_frames, out_dev, out_dev_size, nullptr, ctx->stream, out);
+}
+
+// ---- streaming: batches of frames pipelined through `depth` recycled device slots
+struct mzd_stream {
+    mzd_ctx *ctx = nullptr;
+    struct Slot {
+        mzd_dbatch *db = nullptr;
+        hipEvent_t ready = nullptr, run_done = nullptr, done = nullptr;
+        int32_t *h_status = nullptr;  // pinned
+        uint64_t *h_out_len = nullptr;
+        size_t h_cap = 0;
+        uint64_t ticket = 0;  // 0 = free
+        uint32_t n_frames = 0;
+        int error = MZD_OK;
+    };
+    std::vector<Slot> slots;
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    uint64_t next_ticket = 1;
+};
+
+mzd_stream *mzd_stream_create(mzd_ctx *ctx, uint32_t depth, int *err)
+{
+    if (!ctx || depth < 1 || depth > 8) {
+        if (err) *err = MZD_ERR_INVALID_ARG;
+        return nullptr;
+    }
+    (void)hipSetDevice(ctx->device);
+    mzd_stream *st = new mzd_stream();
+    st->ctx = ctx;
+    st->slots.resize(depth);
+    bool ok = hipStreamCreateWithFlags(&st->s_in, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->s_run, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->s_out, hipStreamNonBlocking) == hipSuccess;
+    for (auto &sl : st->slots) {
+        sl.db = new mzd_dbatch();
+        ok = ok && hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.run_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        if (err) *err = MZD_ERR_DEVICE;
+        mzd_stream_destroy(st);
+        return nullptr;
+    }
+    if (err) *err = MZD_OK;
+    return st;
+}
+
+void mzd_stream_destroy(mzd_stream *st)
+{
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &sl : st->slots) {
+        if (sl.db) mzd_batch_free(st->ctx, sl.db);
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.run_done) (void)hipEventDestroy(sl.run_done);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        (void)hipHostFree(sl.h_status);
+        (void)hipHostFree(sl.h_out_len);
+    }
+    if (st->s_in) (void)hipStreamDestroy(st->s_in);
+    if (st->s_run) (void)hipStreamDestroy(st->s_run);
+    if (st->s_out) (void)hipStreamDestroy(st->s_out);
+    delete st;
+}
+
+int mzd_stream_submit(mzd_stream *st, const uint8_t *in, uint64_t in_size, const uint64_t *frame_off, const uint64_t *frame_len,
+                      uint32_t n_frames, uint8_t *out_host, uint64_t out_cap, uint64_t *ticket)
+{
+    if (!st || !ticket || (!in && in_size) || ((!frame_off || !frame_len) && n_frames) || (!out_host && out_cap)) return MZD_ERR_INVALID_ARG;
+    mzd_ctx *ctx = st->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mzd_stream::Slot &sl = st->slots[(st->next_ticket - 1) % st->slots.size()];
+    if (sl.ticket != 0) {
+        ctx->last_error = "mzd_stream_submit: all slots in flight; collect the oldest ticket with mzd_stream_wait first";
+        return MZD_ERR_INVALID_ARG;
+    }
+    if (sl.h_cap < n_frames) {
+        (void)hipHostFree(sl.h_status);
+        (void)hipHostFree(sl.h_out_len);
+        sl.h_status = nullptr;
+        sl.h_out_len = nullptr;
+        sl.h_cap = 0;
+        const size_t n = (size_t)n_frames + n_frames / 4 + 64;
+        HIP_TRY(ctx, hipHostMalloc((void **)&sl.h_status, n * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc((void **)&sl.h_out_len, n * sizeof(uint64_t), hipHostMallocDefault));
+        sl.h_cap = n;
+    }
+    // copy-in + planning on s_in: the host waits for s_in only; s_run keeps decoding the previous batches
+    mzd_dbatch *db = nullptr;
+    int rc = upload_frames_impl(ctx, in, in_size, 0, frame_off, frame_len, n_frames, nullptr, 0, sl.db, st->s_in, &db);
+    if (rc != MZD_OK) return rc;
+    if (db->out_size > out_cap + 256) {  // the 256 bytes of tail slack are not copied back
+        ctx->last_error = "mzd_stream_submit: out_host too small: the frames need " + std::to_string(db->out_size - 256) + " bytes";
+        return MZD_ERR_DST_FULL;
+    }
+    HIP_TRY(ctx, hipEventRecord(sl.ready, st->s_in));
+    HIP_TRY(ctx, hipStreamWaitEvent(st->s_run, sl.ready, 0));
+    rc = mzd_batch_run(ctx, db, st->s_run);
+    if (rc != MZD_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(sl.run_done, st->s_run));
+    // copy-out on s_out: overlaps the next batch's decode and copy-in
+    HIP_TRY(ctx, hipStreamWaitEvent(st->s_out, sl.run_done, 0));
+    if (db->out_size > 256) HIP_TRY(ctx, hipMemcpyAsync(out_host, db->d_out, db->out_size - 256, hipMemcpyDeviceToHost, st->s_out));
+    if (n_frames) {
+        HIP_TRY(ctx, hipMemcpyAsync(sl.h_status, db->d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, st->s_out));
+        HIP_TRY(ctx, hipMemcpyAsync(sl.h_out_len, db->d_out_len, (size_t)n_frames * sizeof(uint64_t), hipMemcpyDeviceToHost, st->s_out));
+    }
+    HIP_TRY(ctx, hipEventRecord(sl.done, st->s_out));
+    sl.n_frames = n_frames;
+    sl.ticket = st->next_ticket++;
+    *ticket = sl.ticket;
+    return MZD_OK;
+}
+
+int mzd_stream_wait(mzd_stream *st, uint64_t ticket, int32_t *status, uint64_t *out_len, uint64_t *out_offset)
+{
+    if (!st || ticket == 0) return MZD_ERR_INVALID_ARG;
+    mzd_ctx *ctx = st->ctx;
+    mzd_stream::Slot &sl = st->slots[(ticket - 1) % st->slots.size()];
+    if (sl.ticket != ticket) {
+        ctx->last_error = "mzd_stream_wait: unknown or already collected ticket";
+        return MZD_ERR_INVALID_ARG;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(sl.done));
+    for (uint32_t f = 0; f < sl.n_frames; f++) {
+        if (status) status[f] = sl.h_status[f];
+        if (out_len) out_len[f] = sl.h_out_len[f];
+        if (out_offset) out_offset[f] = sl.db->frame_out_off[f];
+    }
+    sl.ticket = 0;
+    return MZD_OK;
+}
+
+void *mzd_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void mzd_host_free(void *p) { (void)hipHostFree(p); }
 
 uint64_t mzd_batch_out_size(mzd_dbatch *db) { return db ? db->out_size : 0; }
 

@@ -754,4 +754,80 @@ int mzd_plan_frame_status(const mzd_plan *p, uint32_t i)
     return p->frame_status[i];
 }
 
+// ---- frame boundaries of a stream of concatenated frames (multi-frame streams, skippable
+// frames).  Header walk only: magic, frame header (frame.go:23-127), block headers (block.go:33-55); nothing
+// of a block's content is looked at.  The reference itself reads ONE frame per reader and leaves what follows
+// (framereader.go:84-94): this is the splitter a caller with a multi-frame file puts in front.
+int mzd_split_frames(const uint8_t *blob, uint64_t size, uint64_t *frame_off, uint64_t *frame_len, uint64_t *out_bound,
+                     uint32_t cap, uint32_t *n_frames, uint64_t *out_total)
+{
+    if ((!blob && size) || !n_frames) return MZD_ERR_INVALID_ARG;
+    uint64_t p = 0, total = 0;
+    uint32_t n = 0;
+    int rc = MZD_OK;
+    while (p < size) {
+        if (size - p < 4) { rc = MZD_ERR_TRUNCATED; break; }
+        const uint32_t magic = blob[p] | ((uint32_t)blob[p + 1] << 8) | ((uint32_t)blob[p + 2] << 16) | ((uint32_t)blob[p + 3] << 24);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame: 4-byte size, then that many bytes of user data
+            if (size - p < 8) { rc = MZD_ERR_TRUNCATED; break; }
+            const uint64_t sk = blob[p + 4] | ((uint64_t)blob[p + 5] << 8) | ((uint64_t)blob[p + 6] << 16) | ((uint64_t)blob[p + 7] << 24);
+            if (size - p - 8 < sk) { rc = MZD_ERR_TRUNCATED; break; }
+            p += 8 + sk;
+            continue;
+        }
+        if (magic != 0xFD2FB528u) { rc = MZD_ERR_MAGIC; break; }
+        const uint64_t begin = p;
+        if (size - p < 5) { rc = MZD_ERR_TRUNCATED; break; }
+        const uint8_t fhd = blob[p + 4];
+        p += 5;
+        const bool single = (fhd >> 5) & 1;
+        static const int kDict[4] = {0, 1, 2, 4};
+        const int fcs_flag = fhd >> 6;
+        const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
+        const uint64_t hdr = (uint64_t)(!single) + kDict[fhd & 3] + fcs_bytes;
+        if (size - p < hdr) { rc = MZD_ERR_TRUNCATED; break; }
+        uint64_t content = MZD_UNKNOWN_SIZE;
+        if (fcs_bytes) {
+            const uint64_t q = p + hdr - fcs_bytes;
+            uint64_t v = 0;
+            for (int i = 0; i < fcs_bytes; i++) v |= (uint64_t)blob[q + i] << (8 * i);
+            if (fcs_bytes == 2) v += 256;
+            content = v;
+        }
+        p += hdr;
+        uint64_t bound = 0;
+        bool last = false;
+        while (!last) {
+            if (size - p < 3) { rc = MZD_ERR_TRUNCATED; break; }
+            const uint32_t h = blob[p] | ((uint32_t)blob[p + 1] << 8) | ((uint32_t)blob[p + 2] << 16);
+            p += 3;
+            last = h & 1;
+            const int type = (h >> 1) & 3;
+            const uint32_t bs = h >> 3;
+            if (type == 3) { rc = MZD_ERR_BLOCK_TYPE; break; }
+            if (bs > kBlockMax) { rc = MZD_ERR_BLOCK_SIZE; break; }
+            const uint64_t payload = type == MZD_BLOCK_RLE ? 1 : bs;
+            if (size - p < payload) { rc = MZD_ERR_TRUNCATED; break; }
+            p += payload;
+            bound += type == MZD_BLOCK_COMPRESSED ? kBlockMax : bs;
+        }
+        if (rc) break;
+        if ((fhd >> 2) & 1) {  // content checksum: belongs to the frame
+            if (size - p < 4) { rc = MZD_ERR_TRUNCATED; break; }
+            p += 4;
+        }
+        const uint64_t ob = content != MZD_UNKNOWN_SIZE ? std::min(content, bound) : bound;
+        if (n < cap) {
+            if (frame_off) frame_off[n] = begin;
+            if (frame_len) frame_len[n] = p - begin;
+            if (out_bound) out_bound[n] = ob;
+        }
+        total += (ob + 255) & ~255ull;
+        n++;
+    }
+    *n_frames = n;  // frames found before the end / the defect; more than `cap`: call again with larger arrays
+    if (out_total) *out_total = total;
+    return rc;
+}
+
 }  // extern "C"

@@ -484,3 +484,68 @@ def test_device_planner_edge_batches(ctx):
     out, st, ln = rb.download()
     assert [int(x) for x in st] == [0, 0, 1, 1] and [int(x) for x in ln[:2]] == [0, 0]
     rb.free()
+
+
+# ---- streaming: batches pipelined through recycled device slots
+
+@pytest.mark.parametrize("depth,pinned", [(2, True), (3, False), (1, True)])
+def test_stream_of_batches_equals_one_shot_decode(corpus, ctx, depth, pinned):
+    """Seven batches of different sizes and content (corpus slices, synthetic frames, a batch with damaged
+    frames, an empty batch) through a `depth`-slot stream: every frame's status and bytes equal the
+    one-shot decode; slots are recycled (batch sizes go up and down)."""
+    from tools import synth_binding as sb
+    frames_all = [comp for _, comp, *_ in corpus]
+    blob4, off4, ln4, _, _ = sb.make_batch(4, 21, 40, threads=4)
+    syn = [bytes(blob4[o:o + l]) for o, l in zip(off4, ln4)]
+    bad = [bytes(bytearray(f[:len(f) // 2])) for f in frames_all[10:14]] + [b"\x28\xb5\x2f\xfd"]
+    batches = [frames_all[:30], syn[:25], frames_all[30:100] + syn[25:], [], bad + frames_all[5:9], syn[:3], frames_all[50:60]]
+    want = [z.decode_frames(b, ctx) if b else ([], []) for b in batches]
+    st = z.Stream(ctx, depth=depth)
+    bufs, inflight, results = [], [], {}
+    for bi, b in enumerate(batches):
+        if len(inflight) == depth:
+            k, t, out = inflight.pop(0)
+            results[k] = (st.wait(t), out)
+        ln = np.array([len(f) for f in b], dtype=np.uint64)
+        off = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.uint64) if len(b) else np.zeros(0, dtype=np.uint64)
+        raw = np.frombuffer(b"".join(b), dtype=np.uint8)
+        cap = z.split_frames(raw)[4] if all(sx != 1 and sx != 2 for sx in want[bi][1]) else 64 << 20
+        if pinned:
+            pin, pout = z.PinnedBuffer(raw.size), z.PinnedBuffer(cap)
+            pin.a[:] = raw
+            bufs += [pin, pout]
+            src, out = pin.a, pout.a
+        else:
+            src, out = raw.copy(), np.zeros(cap, dtype=np.uint8)
+        inflight.append((bi, st.submit(src, off, ln, out), out))
+    for k, t, out in inflight:
+        results[k] = (st.wait(t), out)
+    for bi, b in enumerate(batches):
+        (status, out_len, out_off), out = results[bi]
+        outs_w, sts_w = want[bi]
+        assert [int(x) for x in status] == sts_w, bi
+        for i in range(len(b)):
+            if sts_w[i] == 0:
+                o, n = int(out_off[i]), int(out_len[i])
+                assert out[o:o + n].tobytes() == outs_w[i], (bi, i)
+    st.close()
+
+
+def test_stream_refuses_overcommit_and_small_output(corpus, ctx):
+    f = corpus[3][1]
+    blob = np.frombuffer(f, dtype=np.uint8).copy()
+    off, ln = np.array([0], dtype=np.uint64), np.array([len(f)], dtype=np.uint64)
+    st = z.Stream(ctx, depth=1)
+    out = np.zeros(z.split_frames(f)[4], dtype=np.uint8)  # exactly what the frame's bound needs
+    t = st.submit(blob, off, ln, out)
+    with pytest.raises(z.MzdError) as e:
+        st.submit(blob, off, ln, out)  # the only slot holds an uncollected ticket
+    assert e.value.code == 101
+    status, out_len, out_off = st.wait(t)
+    assert int(status[0]) == 0
+    with pytest.raises(z.MzdError) as e:
+        st.submit(blob, off, ln, np.zeros(16, dtype=np.uint8))
+    assert e.value.code == 15
+    t = st.submit(blob, off, ln, out)  # the slot is usable again
+    assert int(st.wait(t)[0][0]) == 0
+    st.close()

@@ -172,3 +172,35 @@ def test_planner_records_content_checksums(corpus, oracle):
         if exp is not None:
             assert fd.checksum == oracle.xxh64(exp) & 0xFFFFFFFF
     p.close()
+
+
+def test_split_frames_multi_frame_stream_with_skippable_frames(corpus):
+    """mzd_split_frames: concatenated frames + skippable frames -> the frames' extents (checksum included) and
+    output bounds equal to the planner's; defects end the walk with their status."""
+    import numpy as np
+    frames = [comp for _, comp, *_ in corpus]
+    skip = bytes([0x5A, 0x2A, 0x4D, 0x18, 3, 0, 0, 0]) + b"abc"
+    blob = skip + frames[0] + skip + skip + b"".join(frames[1:]) + skip
+    rc, off, ln, ob, total = z.split_frames(blob)
+    assert rc == 0 and len(off) == len(frames)
+    for f, o, l in zip(frames, off, ln):
+        assert blob[int(o):int(o) + int(l)] == f
+    p = z.Plan()
+    for f in frames:
+        assert p.add_frame(f)[0] == 0
+    b = p.finalize()
+    assert [int(x) for x in ob] == [int(b.frames[i].out_capacity) for i in range(b.n_frames)]
+    assert total == b.out_size - 256
+    p.close()
+    assert z.split_frames(b"")[0] == 0 and len(z.split_frames(b"")[1]) == 0
+    rc, off, *_ = z.split_frames(blob[:-2])  # the last skippable frame is cut
+    assert rc == 1 and len(off) == len(frames)
+    rc, off, *_ = z.split_frames(frames[0] + b"\x00\x01\x02\x03" + frames[1])
+    assert rc == 2 and len(off) == 1
+    cut = frames[2][:len(frames[2]) // 2]
+    rc, off, *_ = z.split_frames(frames[0] + cut)
+    assert rc == 1 and len(off) == 1
+    # more frames than the first guess of the binding (1024)
+    many = frames[1] * 1500
+    rc, off, ln, _, _ = z.split_frames(many)
+    assert rc == 0 and len(off) == 1500 and int(off[-1]) == 1499 * len(frames[1])
