@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -883,6 +884,7 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
 }
 
 // ---- streaming: batches of frames pipelined through `depth` recycled device slots
+
 struct mzd_stream {
     mzd_ctx *ctx = nullptr;
     struct Slot {
@@ -898,6 +900,7 @@ struct mzd_stream {
     std::vector<Slot> slots;
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
     uint64_t next_ticket = 1;
+
 };
 
 mzd_stream *mzd_stream_create(mzd_ctx *ctx, uint32_t depth, int *err)
@@ -910,8 +913,12 @@ mzd_stream *mzd_stream_create(mzd_ctx *ctx, uint32_t depth, int *err)
     mzd_stream *st = new mzd_stream();
     st->ctx = ctx;
     st->slots.resize(depth);
+
+    // The runtime multiplexes HIP streams onto a few hardware queues (4 by default: GPU_MAX_HW_QUEUES) and two
+    // streams on one queue serialise: the decode runs on the context's own stream (+ its helper stream), so a
+    // streaming context uses exactly four.
+    st->s_run = ctx->stream;
     bool ok = hipStreamCreateWithFlags(&st->s_in, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&st->s_run, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&st->s_out, hipStreamNonBlocking) == hipSuccess;
     for (auto &sl : st->slots) {
         sl.db = new mzd_dbatch();
@@ -942,7 +949,6 @@ void mzd_stream_destroy(mzd_stream *st)
         (void)hipHostFree(sl.h_out_len);
     }
     if (st->s_in) (void)hipStreamDestroy(st->s_in);
-    if (st->s_run) (void)hipStreamDestroy(st->s_run);
     if (st->s_out) (void)hipStreamDestroy(st->s_out);
     delete st;
 }
@@ -984,6 +990,7 @@ int mzd_stream_submit(mzd_stream *st, const uint8_t *in, uint64_t in_size, const
     HIP_TRY(ctx, hipEventRecord(sl.run_done, st->s_run));
     // copy-out on s_out: overlaps the next batch's decode and copy-in
     HIP_TRY(ctx, hipStreamWaitEvent(st->s_out, sl.run_done, 0));
+    // (a shader copy kernel into mapped host memory was tried instead of the DMA engine: 25.3 vs 20.9 ms per batch)
     if (db->out_size > 256) HIP_TRY(ctx, hipMemcpyAsync(out_host, db->d_out, db->out_size - 256, hipMemcpyDeviceToHost, st->s_out));
     if (n_frames) {
         HIP_TRY(ctx, hipMemcpyAsync(sl.h_status, db->d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, st->s_out));
