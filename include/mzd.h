@@ -210,7 +210,9 @@ typedef struct mzd_options {
     uint32_t verify_checksum; /* 1: frames that carry a content checksum are verified on the device after the
                                  pass (k_xxh64); a mismatch gives MZD_ERR_CHECKSUM.  Default 0:
                                  the reference never checks it */
-    uint32_t reserved[1];
+    uint32_t seq_window_kib;  /* testing: k_seq_pipe launches cover at most this many KiB of the input blob (default:
+                                 just under 4 GiB -- the kernel addresses bitstreams with 32-bit offsets from the
+                                 window; larger blobs are decoded window by window) */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

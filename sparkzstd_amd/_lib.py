@@ -84,7 +84,7 @@ class Batch(ctypes.Structure):
 class Options(ctypes.Structure):
     _fields_ = [("seq_variant", ctypes.c_uint32), ("exec_threads", ctypes.c_uint32),
                 ("exec_chunk", ctypes.c_uint32), ("huf_min_lds", ctypes.c_uint32), ("no_split", ctypes.c_uint32),
-                ("assume_cus", ctypes.c_uint32), ("verify_checksum", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
+                ("assume_cus", ctypes.c_uint32), ("verify_checksum", ctypes.c_uint32), ("seq_window_kib", ctypes.c_uint32)]
 
 
 class BatchStats(ctypes.Structure):

@@ -97,6 +97,7 @@ struct mzd_dbatch {
     uint32_t huf_slot_cells = 2;
     std::vector<uint32_t> frame_seq_task;  // host: index of the first SeqTask of every frame (+ total)
     std::vector<uint64_t> frame_out_off, frame_out_cap;  // host: output slab of every frame
+    std::vector<uint64_t> frame_in_lo, frame_in_hi;      // host: extent of the frame's sequence bitstreams in the blob (lo > hi: none)
     float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
     uint64_t out_size = 0;
     mzd_batch_stats stats{};
@@ -363,6 +364,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     mzd_batch_stats st{};
     auto in_range = [&](uint64_t off, uint64_t n) { return off <= b->in_size && n <= b->in_size - off; };
     std::vector<uint32_t> frame_seq_task(b->n_frames + 1, 0);
+    std::vector<uint64_t> frame_in_lo(b->n_frames, ~0ull), frame_in_hi(b->n_frames, 0);
     for (uint32_t f = 0; f < b->n_frames; f++) {
         frame_seq_task[f] = (uint32_t)seq_tasks.size();
         const mzd_frame_desc &fd = b->frames[f];
@@ -384,6 +386,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         }
         st.out_capacity_bytes += fd.out_capacity;
         bool seen_seq = false;
+        uint64_t in_lo = ~0ull, in_hi = 0;
         for (uint32_t k = 0; k < fd.n_blocks && df.plan_status == MZD_OK; k++) {
             const uint32_t bi = fd.first_block + k;
             const mzd_block_desc &bd = b->blocks[bi];
@@ -470,6 +473,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                 t.ml_log = b->fse_tables[bd.ml_table].acc_log;
                 t.hist_known = seen_seq ? 0 : 1;
                 seen_seq = true;
+                in_lo = std::min<uint64_t>(in_lo, bd.seq_off);
+                in_hi = std::max<uint64_t>(in_hi, bd.seq_off + bd.seq_size);
                 seq_tasks.push_back(t);
                 d.rec_off = rec_total;
                 d.tile_off = (uint32_t)tile_total;
@@ -481,6 +486,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
             }
         }
         if (df.plan_status != MZD_OK) df.n_blocks = 0;
+        frame_in_lo[f] = in_lo;
+        frame_in_hi[f] = in_hi;
     }
     frame_seq_task[b->n_frames] = (uint32_t)seq_tasks.size();
     st.table_bytes = (uint64_t)b->n_fse_entries * 4 + (uint64_t)b->n_huf_entries * 2;
@@ -494,6 +501,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->n_seq_tasks = (uint32_t)seq_tasks.size();
     db->huf_slot_cells = 1u << max_huf_bits;
     db->frame_seq_task = std::move(frame_seq_task);
+    db->frame_in_lo = std::move(frame_in_lo);
+    db->frame_in_hi = std::move(frame_in_hi);
     db->frame_out_off.resize(b->n_frames);
     db->frame_out_cap.resize(b->n_frames);
     for (uint32_t f = 0; f < b->n_frames; f++) {
@@ -727,6 +736,8 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     std::vector<uint32_t> frame_seq_task(n_frames + 1, 0);
     db->frame_out_off.assign(n_frames, 0);
     db->frame_out_cap.assign(n_frames, 0);
+    db->frame_in_lo.assign(n_frames, ~0ull);
+    db->frame_in_hi.assign(n_frames, 0);
     uint64_t n_blocks = 0, n_seq = 0, n_hufb = 0, n_fse_tab = 3, n_fse_src = 0, n_fse_dev = 0, n_huf_tab = 0, n_huf_src = 0, n_huf_dev = 0,
              n_tile = 0, n_rec = 0, lit_total = 0, out_at = 0;
     uint32_t predef_src[3];
@@ -756,6 +767,10 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         fb.out_off = out_at;
         fb.out_cap = c.status == MZD_OK ? c.out_bound : 0;
         frame_seq_task[f] = (uint32_t)n_seq;
+        if (c.n_seq && frame_off[f] <= in_size && frame_len[f] <= in_size - frame_off[f]) {
+            db->frame_in_lo[f] = frame_off[f];
+            db->frame_in_hi[f] = frame_off[f] + frame_len[f];
+        }
         db->frame_out_off[f] = fb.out_off;
         db->frame_out_cap[f] = fb.out_cap;
         out_at += (fb.out_cap + 255) & ~255ull;
@@ -1076,12 +1091,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // seq_variant 0 (default): k_seq_pipe; 1: k_seq, the two-wavefront kernel.  k_seq_pipe addresses the
     // bitstreams with 32-bit offsets from the blob's front slack, so larger blobs take k_seq as well.
     if (ctx->opt.seq_variant > 1) return MZD_ERR_INVALID_ARG;
-    const bool pipe = ctx->opt.seq_variant == 0 && db->in_size + 2 * MZD_IN_PAD < (1ull << 32);
+    const bool pipe = ctx->opt.seq_variant == 0;
     // k_seq_pipe: two chains fewer than fit, so that ~6 KiB of every CU's LDS stay free and the small
     // k_huf workgroups run in k_seq's shadow instead of queueing for whole CUs (measured: -0.9 ms per step)
     const uint32_t nch = pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16;
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
-    uint32_t fA = db->n_frames, tA = db->n_seq_tasks;
+    uint32_t fA = db->n_frames;
     if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
         const uint64_t lim = (db->n_seq_tasks / per_round) * per_round;
         // last frame boundary at or below the limit
@@ -1093,7 +1108,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
         if (lo > 0 && lo < db->n_frames) {
             fA = lo;
-            tA = db->frame_seq_task[lo];
         }
     }
     const bool split = fA < db->n_frames;
@@ -1110,19 +1124,48 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         ctx->run_split[ctx->runs] = split;
         ev = ctx->ev.data() + ctx->runs * kEvPerRun;
     }
-    auto launch_seq = [&](uint32_t first, uint32_t count) {
+    auto launch_seq_tasks = [&](uint32_t first, uint32_t count, bool use_pipe, uint64_t base) {
         if (!count) return;
-        if (pipe) {
+        if (use_pipe) {
             // chains per workgroup: as few as fill the same number of rounds (a lone chain per CU when
             // the batch is small -- the step latency does not depend on the number of lanes)
             const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1);
             const uint64_t rounds = (count + cus * nch - 1) / (cus * nch);
             const uint32_t per_wg = (uint32_t)std::min<uint64_t>(nch, (count + rounds * cus - 1) / (rounds * cus));
             k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
-                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg);
+                db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base);
         } else {
             k_seq<<<(count + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+        }
+    };
+    // Sequence decode of the frames [f0, f1).  k_seq_pipe addresses the bitstreams with 32-bit offsets from the
+    // front slack of a WINDOW of the blob: the frames are cut into runs whose bitstreams span < 4 GiB, one launch
+    // per run (one run unless the blob is that large); a single frame beyond that takes k_seq.
+    auto launch_seq = [&](uint32_t f0, uint32_t f1) {
+        if (!pipe) {
+            launch_seq_tasks(db->frame_seq_task[f0], db->frame_seq_task[f1] - db->frame_seq_task[f0], false, 0);
+            return;
+        }
+        const uint64_t kWindow = ctx->opt.seq_window_kib ? (uint64_t)ctx->opt.seq_window_kib << 10 : (1ull << 32) - 2 * MZD_IN_PAD - 4096;
+        uint32_t g = f0;
+        while (g < f1) {
+            uint64_t lo = ~0ull, hi = 0;
+            uint32_t e = g;
+            for (; e < f1; e++) {
+                if (db->frame_in_lo[e] > db->frame_in_hi[e]) continue;  // no sequences
+                const uint64_t nlo = std::min(lo, db->frame_in_lo[e]), nhi = std::max(hi, db->frame_in_hi[e]);
+                if (nhi - nlo > kWindow) break;
+                lo = nlo;
+                hi = nhi;
+            }
+            if (e == g) {  // one frame wider than the window
+                launch_seq_tasks(db->frame_seq_task[g], db->frame_seq_task[g + 1] - db->frame_seq_task[g], false, 0);
+                e = g + 1;
+            } else {
+                launch_seq_tasks(db->frame_seq_task[g], db->frame_seq_task[e] - db->frame_seq_task[g], true, lo == ~0ull ? 0 : lo);
+            }
+            g = e;
         }
     };
     auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {
@@ -1148,7 +1191,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_init_done, s));
     // k_seq(head) is submitted FIRST so that its workgroups (nearly all of a CU's LDS each) claim the
     // CUs; k_huf's small workgroups then fill what is left instead of delaying them
-    launch_seq(0, tA);
+    launch_seq(0, fA);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
     HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
@@ -1166,7 +1209,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         launch_verify(s2, 0, fA);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[10], s2));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s2));
-        launch_seq(tA, db->n_seq_tasks - tA);
+        launch_seq(fA, db->n_frames);
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
         launch_exec(s, fA, db->n_frames - fA);

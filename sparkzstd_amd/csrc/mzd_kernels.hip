@@ -806,7 +806,7 @@ __device__ __forceinline__ uint32_t sub_sat(uint32_t a, uint32_t b)  // max(0, a
 __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                                   uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                                   uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
-                                                  BlockSum *sums, uint32_t nch)
+                                                  BlockSum *sums, uint32_t nch, uint64_t in_base)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *CTc = (uint32_t *)smem;  // [2][64] by c6: base(24) | extra(8)   (predefined.go:5-20,36-50)
@@ -817,11 +817,14 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     const uint32_t tid = blockIdx.x * nch + lane;
     const bool has = (uint32_t)lane < nch && tid < n_tasks;
     SeqTask t;
-    if (has) t = tasks[tid];
-    else {
+    if (has) {
+        t = tasks[tid];
+        t.in_off -= in_base;  // the launch's window of the blob: bitstreams are addressed with 32-bit offsets from it
+    } else {
         t.n_seq = 0; t.in_size = 0; t.ll_off = t.of_off = t.ml_off = 0; t.ll_log = t.of_log = t.ml_log = 0;
         t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
     }
+    in += in_base;
     if (wave == 3) {
         CTc[lane] = 0;
         CTc[64 + lane] = 0;
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         // ================= stage A: the serial chain =================
         const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
         // bit window as in SeqBits, with the refill address as a 32-bit offset from the start of the
-        // blob's front slack (the whole blob, slack included, is < 4 GiB for this kernel: mzd_batch_run checks)
+        // window's front slack (a launch covers < 4 GiB of the blob, slack included: mzd_batch_run cuts the windows)
         const uint8_t *inb = in - MZD_IN_PAD;
         uint64_t C = 0, D = 0;
         uint32_t off = 0;

@@ -549,3 +549,19 @@ def test_stream_refuses_overcommit_and_small_output(corpus, ctx):
     t = st.submit(blob, off, ln, out)  # the slot is usable again
     assert int(st.wait(t)[0][0]) == 0
     st.close()
+
+
+@pytest.mark.parametrize("window_kib,device_plan", [(64, False), (64, True), (300, True), (1, False)])
+def test_input_blob_decoded_window_by_window(corpus, ctx, window_kib, device_plan):
+    """k_seq_pipe addresses bitstreams with 32-bit offsets from a window of the blob; blobs of 4 GiB and more
+    are decoded window by window.  With the window shrunk to a few KiB the corpus + synthetic batch takes many
+    launches, and frames wider than a window take the two-wavefront kernel: same bytes either way."""
+    from tools import synth_binding as sb
+    blob, off, ln, _, _ = sb.make_batch(4, 31, 24, threads=4)
+    frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+    want, sts_w = z.decode_frames(frames, ctx)
+    c = z.Context(0, seq_window_kib=window_kib, assume_cus=3)
+    outs, sts = z.decode_frames(frames, c, device_plan=device_plan)
+    assert sts == sts_w == [0] * len(frames)
+    assert outs == want
+    c.close()
