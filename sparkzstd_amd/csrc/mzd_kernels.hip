@@ -1137,13 +1137,12 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_add_u32 v221, v221, %[nbM0]\n\t"     /* nbM */                                                       \
     "v_add_u32 v222, v222, %[nbO0]\n\t"     /* nbO */                                                       \
     "v_add3_u32 v223, v214, v216, v215\n\t" /* o3 = exO + exM + exL */                                      \
-    "v_add_u32 v225, v220, v221\n\t"        /* nbL + nbM */                                                 \
-    "v_sub_u32 v224, 32, v220\n\t"          /* field positions in X: 32 - nbL, ... */                       \
+    /* field positions in X.hi as NEGATED running sums (v_bfe_u32 takes the offset mod 32): -nbL, ... */    \
+    "v_sub_u32 v224, 0, v220\n\t"           /* -nbL */                                                      \
     "v_add_u32 v229, v223, %[k]\n\t"        /* k + o3 */                                                    \
-    "v_add_u32 v226, v225, v222\n\t"        /* nbL + nbM + nbO */                                           \
-    "v_sub_u32 v225, 32, v225\n\t"                                                                          \
-    "v_add_u32 v230, v223, v226\n\t"        /* total */                                                     \
-    "v_sub_u32 v226, 32, v226\n\t"                                                                          \
+    "v_sub_u32 v225, v224, v221\n\t"        /* -(nbL + nbM) */                                              \
+    "v_sub_u32 v226, v225, v222\n\t"        /* -(nbL + nbM + nbO) */                                        \
+    "v_sub_u32 v230, v223, v226\n\t"        /* total */                                                     \
     "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
     /* merge the bytes of the load issued one step ago (as late as possible: a 59-line gather takes       */ \
     /* ~450 cycles): C += (DM >> 1) >> (63 - 8nb)                                                         */ \
