@@ -924,8 +924,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         sL += sizeL; sM += sizeM; sO += sizeO;  // states are kept pre-biased by the table size
         const uint32_t slot = live ? (uint32_t)lane * kSeqCellsPerChain : 0u;
         uint32_t last_i = t.n_seq - 1;
-        // parked: limit 0, cell 0 of its slot, refills from the (readable) front slack of the blob
-        auto park = [&]() { off = 0; C = D = 0; k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; last_i = 0xFFFFFFFFu; };
+        // parked: limit 0, cell 0 of its slot, refills from the (readable) front slack of the blob (the hot
+        // loop loads 16 bytes from 8 below `off`: 32 keeps that inside the MZD_IN_PAD = 64 bytes of slack)
+        auto park = [&]() { off = 32; C = D = 0; k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; last_i = 0xFFFFFFFFu; };
         if (!live) park();
         const uint32_t nbL0 = (uint32_t)(alL - 31), nbM0 = (uint32_t)(alM - 31), nbO0 = (uint32_t)(alO - 31);  // nbits = acc_log - 31 + clz(next)
         const uint16_t *cL = cells + slot - sizeL;
@@ -1066,23 +1067,26 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             {
                 // The same step, hand-scheduled: as a lone wavefront pays ~4.4 cycles per instruction of any
                 // kind, the instruction count IS the step latency (~70 here; hipcc's version of the C++
-                // statement above: ~110).  The refill load of a step is issued FIRST and merged into the
-                // window one step later, after that step's cell decode: a 59-line gather takes ~450
-                // cycles to come back.  Two D registers alternate.  The loop body is the step EIGHT times,
-                // one instance per queue slot: the slot addresses are immediates, queue space is checked and
-                // the cursor published to wave P once per batch of four (stage B consumes whole batches),
-                // head1 is published and nmax checked at the end of a batch (so i may overshoot nmax by up
-                // to 3 steps of parked lanes, inside a batch whose slots are known to be free).  The last
-                // sequence of a lane is a "no go" through the per-lane countdown `left`.
-                // Temporaries are fixed registers v200..v231 / s86.
+                // statement above: ~110).
+                // REFILL: a 57-line gather takes ~450 cycles to come back, about one step.  Every step issues
+                // FIRST a 16-byte load of the bytes below its window and merges, in the shadow of its cell
+                // reads, the load issued TWO steps ago: of those 16 bytes the window takes the (up to 7) bytes
+                // that lie `s` bytes below the top, s = the bytes the step in between consumed (<= 7, so
+                // 16 bytes always cover both steps).  Four register quads rotate (v[232:247]); the byte shifts
+                // of the previous step alternate between (v206, v208) and (v248, v249).
+                // The loop body is the step EIGHT times, one instance per queue slot: the slot addresses are
+                // immediates, queue space is checked and the cursor published to wave P once per batch of four
+                // (stage B consumes whole batches), head1 is published and nmax checked at the end of a batch
+                // (so i may overshoot nmax by up to 3 steps of parked lanes, inside a batch whose slots are
+                // known to be free).  The last sequence of a lane is a "no go" through the per-lane countdown
+                // `left`.  Temporaries are fixed registers v200..v251 / s86.
                 static_assert(kPipeDepth == 8 && kPipeBatch == 4, "the unrolled loop assumes 2 batches of 4 slots");
                 const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
                 const uint32_t sel1 = 0x0c0c0501u, sel2 = 0x0c050100u;
-                uint64_t D2 = 0;
                 uint32_t sLb = sL, sMb = sM, sOb = sO;  // the states alternate between two register sets
-                if (i & 1) D2 = D;  // odd slots take their bytes from D2 (and their states from set b)
                 uint32_t left = last_i - i;  // steps before the lane's last sequence (parked lane: huge)
                 uint32_t rem1 = (uint32_t)rem + 1u;
+                uint32_t Dlo = (uint32_t)D, Dhi = (uint32_t)(D >> 32);
 #define MZD_PIPE_CHECK(TAG)                                                                                 \
     "L_pipe_top" TAG "_%=:\n\t"                                                                             \
     "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
@@ -1098,10 +1102,15 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_pipe_poll" TAG "_%=\n"
 #define MZD_PIPE_PROG "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"
-#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, PROG, QT, QP, OUT)                                                      \
+#ifdef MZD_PIPE_NOGATHER  /* timing experiment only (wrong results): what does the refill gather cost? */
+#define MZD_PIPE_GATHER(LI) ""
+#else
+#define MZD_PIPE_GATHER(LI) "global_load_dwordx4 " LI ", %[off], %[inb] offset:-8\n\t" /* the 16 bytes below the window */
+#endif
+// LI: quad the step loads into; LMLO / LMHI: halves of the quad loaded two steps ago;
+// C8 / C63: this step's 8 * bytes and 63 - 8 * bytes; P8 / P63: the previous step's
+#define MZD_PIPE_STEP(LI, LMLO, LMHI, C8, C63, P8, P63, SA, SB, TAG, PROG, QT, QP, OUT)                     \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
-    /* next refill load first: off -= k >> 3; DL = 8 bytes at off.  Independent instructions are      */  \
-    /* interleaved throughout: a dependent VALU pair costs about twice an independent one.            */  \
     "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
     "v_lshl_add_u32 v200, %[sL" SA "], 1, %[cbL]\n\t"                                                       \
     "v_lshl_add_u32 v201, %[sM" SA "], 1, %[cbM]\n\t"                                                       \
@@ -1109,18 +1118,29 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_lshl_add_u32 v202, %[sO" SA "], 1, %[cbO]\n\t"                                                       \
     "ds_read_u16 v203, v200\n\t" /* xl */                                                                   \
     "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
-    "global_load_dwordx2 " DL ", %[off], %[inb]\n\t"                                                        \
     "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
+    /* after the cell reads: issuing a 57-line gather holds the wavefront for about a cycle per lane */     \
+    MZD_PIPE_GATHER(LI)                                                                                     \
     PROG                                                                                                    \
-    /* C <<= 8 * (k >> 3); k &= 7 (the bytes that come in from DM are merged below) */                      \
-    "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
+    /* C <<= 8 * (k >> 3); k &= 7 */                                                                        \
+    "v_and_b32 " C8 ", -8, %[k]\n\t"                                                                        \
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
-    "v_sub_u32 v208, 63, v206\n\t"                                                                          \
-    "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
+    "v_sub_u32 " C63 ", 63, " C8 "\n\t"                                                                     \
+    "v_lshlrev_b64 %[C], " C8 ", %[C]\n\t"                                                                  \
     "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
-    /* in the shadow of the cell reads: the step limit */                                                   \
+    /* in the shadow of the cell reads: M = the 8 bytes that end s bytes below the top of the quad         */ \
+    /* loaded two steps ago; C += (M >> 1) >> (63 - 8nb); and the step limit                               */ \
+    "s_waitcnt vmcnt(2)\n\t"                                                                                \
+    "v_lshrrev_b64 v[210:211], 1, " LMLO "\n\t"                                                             \
+    "v_lshlrev_b64 v[250:251], " P8 ", " LMHI "\n\t"                                                        \
+    "v_lshrrev_b64 v[210:211], " P63 ", v[210:211]\n\t"                                                     \
     "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
+    "v_or_b32 v210, v210, v250\n\t"                                                                         \
+    "v_or_b32 v211, v211, v251\n\t"                                                                         \
     "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
+    "v_lshrrev_b64 v[210:211], 1, v[210:211]\n\t"                                                           \
+    "v_lshrrev_b64 v[210:211], " C63 ", v[210:211]\n\t"                                                     \
+    "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
@@ -1144,17 +1164,11 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_sub_u32 v226, v225, v222\n\t"        /* -(nbL + nbM + nbO) */                                        \
     "v_sub_u32 v230, v223, v226\n\t"        /* total */                                                     \
     "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
-    /* merge the bytes of the load issued one step ago (as late as possible: a 59-line gather takes       */ \
-    /* ~450 cycles): C += (DM >> 1) >> (63 - 8nb)                                                         */ \
-    "s_waitcnt vmcnt(1)\n\t"                                                                                \
-    "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
-    "v_cmp_lt_u32 vcc, v227, v228\n\t"                  /* go (= advance; never at the last sequence) */    \
-    "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
     "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
-    "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
+    "v_cmp_lt_u32 vcc, v227, v228\n\t"                  /* go (= advance; never at the last sequence) */    \
+    "v_lshlrev_b64 v[210:211], v229, %[C]\n\t"          /* X = C << (k + o3): state bits from bit 63 */     \
     "s_andn2_b64 %[smask], %[live], vcc\n\t"            /* special = live & ~go */                          \
     "v_cndmask_b32 v230, 0, v230, vcc\n\t"                                                                  \
-    "v_lshlrev_b64 v[210:211], v229, %[C]\n\t"          /* X = C << (k + o3): state bits from bit 63 */     \
     "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T = C << k */                                    \
     "v_sub_u32 %[rem1], %[rem1], v230\n\t"                                                                  \
     "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
@@ -1172,6 +1186,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
     "s_cbranch_scc1 " OUT "\n\t"
+#define MZD_PS(...) MZD_PIPE_STEP(__VA_ARGS__)  /* expands MZD_EVEN / MZD_ODD into four arguments */
 #define MZD_PIPE_PUBLISH(OUT)                                                                               \
     "v_mov_b32 v202, %[i]\n\t"                                                                              \
     "ds_write_b32 %[vzero], v202 offset:%[o_head1]\n\t"                                                     \
@@ -1179,8 +1194,36 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_cbranch_scc0 " OUT "\n\t"
 #define MZD_OUTE "L_pipe_oute_%="
 #define MZD_OUTO "L_pipe_outo_%="
+#define MZD_Q0 "v[232:235]"
+#define MZD_Q1 "v[236:239]"
+#define MZD_Q2 "v[240:243]"
+#define MZD_Q3 "v[244:247]"
+#define MZD_EVEN "v206", "v208", "v248", "v249"
+#define MZD_ODD "v248", "v249", "v206", "v208"
                 asm volatile(
-                    // entry: the instance of slot i % 8; the valid lookahead bytes are in D (even) / D2 (odd)
+                    // prologue: every quad = the 16 bytes below the window (upper half: D, which the C++ side
+                    // keeps valid), no bytes consumed by "the step in between"
+                    "global_load_dwordx2 v[232:233], %[off], %[inb] offset:-8\n\t"
+                    "v_mov_b32 v234, %[Dlo]\n\t"
+                    "v_mov_b32 v235, %[Dhi]\n\t"
+                    "v_mov_b32 v206, 0\n\t"
+                    "v_mov_b32 v208, 63\n\t"
+                    "v_mov_b32 v248, 0\n\t"
+                    "v_mov_b32 v249, 63\n\t"
+                    "v_mov_b32 v238, v234\n\t"
+                    "v_mov_b32 v239, v235\n\t"
+                    "v_mov_b32 v242, v234\n\t"
+                    "v_mov_b32 v243, v235\n\t"
+                    "v_mov_b32 v246, v234\n\t"
+                    "v_mov_b32 v247, v235\n\t"
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "v_mov_b32 v236, v232\n\t"
+                    "v_mov_b32 v237, v233\n\t"
+                    "v_mov_b32 v240, v232\n\t"
+                    "v_mov_b32 v241, v233\n\t"
+                    "v_mov_b32 v244, v232\n\t"
+                    "v_mov_b32 v245, v233\n\t"
+                    // entry: the instance of slot i % 8 (odd slots take their states from set b: both sets are equal here)
                     "s_and_b32 s86, %[i], 7\n\t"
                     "s_cmp_eq_u32 s86, 0\n\t"
                     "s_cbranch_scc1 L_pipe_top0_%=\n\t"
@@ -1198,21 +1241,19 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "s_cbranch_scc1 L_pipe_go6_%=\n\t"
                     "s_branch L_pipe_go7_%=\n"
                     MZD_PIPE_CHECK("0")
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "0", MZD_PIPE_PROG, "%[qt0]", "%[qp0]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "1", "", "%[qt1]", "%[qp1]", MZD_OUTO)
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "2", "", "%[qt2]", "%[qp2]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "3", "", "%[qt3]", "%[qp3]", MZD_OUTO)
+                    MZD_PS(MZD_Q0, "v[240:241]", "v[242:243]", MZD_EVEN, "a", "b", "0", MZD_PIPE_PROG, "%[qt0]", "%[qp0]", MZD_OUTE)
+                    MZD_PS(MZD_Q1, "v[244:245]", "v[246:247]", MZD_ODD, "b", "a", "1", "", "%[qt1]", "%[qp1]", MZD_OUTO)
+                    MZD_PS(MZD_Q2, "v[232:233]", "v[234:235]", MZD_EVEN, "a", "b", "2", "", "%[qt2]", "%[qp2]", MZD_OUTE)
+                    MZD_PS(MZD_Q3, "v[236:237]", "v[238:239]", MZD_ODD, "b", "a", "3", "", "%[qt3]", "%[qp3]", MZD_OUTO)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     MZD_PIPE_CHECK("4")
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "4", MZD_PIPE_PROG, "%[qt4]", "%[qp4]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "5", "", "%[qt5]", "%[qp5]", MZD_OUTO)
-                    MZD_PIPE_STEP("%[D]", "%[D2]", "a", "b", "6", "", "%[qt6]", "%[qp6]", MZD_OUTE)
-                    MZD_PIPE_STEP("%[D2]", "%[D]", "b", "a", "7", "", "%[qt7]", "%[qp7]", MZD_OUTO)
+                    MZD_PS(MZD_Q0, "v[240:241]", "v[242:243]", MZD_EVEN, "a", "b", "4", MZD_PIPE_PROG, "%[qt4]", "%[qp4]", MZD_OUTE)
+                    MZD_PS(MZD_Q1, "v[244:245]", "v[246:247]", MZD_ODD, "b", "a", "5", "", "%[qt5]", "%[qp5]", MZD_OUTO)
+                    MZD_PS(MZD_Q2, "v[232:233]", "v[234:235]", MZD_EVEN, "a", "b", "6", "", "%[qt6]", "%[qp6]", MZD_OUTE)
+                    MZD_PS(MZD_Q3, "v[236:237]", "v[238:239]", MZD_ODD, "b", "a", "7", "", "%[qt7]", "%[qp7]", MZD_OUTO)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     "s_branch L_pipe_top0_%=\n"
-                    "L_pipe_oute_%=:\n\t"  // left after an even slot: the current lookahead is in D2, the new states in set b
-                    "s_waitcnt vmcnt(0)\n\t"
-                    "v_lshlrev_b64 %[D], 0, %[D2]\n\t"
+                    "L_pipe_oute_%=:\n\t"  // left after an even slot: the new states are in set b
                     "v_cndmask_b32 %[sLa], %[sLa], %[sLb], vcc\n\t"  // vcc is still the last step's "go"
                     "v_cndmask_b32 %[sMa], %[sMa], %[sMb], vcc\n\t"
                     "v_cndmask_b32 %[sOa], %[sOa], %[sOb], vcc\n\t"
@@ -1222,9 +1263,15 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "v_cndmask_b32 %[sMa], %[sMb], %[sMa], vcc\n\t"
                     "v_cndmask_b32 %[sOa], %[sOb], %[sOa], vcc\n"
                     "L_pipe_done_%=:\n\t"
+                    // the C++ side's lookahead: the 8 bytes below the (not yet normalised) window
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "global_load_dwordx2 v[250:251], %[off], %[inb]\n\t"
                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-                    : [sLa] "+v"(sL), [sMa] "+v"(sM), [sOa] "+v"(sO), [sLb] "+v"(sLb), [sMb] "+v"(sMb), [sOb] "+v"(sOb), [k] "+v"(k), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(off),
-                      [C] "+v"(C), [D] "+v"(D), [D2] "+v"(D2), [i] "+s"(i), [tail] "+s"(tail_seen), [smask] "=&s"(smask)
+                    "v_mov_b32 %[Dlo], v250\n\t"
+                    "v_mov_b32 %[Dhi], v251\n\t"
+                    : [sLa] "+v"(sL), [sMa] "+v"(sM), [sOa] "+v"(sO), [sLb] "+v"(sLb), [sMb] "+v"(sMb), [sOb] "+v"(sOb), [k] "+v"(k),
+                      [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(off), [C] "+v"(C), [Dlo] "+v"(Dlo), [Dhi] "+v"(Dhi), [i] "+s"(i),
+                      [tail] "+s"(tail_seen), [smask] "=&s"(smask)
                     : [cbL] "v"(cbL), [cbM] "v"(cbM), [cbO] "v"(cbO), [nbL0] "v"(nbL0), [nbM0] "v"(nbM0), [nbO0] "v"(nbO0),
                       [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [nmax] "s"(nmax),
                       [live] "s"(livemask), [inb] "s"(inb), [sel1] "s"(sel1), [sel2] "s"(sel2),
@@ -1239,16 +1286,26 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     : "memory", "vcc", "scc", "s86",
                       "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v210", "v211", "v212", "v213",
                       "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
-                      "v227", "v228", "v229", "v230", "v231");
+                      "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+                      "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
 #undef MZD_PIPE_STEP
+#undef MZD_PS
 #undef MZD_PIPE_CHECK
 #undef MZD_PIPE_PUBLISH
 #undef MZD_PIPE_PROG
+#undef MZD_PIPE_GATHER
 #undef MZD_OUTE
 #undef MZD_OUTO
+#undef MZD_Q0
+#undef MZD_Q1
+#undef MZD_Q2
+#undef MZD_Q3
+#undef MZD_EVEN
+#undef MZD_ODD
 #undef MZD_QT
 #undef MZD_QP
                 rem = (int)(rem1 - 1u);
+                D = (uint64_t)Dlo | ((uint64_t)Dhi << 32);
             }
 #endif
             // i has moved past the step; lanes in smask have not done it yet
