@@ -50,6 +50,13 @@ __device__ __forceinline__ void touch_line(const uint8_t *p)
     asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
 }
 
+// The same without waiting: the result lands in v255, which nothing else uses (fire and forget; only for
+// wavefronts that never wait on vmcnt themselves, where a pending miss then delays nobody).
+__device__ __forceinline__ void touch_line_nowait(const uint8_t *p)
+{
+    asm volatile("global_load_dword v255, %0, off" : : "v"(p) : "memory", "v255");
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 #pragma unroll
@@ -752,6 +759,7 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 //
 // LDS: [CTc 128 dwords][PipeShared][cells: nch x 1280 x u16], nch <= kPipeMaxChains at launch.
 
+constexpr int kPipeRing = 128;  // bytes of every chain's bitstream wave P keeps in LDS for stage A
 constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
 #ifndef MZD_PIPE_AHEAD
 #define MZD_PIPE_AHEAD 256  // bytes wave P keeps touched below every chain's cursor
@@ -763,10 +771,12 @@ struct PipeShared {
     uint64_t q1t[kPipeDepth][64];         // mode 0: bit window T; mode 1: LL:17 | ML:18 | offset value:29
     uint32_t q1p[kPipeDepth][64];         // mode 0: byte 0/1/2 = high byte of the LL/ML/OF cell; mode 1: bit 31
     uint64_t q2[kPipeDepth][64];          // LL:17 | ML:18 | offset value:29 (2^28 = "too large")
+    uint32_t ring_low[64];                // per chain: lowest offset (from in - MZD_IN_PAD) wave P has put in the ring
+    uint8_t ring[64][kPipeRing + 8];      // per chain: 128 bytes of bitstream at (offset & 127) + the first 8 again
 };
 constexpr int kPipeFixedLds = 512 + (int)sizeof(PipeShared);
 constexpr int kPipeMaxChains = (160 * 1024 - kPipeFixedLds) / (kSeqCellsPerChain * 2);
-static_assert(kPipeFixedLds % 16 == 0 && kPipeMaxChains >= 59, "k_seq_pipe LDS layout");
+static_assert(kPipeFixedLds % 16 == 0 && kPipeMaxChains >= 56 && offsetof(PipeShared, ring) % 8 == 0, "k_seq_pipe LDS layout");
 constexpr uint32_t kPipeEscape = 64;
 
 // symbol -> c6 (see above); kind 0 = literal lengths, 1 = match lengths
@@ -829,6 +839,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         CTc[lane] = 0;
         CTc[64 + lane] = 0;
         shs->progress[lane] = (uint32_t)t.in_off + MZD_IN_PAD + t.in_size;
+        shs->ring_low[lane] = (has && t.n_seq > 0) ? 0xFFFFFFFFu : 0u;  // nothing in the ring yet / nothing needed
         shs->stC[lane] = MZD_OK;
         if (lane == 0) { shs->head1 = 0; shs->tail1 = 0; shs->head2 = 0; shs->tail2 = 0; }
         __builtin_amdgcn_s_waitcnt(0);  // the zero fill above before the scattered fill below (same wavefront: LDS is in order)
@@ -924,9 +935,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         sL += sizeL; sM += sizeM; sO += sizeO;  // states are kept pre-biased by the table size
         const uint32_t slot = live ? (uint32_t)lane * kSeqCellsPerChain : 0u;
         uint32_t last_i = t.n_seq - 1;
-        // parked: limit 0, cell 0 of its slot, refills from the (readable) front slack of the blob (the hot
-        // loop loads 16 bytes from 8 below `off`: 32 keeps that inside the MZD_IN_PAD = 64 bytes of slack)
-        auto park = [&]() { off = 32; C = D = 0; k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; last_i = 0xFFFFFFFFu; };
+        // parked: limit 0, cell 0 of its slot, cursor 0 = the (readable) front slack of the window; the hot loop's
+        // ring check, ring_low <= off - 40 as unsigned numbers, is always true for it
+        auto park = [&]() { off = 0; C = D = 0; k = 0; rem = 0; sL = sizeL; sM = sizeM; sO = sizeO; live = false; last_i = 0xFFFFFFFFu; };
         if (!live) park();
         const uint32_t nbL0 = (uint32_t)(alL - 31), nbM0 = (uint32_t)(alM - 31), nbO0 = (uint32_t)(alO - 31);  // nbits = acc_log - 31 + clz(next)
         const uint16_t *cL = cells + slot - sizeL;
@@ -934,6 +945,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         const uint16_t *cO = cells + slot + 1024 - sizeO;
 
         uint32_t tail_seen = 0;
+        uint32_t polls = 0;  // diagnostics (-DMZD_PIPE_PROF prints it): queue-full polls | ring-not-ready polls << 16
 #ifdef MZD_PIPE_PROF
         long long prof_wait = 0, prof_t0 = clock64(), prof_r0 = wall_clock64();
         if (blockIdx.x == 0 && lane == 0) printf("A: staging + init %lld cycles\n", prof_t0 - prof_k0);
@@ -1066,50 +1078,61 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
 #else
             {
                 // The same step, hand-scheduled: as a lone wavefront pays ~4.4 cycles per instruction of any
-                // kind, the instruction count IS the step latency (~70 here; hipcc's version of the C++
+                // kind, the instruction count IS the step latency (~68 here; hipcc's version of the C++
                 // statement above: ~110).
-                // REFILL: a 57-line gather takes ~450 cycles to come back, about one step.  Every step issues
-                // FIRST a 16-byte load of the bytes below its window and merges, in the shadow of its cell
-                // reads, the load issued TWO steps ago: of those 16 bytes the window takes the (up to 7) bytes
-                // that lie `s` bytes below the top, s = the bytes the step in between consumed (<= 7, so
-                // 16 bytes always cover both steps).  Four register quads rotate (v[232:247]); the byte shifts
-                // of the previous step alternate between (v206, v208) and (v248, v249).
+                // REFILL from LDS: a per-lane gather of the bitstream from global memory (57 distinct lines
+                // per step) was what bounded the step at 57 chains -- each 128-byte line was fetched ~40
+                // times.  Wave P now keeps 128 bytes of every chain's bitstream in an LDS ring (one 32-byte
+                // load per chain every ~10 steps) and a step reads the 8 bytes below its window from the ring
+                // (byte offset & 127; the ring repeats its first 8 bytes at the end), merged into the window
+                // one step later, in the shadow of that step's cell reads.  Once per batch of four steps (and
+                // at every entry) the lanes check that P is at least 40 bytes ahead of them.  Two register
+                // pairs alternate (v[232:233], v[234:235]).
                 // The loop body is the step EIGHT times, one instance per queue slot: the slot addresses are
                 // immediates, queue space is checked and the cursor published to wave P once per batch of four
                 // (stage B consumes whole batches), head1 is published and nmax checked at the end of a batch
                 // (so i may overshoot nmax by up to 3 steps of parked lanes, inside a batch whose slots are
                 // known to be free).  The last sequence of a lane is a "no go" through the per-lane countdown
-                // `left`.  Temporaries are fixed registers v200..v251 / s86.
-                static_assert(kPipeDepth == 8 && kPipeBatch == 4, "the unrolled loop assumes 2 batches of 4 slots");
+                // `left`.  Temporaries are fixed registers v200..v235 / s86.
+                static_assert(kPipeDepth == 8 && kPipeBatch == 4 && kPipeRing == 128, "the unrolled loop assumes 2 batches of 4 slots, a 128-byte ring");
                 const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
                 const uint32_t sel1 = 0x0c0c0501u, sel2 = 0x0c050100u;
                 uint32_t sLb = sL, sMb = sM, sOb = sO;  // the states alternate between two register sets
                 uint32_t left = last_i - i;  // steps before the lane's last sequence (parked lane: huge)
                 uint32_t rem1 = (uint32_t)rem + 1u;
                 uint32_t Dlo = (uint32_t)D, Dhi = (uint32_t)(D >> 32);
+                const uint32_t ringl = 512u + (uint32_t)offsetof(PipeShared, ring) + (uint32_t)lane * (kPipeRing + 8);
+// the cursor goes to wave P, then: queue space for the batch, and the ring at least 40 bytes below the cursor
+#define MZD_PIPE_RINGCHK(TAG)                                                                               \
+    "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n"                                                      \
+    "L_pipe_ring" TAG "_%=:\n\t"                                                                            \
+    "ds_read_b32 v200, %[lane4] offset:%[o_rlow]\n\t"                                                       \
+    "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_cmp_gt_u32 vcc, v200, v201\n\t"                                                                      \
+    "s_cbranch_vccz L_pipe_go" TAG "_%=\n\t"                                                                \
+    "s_add_u32 %[polls], %[polls], 0x10000\n\t"                                                             \
+    "s_sleep 1\n\t"                                                                                         \
+    "s_branch L_pipe_ring" TAG "_%=\n"
 #define MZD_PIPE_CHECK(TAG)                                                                                 \
     "L_pipe_top" TAG "_%=:\n\t"                                                                             \
     "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
     "s_cmp_lt_u32 s86, 5\n\t" /* i + 3 - tail1 < depth */                                                   \
-    "s_cbranch_scc1 L_pipe_go" TAG "_%=\n"                                                                  \
+    "s_cbranch_scc1 L_pipe_spc" TAG "_%=\n"                                                                 \
     "L_pipe_poll" TAG "_%=:\n\t"                                                                            \
     "ds_read_b32 v200, %[vzero] offset:%[o_tail1]\n\t"                                                      \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_readfirstlane_b32 %[tail], v200\n\t"                                                                 \
     "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
     "s_cmp_lt_u32 s86, 5\n\t"                                                                               \
-    "s_cbranch_scc1 L_pipe_go" TAG "_%=\n\t"                                                                \
+    "s_cbranch_scc1 L_pipe_spc" TAG "_%=\n\t"                                                               \
+    "s_add_u32 %[polls], %[polls], 1\n\t"                                                                   \
     "s_sleep 1\n\t"                                                                                         \
-    "s_branch L_pipe_poll" TAG "_%=\n"
-#define MZD_PIPE_PROG "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"
-#ifdef MZD_PIPE_NOGATHER  /* timing experiment only (wrong results): what does the refill gather cost? */
-#define MZD_PIPE_GATHER(LI) ""
-#else
-#define MZD_PIPE_GATHER(LI) "global_load_dwordx4 " LI ", %[off], %[inb] offset:-8\n\t" /* the 16 bytes below the window */
-#endif
-// LI: quad the step loads into; LMLO / LMHI: halves of the quad loaded two steps ago;
-// C8 / C63: this step's 8 * bytes and 63 - 8 * bytes; P8 / P63: the previous step's
-#define MZD_PIPE_STEP(LI, LMLO, LMHI, C8, C63, P8, P63, SA, SB, TAG, PROG, QT, QP, OUT)                     \
+    "s_branch L_pipe_poll" TAG "_%=\n"                                                                      \
+    "L_pipe_spc" TAG "_%=:\n\t"                                                                             \
+    MZD_PIPE_RINGCHK(TAG)
+// DM: the 8 bytes the previous step read from the ring; DL: where this step's go
+#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT)                                                     \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
     "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
     "v_lshl_add_u32 v200, %[sL" SA "], 1, %[cbL]\n\t"                                                       \
@@ -1117,30 +1140,22 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
     "v_lshl_add_u32 v202, %[sO" SA "], 1, %[cbO]\n\t"                                                       \
     "ds_read_u16 v203, v200\n\t" /* xl */                                                                   \
+    "v_and_b32 v209, 127, %[off]\n\t"                                                                       \
     "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
+    "v_add_u32 v209, v209, %[ringl]\n\t"                                                                    \
     "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
-    /* after the cell reads: issuing a 57-line gather holds the wavefront for about a cycle per lane */     \
-    MZD_PIPE_GATHER(LI)                                                                                     \
-    PROG                                                                                                    \
-    /* C <<= 8 * (k >> 3); k &= 7 */                                                                        \
-    "v_and_b32 " C8 ", -8, %[k]\n\t"                                                                        \
+    "ds_read_b64 " DL ", v209\n\t" /* the 8 bytes below the window, for the next step */                    \
+    /* C <<= 8 * (k >> 3); k &= 7; then the bytes that come in from DM: C += (DM >> 1) >> (63 - 8nb) */    \
+    "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
-    "v_sub_u32 " C63 ", 63, " C8 "\n\t"                                                                     \
-    "v_lshlrev_b64 %[C], " C8 ", %[C]\n\t"                                                                  \
+    "v_sub_u32 v208, 63, v206\n\t"                                                                          \
+    "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
+    "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
     "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
-    /* in the shadow of the cell reads: M = the 8 bytes that end s bytes below the top of the quad         */ \
-    /* loaded two steps ago; C += (M >> 1) >> (63 - 8nb); and the step limit                               */ \
-    "s_waitcnt vmcnt(2)\n\t"                                                                                \
-    "v_lshrrev_b64 v[210:211], 1, " LMLO "\n\t"                                                             \
-    "v_lshlrev_b64 v[250:251], " P8 ", " LMHI "\n\t"                                                        \
-    "v_lshrrev_b64 v[210:211], " P63 ", v[210:211]\n\t"                                                     \
+    "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
     "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
-    "v_or_b32 v210, v210, v250\n\t"                                                                         \
-    "v_or_b32 v211, v211, v251\n\t"                                                                         \
-    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
-    "v_lshrrev_b64 v[210:211], 1, v[210:211]\n\t"                                                           \
-    "v_lshrrev_b64 v[210:211], " C63 ", v[210:211]\n\t"                                                     \
     "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
+    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
@@ -1186,7 +1201,6 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
     "s_cbranch_scc1 " OUT "\n\t"
-#define MZD_PS(...) MZD_PIPE_STEP(__VA_ARGS__)  /* expands MZD_EVEN / MZD_ODD into four arguments */
 #define MZD_PIPE_PUBLISH(OUT)                                                                               \
     "v_mov_b32 v202, %[i]\n\t"                                                                              \
     "ds_write_b32 %[vzero], v202 offset:%[o_head1]\n\t"                                                     \
@@ -1194,36 +1208,20 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_cbranch_scc0 " OUT "\n\t"
 #define MZD_OUTE "L_pipe_oute_%="
 #define MZD_OUTO "L_pipe_outo_%="
-#define MZD_Q0 "v[232:235]"
-#define MZD_Q1 "v[236:239]"
-#define MZD_Q2 "v[240:243]"
-#define MZD_Q3 "v[244:247]"
-#define MZD_EVEN "v206", "v208", "v248", "v249"
-#define MZD_ODD "v248", "v249", "v206", "v208"
+#define MZD_DA "v[232:233]"
+#define MZD_DB "v[234:235]"
                 asm volatile(
-                    // prologue: every quad = the 16 bytes below the window (upper half: D, which the C++ side
-                    // keeps valid), no bytes consumed by "the step in between"
-                    "global_load_dwordx2 v[232:233], %[off], %[inb] offset:-8\n\t"
+                    // prologue: both lookahead pairs = the 8 bytes below the window (D, which the C++ side keeps
+                    // valid); the entry's ring check; then the instance of slot i % 8
+                    "v_mov_b32 v232, %[Dlo]\n\t"
+                    "v_mov_b32 v233, %[Dhi]\n\t"
                     "v_mov_b32 v234, %[Dlo]\n\t"
                     "v_mov_b32 v235, %[Dhi]\n\t"
-                    "v_mov_b32 v206, 0\n\t"
-                    "v_mov_b32 v208, 63\n\t"
-                    "v_mov_b32 v248, 0\n\t"
-                    "v_mov_b32 v249, 63\n\t"
-                    "v_mov_b32 v238, v234\n\t"
-                    "v_mov_b32 v239, v235\n\t"
-                    "v_mov_b32 v242, v234\n\t"
-                    "v_mov_b32 v243, v235\n\t"
-                    "v_mov_b32 v246, v234\n\t"
-                    "v_mov_b32 v247, v235\n\t"
-                    "s_waitcnt vmcnt(0)\n\t"
-                    "v_mov_b32 v236, v232\n\t"
-                    "v_mov_b32 v237, v233\n\t"
-                    "v_mov_b32 v240, v232\n\t"
-                    "v_mov_b32 v241, v233\n\t"
-                    "v_mov_b32 v244, v232\n\t"
-                    "v_mov_b32 v245, v233\n\t"
-                    // entry: the instance of slot i % 8 (odd slots take their states from set b: both sets are equal here)
+                    "s_and_b32 s86, %[i], 3\n\t"
+                    "s_cmp_eq_u32 s86, 0\n\t"
+                    "s_cbranch_scc1 L_pipe_goe_%=\n\t"  // slots 0 and 4 make the check themselves
+                    MZD_PIPE_RINGCHK("e")
+                    "L_pipe_goe_%=:\n\t"
                     "s_and_b32 s86, %[i], 7\n\t"
                     "s_cmp_eq_u32 s86, 0\n\t"
                     "s_cbranch_scc1 L_pipe_top0_%=\n\t"
@@ -1241,16 +1239,16 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "s_cbranch_scc1 L_pipe_go6_%=\n\t"
                     "s_branch L_pipe_go7_%=\n"
                     MZD_PIPE_CHECK("0")
-                    MZD_PS(MZD_Q0, "v[240:241]", "v[242:243]", MZD_EVEN, "a", "b", "0", MZD_PIPE_PROG, "%[qt0]", "%[qp0]", MZD_OUTE)
-                    MZD_PS(MZD_Q1, "v[244:245]", "v[246:247]", MZD_ODD, "b", "a", "1", "", "%[qt1]", "%[qp1]", MZD_OUTO)
-                    MZD_PS(MZD_Q2, "v[232:233]", "v[234:235]", MZD_EVEN, "a", "b", "2", "", "%[qt2]", "%[qp2]", MZD_OUTE)
-                    MZD_PS(MZD_Q3, "v[236:237]", "v[238:239]", MZD_ODD, "b", "a", "3", "", "%[qt3]", "%[qp3]", MZD_OUTO)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE)
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE)
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     MZD_PIPE_CHECK("4")
-                    MZD_PS(MZD_Q0, "v[240:241]", "v[242:243]", MZD_EVEN, "a", "b", "4", MZD_PIPE_PROG, "%[qt4]", "%[qp4]", MZD_OUTE)
-                    MZD_PS(MZD_Q1, "v[244:245]", "v[246:247]", MZD_ODD, "b", "a", "5", "", "%[qt5]", "%[qp5]", MZD_OUTO)
-                    MZD_PS(MZD_Q2, "v[232:233]", "v[234:235]", MZD_EVEN, "a", "b", "6", "", "%[qt6]", "%[qp6]", MZD_OUTE)
-                    MZD_PS(MZD_Q3, "v[236:237]", "v[238:239]", MZD_ODD, "b", "a", "7", "", "%[qt7]", "%[qp7]", MZD_OUTO)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE)
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE)
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     "s_branch L_pipe_top0_%=\n"
                     "L_pipe_oute_%=:\n\t"  // left after an even slot: the new states are in set b
@@ -1263,20 +1261,19 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "v_cndmask_b32 %[sMa], %[sMb], %[sMa], vcc\n\t"
                     "v_cndmask_b32 %[sOa], %[sOb], %[sOa], vcc\n"
                     "L_pipe_done_%=:\n\t"
-                    // the C++ side's lookahead: the 8 bytes below the (not yet normalised) window
-                    "s_waitcnt vmcnt(0)\n\t"
-                    "global_load_dwordx2 v[250:251], %[off], %[inb]\n\t"
+                    // the C++ side's lookahead: the 8 bytes below the (not yet normalised) window, from memory
+                    "global_load_dwordx2 v[232:233], %[off], %[inb]\n\t"
                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-                    "v_mov_b32 %[Dlo], v250\n\t"
-                    "v_mov_b32 %[Dhi], v251\n\t"
+                    "v_mov_b32 %[Dlo], v232\n\t"
+                    "v_mov_b32 %[Dhi], v233\n\t"
                     : [sLa] "+v"(sL), [sMa] "+v"(sM), [sOa] "+v"(sO), [sLb] "+v"(sLb), [sMb] "+v"(sMb), [sOb] "+v"(sOb), [k] "+v"(k),
                       [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(off), [C] "+v"(C), [Dlo] "+v"(Dlo), [Dhi] "+v"(Dhi), [i] "+s"(i),
-                      [tail] "+s"(tail_seen), [smask] "=&s"(smask)
+                      [tail] "+s"(tail_seen), [polls] "+s"(polls), [smask] "=&s"(smask)
                     : [cbL] "v"(cbL), [cbM] "v"(cbM), [cbO] "v"(cbO), [nbL0] "v"(nbL0), [nbM0] "v"(nbM0), [nbO0] "v"(nbO0),
-                      [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [nmax] "s"(nmax),
+                      [lane4] "v"(lane4), [lane8] "v"(lane8), [vzero] "v"(vzero), [ringl] "v"(ringl), [nmax] "s"(nmax),
                       [live] "s"(livemask), [inb] "s"(inb), [sel1] "s"(sel1), [sel2] "s"(sel2),
                       [o_tail1] "n"(512 + offsetof(PipeShared, tail1)), [o_head1] "n"(512 + offsetof(PipeShared, head1)),
-                      [o_prog] "n"(512 + offsetof(PipeShared, progress)),
+                      [o_prog] "n"(512 + offsetof(PipeShared, progress)), [o_rlow] "n"(512 + offsetof(PipeShared, ring_low)),
 #define MZD_QT(S) (512 + offsetof(PipeShared, q1t) + (S) * 512)
 #define MZD_QP(S) (512 + offsetof(PipeShared, q1p) + (S) * 256)
                       [qt0] "n"(MZD_QT(0)), [qt1] "n"(MZD_QT(1)), [qt2] "n"(MZD_QT(2)), [qt3] "n"(MZD_QT(3)),
@@ -1284,24 +1281,17 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                       [qp0] "n"(MZD_QP(0)), [qp1] "n"(MZD_QP(1)), [qp2] "n"(MZD_QP(2)), [qp3] "n"(MZD_QP(3)),
                       [qp4] "n"(MZD_QP(4)), [qp5] "n"(MZD_QP(5)), [qp6] "n"(MZD_QP(6)), [qp7] "n"(MZD_QP(7))
                     : "memory", "vcc", "scc", "s86",
-                      "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v210", "v211", "v212", "v213",
+                      "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213",
                       "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
-                      "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
-                      "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
+                      "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235");
 #undef MZD_PIPE_STEP
-#undef MZD_PS
 #undef MZD_PIPE_CHECK
+#undef MZD_PIPE_RINGCHK
 #undef MZD_PIPE_PUBLISH
-#undef MZD_PIPE_PROG
-#undef MZD_PIPE_GATHER
 #undef MZD_OUTE
 #undef MZD_OUTO
-#undef MZD_Q0
-#undef MZD_Q1
-#undef MZD_Q2
-#undef MZD_Q3
-#undef MZD_EVEN
-#undef MZD_ODD
+#undef MZD_DA
+#undef MZD_DB
 #undef MZD_QT
 #undef MZD_QP
                 rem = (int)(rem1 - 1u);
@@ -1315,7 +1305,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         }
 #ifdef MZD_PIPE_PROF
         if (blockIdx.x == 0 && lane == 0)
-            printf("A: steps %u cycles %lld wait %lld real(100MHz) %lld\n", nmax, clock64() - prof_t0, prof_wait, wall_clock64() - prof_r0);
+            printf("A: steps %u cycles %lld wait %lld real(100MHz) %lld queue-full polls %u ring polls %u\n", nmax, clock64() - prof_t0,
+                   prof_wait, wall_clock64() - prof_r0, polls & 0xFFFF, polls >> 16);
+        (void)polls;
 #endif
     } else if (wave == 1) {
         // ================= stage B: field extraction and values, four steps at a time =================
@@ -1461,26 +1453,48 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         if (blockIdx.x == 0 && lane == 0) printf("C: cycles %lld wait_in %lld\n", clock64() - prof_t0, prof_wait);
 #endif
     } else {
-        // ================= wave P: touch the bitstream lines ahead of stage A =================
+        // ================= wave P: the chains' bitstreams, ahead of stage A =================
+        // Keeps the 128 bytes around every chain's cursor in the chain's LDS ring, 32-byte units at (offset & 127):
+        // the unit [low - 32, low) may replace [low + 96, low + 128) once A's published cursor is <= low + 88 (A
+        // reads nothing at or above cursor + 8); ring_low tells A how far down the ring reaches.  (The prefetch
+        // touches far below the cursor are wave B's.)
+        const uint8_t *inb = in - MZD_IN_PAD;
         const uint8_t *sbase = in + t.in_off;
-        int low = (int)t.in_size;  // everything at or above `low` has been requested
+        const bool work = has && t.n_seq > 0;
+        int low = (int)t.in_size;  // prefetch touches: everything at or above `low` has been requested
         constexpr int kAhead = MZD_PIPE_AHEAD, kLine = 128;
+        uint32_t rlow = ((uint32_t)t.in_off + MZD_IN_PAD + t.in_size + 31u) & ~31u;  // ring: nothing yet
+        uint8_t *ring = shs->ring[lane];
         for (;;) {
             const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)__hip_atomic_load(&shs->head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             // parked lanes point outside the stream
             const uint32_t raw = __hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int cur = (int)(raw - ((uint32_t)t.in_off + MZD_IN_PAD));  // A publishes its refill offset from in - MZD_IN_PAD
-            const bool inside = cur >= -64 && cur <= (int)t.in_size;
-            const int target = inside ? max(cur - kAhead, 0) : low;
-            int guard = 0;
-            while (has && low > target && guard < 8) {
-                low = max(low - kLine, 0);
-                touch_line(sbase + (low & ~3));
-                guard++;
+            const bool inside = cur >= -56 && cur <= (int)t.in_size;
+            if (work && inside) {
+                for (int g = 0; g < 4 && raw <= rlow + 88u && rlow >= 32u; g++) {
+                    const uint32_t u = rlow - 32u;
+                    const uint64_t w0 = ld64u(inb + u), w1 = ld64u(inb + u + 8), w2 = ld64u(inb + u + 16), w3 = ld64u(inb + u + 24);
+                    uint64_t *d = (uint64_t *)(ring + (u & (kPipeRing - 1)));
+                    d[0] = w0; d[1] = w1; d[2] = w2; d[3] = w3;
+                    if ((u & (kPipeRing - 1)) == 0) *(uint64_t *)(ring + kPipeRing) = w0;
+                    rlow = u;
+                }
+                asm volatile("" ::: "memory");
+                __hip_atomic_store(&shs->ring_low[lane], rlow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(&shs->ring_low[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            {  // prefetch touches after the ring work (before it: 28.78 vs 28.62 ms): they are HBM misses by design and P waits for each
+                const int target = inside ? max(cur - kAhead, 0) : low;
+                for (int g = 0; g < 8 && has && low > target; g++) {
+                    low = max(low - kLine, 0);
+                    touch_line(sbase + (low & ~3));
+                }
             }
             if (hd >= nmax) break;
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
