@@ -761,6 +761,9 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 
 constexpr int kPipeRing = 128;  // bytes of every chain's bitstream wave P keeps in LDS for stage A
 constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
+#ifndef MZD_PIPE_TOUCHES
+#define MZD_PIPE_TOUCHES 8  // lines wave P touches per chain and iteration at most
+#endif
 #ifndef MZD_PIPE_AHEAD
 #define MZD_PIPE_AHEAD 256  // bytes wave P keeps touched below every chain's cursor
 #endif
@@ -1130,9 +1133,14 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_pipe_poll" TAG "_%=\n"                                                                      \
     "L_pipe_spc" TAG "_%=:\n\t"                                                                             \
+    /* fast path: ring_low as read during the previous step (v236; it only ever decreases) */               \
+    "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    "v_cmp_gt_u32 vcc, v236, v201\n\t"                                                                      \
+    "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"                                                    \
+    "s_cbranch_vccz L_pipe_go" TAG "_%=\n\t"                                                                \
     MZD_PIPE_RINGCHK(TAG)
 // DM: the 8 bytes the previous step read from the ring; DL: where this step's go
-#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT)                                                     \
+#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT, RLOW)                                                    \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
     "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
     "v_lshl_add_u32 v200, %[sL" SA "], 1, %[cbL]\n\t"                                                       \
@@ -1145,6 +1153,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_add_u32 v209, v209, %[ringl]\n\t"                                                                    \
     "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
     "ds_read_b64 " DL ", v209\n\t" /* the 8 bytes below the window, for the next step */                    \
+    RLOW                                                                                                    \
     /* C <<= 8 * (k >> 3); k &= 7; then the bytes that come in from DM: C += (DM >> 1) >> (63 - 8nb) */    \
     "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
@@ -1208,6 +1217,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "s_cbranch_scc0 " OUT "\n\t"
 #define MZD_OUTE "L_pipe_oute_%="
 #define MZD_OUTO "L_pipe_outo_%="
+#define MZD_RLOW "ds_read_b32 v236, %[lane4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
 #define MZD_DA "v[232:233]"
 #define MZD_DB "v[234:235]"
                 asm volatile(
@@ -1217,6 +1227,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "v_mov_b32 v233, %[Dhi]\n\t"
                     "v_mov_b32 v234, %[Dlo]\n\t"
                     "v_mov_b32 v235, %[Dhi]\n\t"
+                    "v_mov_b32 v236, -1\n\t"  // no ring_low read ahead yet: the first batch check takes the slow path
                     "s_and_b32 s86, %[i], 3\n\t"
                     "s_cmp_eq_u32 s86, 0\n\t"
                     "s_cbranch_scc1 L_pipe_goe_%=\n\t"  // slots 0 and 4 make the check themselves
@@ -1239,16 +1250,16 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "s_cbranch_scc1 L_pipe_go6_%=\n\t"
                     "s_branch L_pipe_go7_%=\n"
                     MZD_PIPE_CHECK("0")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE)
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO)
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE)
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO, "")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO, MZD_RLOW)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     MZD_PIPE_CHECK("4")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE)
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO)
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE)
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO, "")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO, MZD_RLOW)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     "s_branch L_pipe_top0_%=\n"
                     "L_pipe_oute_%=:\n\t"  // left after an even slot: the new states are in set b
@@ -1283,13 +1294,14 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     : "memory", "vcc", "scc", "s86",
                       "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213",
                       "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
-                      "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235");
+                      "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236");
 #undef MZD_PIPE_STEP
 #undef MZD_PIPE_CHECK
 #undef MZD_PIPE_RINGCHK
 #undef MZD_PIPE_PUBLISH
 #undef MZD_OUTE
 #undef MZD_OUTO
+#undef MZD_RLOW
 #undef MZD_DA
 #undef MZD_DB
 #undef MZD_QT
@@ -1486,9 +1498,10 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             } else {
                 __hip_atomic_store(&shs->ring_low[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            {  // prefetch touches after the ring work (before it: 28.78 vs 28.62 ms): they are HBM misses by design and P waits for each
+            {  // prefetch touches after the ring work (before it: 28.78 vs 28.62 ms): they are HBM misses by design and P
+               // WAITS for each -- unthrottled touches (from a wavefront that never waits) crowd the CU's miss path: 30.7 ms
                 const int target = inside ? max(cur - kAhead, 0) : low;
-                for (int g = 0; g < 8 && has && low > target; g++) {
+                for (int g = 0; g < MZD_PIPE_TOUCHES && has && low > target; g++) {
                     low = max(low - kLine, 0);
                     touch_line(sbase + (low & ~3));
                 }
