@@ -1149,17 +1149,40 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             return;
         }
         const uint64_t kWindow = ctx->opt.seq_window_kib ? (uint64_t)ctx->opt.seq_window_kib << 10 : (1ull << 32) - 2 * MZD_IN_PAD - 4096;
-        uint32_t g = f0;
-        while (g < f1) {
+        // greedy cut first: how many launches does the range need at least?
+        auto cut = [&](uint32_t g, uint32_t limit_tasks, uint64_t &lo_out) -> uint32_t {  // frames [g, e) of one launch
             uint64_t lo = ~0ull, hi = 0;
             uint32_t e = g;
+            const uint32_t t0 = db->frame_seq_task[g];
             for (; e < f1; e++) {
+                if (e > g && db->frame_seq_task[e] - t0 >= limit_tasks) break;
                 if (db->frame_in_lo[e] > db->frame_in_hi[e]) continue;  // no sequences
                 const uint64_t nlo = std::min(lo, db->frame_in_lo[e]), nhi = std::max(hi, db->frame_in_hi[e]);
                 if (nhi - nlo > kWindow) break;
                 lo = nlo;
                 hi = nhi;
             }
+            lo_out = lo;
+            return e;
+        };
+        uint32_t n_launch = 0;
+        for (uint32_t g = f0; g < f1;) {
+            uint64_t lo;
+            const uint32_t e = cut(g, 0xFFFFFFFFu, lo);
+            g = e == g ? g + 1 : e;
+            n_launch++;
+        }
+        // several launches: give them equal numbers of whole rounds rather than a full window and a remainder
+        uint32_t limit = 0xFFFFFFFFu;
+        if (n_launch > 1) {
+            const uint64_t total = db->frame_seq_task[f1] - db->frame_seq_task[f0];
+            const uint64_t round = (uint64_t)nch * (uint64_t)std::max(ctx->num_cus, 1);
+            limit = (uint32_t)std::min<uint64_t>(((total + n_launch - 1) / n_launch + round - 1) / round * round, 0xFFFFFFFFu);
+        }
+        uint32_t g = f0;
+        while (g < f1) {
+            uint64_t lo;
+            uint32_t e = cut(g, limit, lo);
             if (e == g) {  // one frame wider than the window
                 launch_seq_tasks(db->frame_seq_task[g], db->frame_seq_task[g + 1] - db->frame_seq_task[g], false, 0);
                 e = g + 1;
