@@ -761,11 +761,15 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 
 constexpr int kPipeRing = 128;  // bytes of every chain's bitstream wave P keeps in LDS for stage A
 constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
+#ifndef MZD_PIPE_TOUCH_EVERY
+#define MZD_PIPE_TOUCH_EVERY 7  // mask on wave P's iteration count: it touches (and waits for the misses) only when
+                               // (iter & mask) == 0, so that the ring refills of the other iterations are not held up
+#endif
 #ifndef MZD_PIPE_TOUCHES
 #define MZD_PIPE_TOUCHES 8  // lines wave P touches per chain and iteration at most
 #endif
 #ifndef MZD_PIPE_AHEAD
-#define MZD_PIPE_AHEAD 256  // bytes wave P keeps touched below every chain's cursor
+#define MZD_PIPE_AHEAD 512  // bytes wave P keeps touched below every chain's cursor
 #endif
 struct PipeShared {
     uint32_t head1, tail1, head2, tail2;  // steps produced / consumed on the A->B and B->C queues
@@ -1477,6 +1481,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         constexpr int kAhead = MZD_PIPE_AHEAD, kLine = 128;
         uint32_t rlow = ((uint32_t)t.in_off + MZD_IN_PAD + t.in_size + 31u) & ~31u;  // ring: nothing yet
         uint8_t *ring = shs->ring[lane];
+        uint32_t iter = 0;
         for (;;) {
             const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)__hip_atomic_load(&shs->head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1501,12 +1506,13 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             {  // prefetch touches after the ring work (before it: 28.78 vs 28.62 ms): they are HBM misses by design and P
                // WAITS for each -- unthrottled touches (from a wavefront that never waits) crowd the CU's miss path: 30.7 ms
                 const int target = inside ? max(cur - kAhead, 0) : low;
-                for (int g = 0; g < MZD_PIPE_TOUCHES && has && low > target; g++) {
+                for (int g = 0; g < MZD_PIPE_TOUCHES && has && low > target && (iter & MZD_PIPE_TOUCH_EVERY) == 0; g++) {
                     low = max(low - kLine, 0);
                     touch_line(sbase + (low & ~3));
                 }
             }
             if (hd >= nmax) break;
+            iter++;
             __builtin_amdgcn_s_sleep(2);
         }
     }
