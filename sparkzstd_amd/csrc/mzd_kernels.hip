@@ -1139,12 +1139,13 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "L_pipe_spc" TAG "_%=:\n\t"                                                                             \
     /* fast path: ring_low as read during the previous step (v236; it only ever decreases) */               \
     "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t" /* v236 was read a step ago */                                               \
     "v_cmp_gt_u32 vcc, v236, v201\n\t"                                                                      \
     "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"                                                    \
     "s_cbranch_vccz L_pipe_go" TAG "_%=\n\t"                                                                \
     MZD_PIPE_RINGCHK(TAG)
 // DM: the 8 bytes the previous step read from the ring; DL: where this step's go
-#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT, RLOW)                                                    \
+#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT, RLOW, NLATE)                                                    \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
     "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
     "v_lshl_add_u32 v200, %[sL" SA "], 1, %[cbL]\n\t"                                                       \
@@ -1163,13 +1164,15 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
     "v_sub_u32 v208, 63, v206\n\t"                                                                          \
     "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
+    "s_waitcnt lgkmcnt(3+" NLATE ")\n\t" /* everything older than this step's reads: the ring read of the step before */ \
     "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
     "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
     "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
     "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
     "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
     "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    /* the three cells only: the (byte-misaligned, a cycle per lane) ring read behind them is for the next step */ \
+    "s_waitcnt lgkmcnt(" NLATE ")\n\t"                                                                      \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
     "v_and_b32 v217, 0x3ff, v203\n\t"       /* nl */                                                        \
@@ -1254,16 +1257,16 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "s_cbranch_scc1 L_pipe_go6_%=\n\t"
                     "s_branch L_pipe_go7_%=\n"
                     MZD_PIPE_CHECK("0")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE, "")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO, "")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE, "")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO, MZD_RLOW)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE, "", "1")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO, "", "1")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE, "", "1")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO, MZD_RLOW, "2")
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     MZD_PIPE_CHECK("4")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE, "")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO, "")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE, "")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO, MZD_RLOW)
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE, "", "1")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO, "", "1")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE, "", "1")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO, MZD_RLOW, "2")
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     "s_branch L_pipe_top0_%=\n"
                     "L_pipe_oute_%=:\n\t"  // left after an even slot: the new states are in set b
@@ -1277,8 +1280,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "v_cndmask_b32 %[sOa], %[sOb], %[sOa], vcc\n"
                     "L_pipe_done_%=:\n\t"
                     // the C++ side's lookahead: the 8 bytes below the (not yet normalised) window, from memory
+                    "s_waitcnt lgkmcnt(0)\n\t"  // the last step's ring read may still be on its way into these registers
                     "global_load_dwordx2 v[232:233], %[off], %[inb]\n\t"
-                    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                    "s_waitcnt vmcnt(0)\n\t"
                     "v_mov_b32 %[Dlo], v232\n\t"
                     "v_mov_b32 %[Dhi], v233\n\t"
                     : [sLa] "+v"(sL), [sMa] "+v"(sM), [sOa] "+v"(sO), [sLb] "+v"(sLb), [sMb] "+v"(sMb), [sOb] "+v"(sOb), [k] "+v"(k),
