@@ -725,7 +725,7 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 // ------------------------------------------------------------------------------------------
 // k_seq_pipe: the sequence decode as a THREE-STAGE PIPELINE ACROSS THE SIMDs OF ONE CU.
 //
-// The LDS-resident tables bound a CU to ~60 chains = one wavefront, and a lone wavefront pays
+// The LDS-resident tables bound a CU to 54-56 chains = one wavefront, and a lone wavefront pays
 // ~4.4 cycles per instruction of whatever type plus ~100 cycles per DEPENDENT LDS round trip: the
 // per-step instruction stream and its LDS trips ARE the step latency.  So the step is cut by
 // dependence, not by data: only what the next state needs stays on the serial chain, everything
@@ -738,9 +738,11 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 //       adds the base values (sequences.go:99-120); hands {LL, ML, offset value} to C.
 //   wave 2 (C): running sums + tile bases, repeat-offset resolution on a concrete-or-symbolic
 //       history (sequence_execution.go:65-114), record packing, the record stores.
-//   wave 3 (P): walks ahead of every chain's read cursor and touches the bitstream lines so
-//       that A's refills hit the CU's vL1D (A's own touches would return in order with, and
-//       so delay, its refill loads).
+//   wave 3 (P): feeds the bitstreams.  Keeps 128 bytes of every chain's stream in an LDS ring
+//       (32-byte units) from which A refills its bit window with one ds_read_b64 per step, and
+//       touches the lines further below the cursors so that its own unit loads hit L1 / L2.
+//       (A used to gather its refill bytes from global memory: 57 distinct lines per step, every
+//       128-byte line fetched ~40 times -- that address path bounded the step at full chain count.)
 //
 // LDS cell (2 bytes): next(10) | c6(6).  next = (baseline + size) >> nbits, from which nbits =
 // acc_log - highbit(next) and baseline + size = next << nbits (fse.go:209-213 backwards).  c6 is
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
 // Lanes without work, failed or finished are PARKED: bit budget 0 and a dummy state, so they
 // never move and need no exec masking.
 //
-// LDS: [CTc 128 dwords][PipeShared][cells: nch x 1280 x u16], nch <= kPipeMaxChains at launch.
+// LDS: [CTc 128 dwords][PipeShared: counters, queues, bitstream rings][cells: nch x 1280 x u16], nch <= kPipeMaxChains at launch.
 
 constexpr int kPipeRing = 128;  // bytes of every chain's bitstream wave P keeps in LDS for stage A
 constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queue depth (two batches)
