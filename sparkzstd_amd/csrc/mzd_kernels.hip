@@ -1931,26 +1931,25 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         // wave-uniform bound on the dword loop from two ballots (a shuffle reduction costs ~450 cycles)
                         const uint32_t mlc = __any(fast && ML > 16) ? 32u : (__any(fast && ML > 8) ? 16u : 8u);
                         if (fast) {
-                            // one exec region for the whole copy; inside, the two size classes of lds_store_upto16
-                            const uint32_t sbyte = mis + (uint32_t)srcM;
-                            const uint32_t sa = sbyte & 3;
-                            const uint32_t *base = (const uint32_t *)(buf + (sbyte & ~3u));
+                            // one exec region for the whole copy; inside, the two size classes of lds_store_upto16.
+                            // The source is read with byte-misaligned 8-byte LDS reads: they cost the LDS pipe a cycle
+                            // per ACTIVE lane, and a pass has ~7 -- cheaper than three aligned dword reads plus the
+                            // funnel shifts per 8 bytes (an aligned LDS instruction costs ~4.3 cycles whatever the lanes).
+                            const uint8_t *sp = lbuf + srcM;
                             uint8_t *d = lbuf + dstM;
-                            const uint32_t tb_byte = sbyte + (ML >= 4 ? ML - 4 : 0);  // tail dword = source bytes [ML-4, ML)
-                            const uint32_t *tp = (const uint32_t *)(buf + (tb_byte & ~3u));
-                            const uint32_t xt = __builtin_amdgcn_alignbyte(tp[1], tp[0], tb_byte & 3);
-                            uint32_t prev = base[0];
                             if (ML >= 4) {
                                 const uint32_t last = ML - 4;
-                                for (uint32_t j = 0; 4 * j < mlc; j++) {
-                                    const uint32_t nxt = base[j + 1];  // past the source: unused (and inside the buffer's slack)
-                                    const uint32_t x = __builtin_amdgcn_alignbyte(nxt, prev, sa);
+                                const uint32_t xt = ((const U32U *)(sp + last))->v;  // source bytes [ML-4, ML)
+                                for (uint32_t j = 0; 4 * j < mlc; j += 2) {
+                                    const uint64_t x2 = ((const U64U *)(sp + 4 * j))->v;  // past the source: unused (and inside the buffer's slack)
                                     // lanes whose copy is complete drop out pairwise (LDS time is per active lane)
-                                    if (j < 2 || 4 * (j & ~1u) < ML) st32u_l(d + min(4 * j, last), 4 * j <= last ? x : xt);
-                                    prev = nxt;
+                                    if (j < 2 || 4 * j < ML) {
+                                        st32u_l(d + min(4 * j, last), 4 * j <= last ? (uint32_t)x2 : xt);
+                                        st32u_l(d + min(4 * j + 4, last), 4 * j + 4 <= last ? (uint32_t)(x2 >> 32) : xt);
+                                    }
                                 }
                             } else {
-                                const uint32_t first = __builtin_amdgcn_alignbyte(base[1], prev, sa);
+                                const uint32_t first = ((const U32U *)sp)->v;
                                 const uint32_t h = ML >> 1, e = ML - 1;
                                 d[0] = (uint8_t)first;
                                 d[h] = (uint8_t)(first >> (8 * h));
