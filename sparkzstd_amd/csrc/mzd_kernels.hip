@@ -1609,6 +1609,13 @@ __device__ __forceinline__ void publish(uint32_t *vmap, uint32_t pos, uint32_t n
 }
 __device__ __forceinline__ uint32_t ld32u_g(const uint8_t *p) { return ((const U32U *)p)->v; }
 __device__ __forceinline__ void st32u_l(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
+// two consecutive (4-byte aligned) LDS dwords with one instruction; `addr` = LDS byte address
+__device__ __forceinline__ uint64_t lds_read2_u32(uint32_t addr)
+{
+    uint64_t v;
+    asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 
 // stores n (0..16) bytes held in w0..w3 (+ wt = bytes [n-4, n) when n >= 4) to LDS at d.
 // k_exec is bound by the CU's one scalar unit, and what it executes is mostly the exec-mask
@@ -1915,9 +1922,9 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     EXEC_STAT(3, 1);
                     bool ready = false;
                     if (pending && isShort) {
-                        const uint32_t v0 = __hip_atomic_load(&vmap[needw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t v1 = __hip_atomic_load(&vmap[needw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint64_t v = (uint64_t)v0 | ((uint64_t)v1 << 32);
+                        // both words in ONE LDS instruction (ds_read2_b32: an aligned LDS instruction costs the pipe ~4.3
+                        // cycles whatever the lanes); bits are only ever set, a stale word just delays the lane one pass
+                        const uint64_t v = lds_read2_u32((uint32_t)(uintptr_t)(vmap + needw));
                         ready = (v & needm) == needm;
                     }
                     asm volatile("" ::: "memory");  // data reads below stay below the validity reads
