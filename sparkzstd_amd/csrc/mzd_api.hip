@@ -1266,6 +1266,15 @@ extern "C" int mzd_debug_exec_stats(unsigned long long *out, int reset)
 }
 #endif
 
+#ifdef MZD_PIPE_STATS
+extern "C" int mzd_debug_pipe_stats(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_pipe_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_pipe_stats), z, sizeof z); }
+    return 0;
+}
+#endif
+
 int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_fse_entry *out, uint32_t cap)
 {
     if (!ctx || !db || !out || (size_t)table + 1 >= db->fse_dev_off.size()) return -MZD_ERR_INVALID_ARG;

@@ -773,6 +773,9 @@ constexpr int kPipeBatch = 4, kPipeDepth = 8;  // steps per consumer batch; queu
 #ifndef MZD_PIPE_AHEAD
 #define MZD_PIPE_AHEAD 512  // bytes wave P keeps touched below every chain's cursor
 #endif
+#ifdef MZD_PIPE_STATS  // whole-pass statistics of stage A (tools/pipe_stats.py): unlike -DMZD_PIPE_PROF, every workgroup counts
+__device__ unsigned long long g_pipe_stats[8];  // workgroups, steps, cycles of stage A, queue-full polls, ring polls
+#endif
 struct PipeShared {
     uint32_t head1, tail1, head2, tail2;  // steps produced / consumed on the A->B and B->C queues
     uint32_t progress[64];                // per chain: bytes of bitstream not yet requested by A
@@ -955,6 +958,9 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
 
         uint32_t tail_seen = 0;
         uint32_t polls = 0;  // diagnostics (-DMZD_PIPE_PROF prints it): queue-full polls | ring-not-ready polls << 16
+#ifdef MZD_PIPE_STATS
+        const long long stats_t0 = clock64();
+#endif
 #ifdef MZD_PIPE_PROF
         long long prof_wait = 0, prof_t0 = clock64(), prof_r0 = wall_clock64();
         if (blockIdx.x == 0 && lane == 0) printf("A: staging + init %lld cycles\n", prof_t0 - prof_k0);
@@ -1325,6 +1331,15 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->head1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#ifdef MZD_PIPE_STATS
+        if (lane == 0) {
+            atomicAdd(&g_pipe_stats[0], 1ull);
+            atomicAdd(&g_pipe_stats[1], (unsigned long long)nmax);
+            atomicAdd(&g_pipe_stats[2], (unsigned long long)(clock64() - stats_t0));
+            atomicAdd(&g_pipe_stats[3], (unsigned long long)(polls & 0xFFFF));
+            atomicAdd(&g_pipe_stats[4], (unsigned long long)(polls >> 16));
+        }
+#endif
 #ifdef MZD_PIPE_PROF
         if (blockIdx.x == 0 && lane == 0)
             printf("A: steps %u cycles %lld wait %lld real(100MHz) %lld queue-full polls %u ring polls %u\n", nmax, clock64() - prof_t0,
