@@ -306,6 +306,8 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         for (uint32_t i = lane; i < n32; i += 64) dst[i] = src[i];
     }
     __syncthreads();
+    // (all lanes still active here) largest MaxBits of the wavefront's tables: decides the bulk loop's refill spacing
+    const bool wide = __builtin_amdgcn_readfirstlane((int)wave_max_u32(t.max_bits)) <= 7;
     if ((t.in_size | t.out_size) == 0) return;  // null task
 
     const uint16_t *tbl = tbl_all + (size_t)(lane >> 2) * slot_cells;
@@ -319,23 +321,45 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     const uint32_t want = t.out_size;
 
     if (status == MZD_OK) {
-        // bulk: 16 symbols per iteration while at least 16*11 bits and 16 output slots remain
+        // bulk: 16 symbols per iteration while at least 16*11 bits and 16 output slots remain.  A refill is a
+        // per-lane gather (64 distinct lines per load): when every table of the wavefront has MaxBits <= 7, EIGHT
+        // symbols fit between two refills (k < 8 after a refill, 7 + 8 * 7 <= 64), else four (7 + 4 * 11 + window).
         while (cnt + 16 <= want && rem >= 16 * 11) {
             uint32_t w[4];
+            if (wide) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                br.refill();  // k < 8 afterwards; 4 symbols * 11 bits + 11-bit window <= 57
-                uint32_t acc = 0;
+                for (int g = 0; g < 4; g += 2) {
+                    br.refill();
+                    uint32_t acc0 = 0, acc1 = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t idx = (uint32_t)((br.C << br.k) >> (64 - mb));
-                    uint32_t e = tbl[idx];
-                    acc |= (e & 0xFF) << (8 * j);
-                    int nb = (int)(e >> 8);
-                    br.k += nb;
-                    rem -= nb;
+                    for (int j = 0; j < 8; j++) {
+                        uint32_t idx = (uint32_t)((br.C << br.k) >> (64 - mb));
+                        uint32_t e = tbl[idx];
+                        if (j < 4) acc0 |= (e & 0xFF) << (8 * j);
+                        else acc1 |= (e & 0xFF) << (8 * (j - 4));
+                        int nb = (int)(e >> 8);
+                        br.k += nb;
+                        rem -= nb;
+                    }
+                    w[g] = acc0;
+                    w[g + 1] = acc1;
                 }
-                w[g] = acc;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    br.refill();  // k < 8 afterwards; 4 symbols * 11 bits + 11-bit window <= 57
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t idx = (uint32_t)((br.C << br.k) >> (64 - mb));
+                        uint32_t e = tbl[idx];
+                        acc |= (e & 0xFF) << (8 * j);
+                        int nb = (int)(e >> 8);
+                        br.k += nb;
+                        rem -= nb;
+                    }
+                    w[g] = acc;
+                }
             }
             U128U v{w[0], w[1], w[2], w[3]};
             *(U128U *)(out + cnt) = v;
