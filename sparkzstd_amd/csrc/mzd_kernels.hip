@@ -322,11 +322,18 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
 
     if (status == MZD_OK) {
         // bulk: 16 symbols per iteration while at least 16*11 bits and 16 output slots remain.  A refill is a
-        // per-lane gather (64 distinct lines per load): when every table of the wavefront has MaxBits <= 7, EIGHT
-        // symbols fit between two refills (k < 8 after a refill, 7 + 8 * 7 <= 64), else four (7 + 4 * 11 + window).
-        while (cnt + 16 <= want && rem >= 16 * 11) {
-            uint32_t w[4];
-            if (wide) {
+        // per-lane gather (64 distinct lines per load) and k_huf shares the CU's address path with k_seq_pipe
+        // (the faster k_huf is out of the way, the shorter the pass), so:
+        //  - when every table of the wavefront has MaxBits <= 7, EIGHT symbols fit between two refills (k < 8 after
+        //    a refill, 7 + 8 * 7 <= 64): half the gathers (same-box A/B of the pass: 26.68 -> 26.05 ms);
+        //  - else four symbols per refill (7 + 4 * 11 + window), but a load brings SIXTEEN bytes and serves TWO
+        //    refills: the first takes its top bytes, the second the bytes `s` below the top (s <= 7 = what the first
+        //    consumed) and issues the next load.  Bytes below the stream's start may be in those 16; only indices
+        //    >= 2 of them are ever taken.  (Config 3, MaxBits 11: 3.43 -> 3.18 ms; with eight symbols per refill
+        //    the extra shifts cost more than the gathers saved: 25.5 -> 25.7 ms.)
+        if (wide) {
+            while (cnt + 16 <= want && rem >= 16 * 11) {
+                uint32_t w[4];
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
                     br.refill();
@@ -344,10 +351,38 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                     w[g] = acc0;
                     w[g + 1] = acc1;
                 }
-            } else {
+                U128U v{w[0], w[1], w[2], w[3]};
+                *(U128U *)(out + cnt) = v;
+                cnt += 16;
+            }
+        } else if (cnt + 16 <= want && rem >= 16 * 11) {
+            const uint8_t *sb = br.s;
+            // Q = the 16 bytes below the window; its upper half is the 8-byte lookahead the reader already holds
+            uint64_t Qhi = br.D, Qlo = ld64u(sb + max(br.ptr - 16, -16));
+            uint32_t s8 = 0;  // 8 * (bytes of Q already taken)
+            auto refill_first = [&]() {  // takes the top bytes of a fresh Q
+                const int nb = br.k >> 3, sh = nb * 8;
+                br.C = (br.C << sh) | ((Qhi >> 1) >> (63 - sh));
+                br.ptr -= nb;
+                br.k &= 7;
+                s8 = (uint32_t)sh;
+            };
+            auto refill_second = [&]() {  // takes the bytes s below the top of Q, then requests the next Q
+                const int nb = br.k >> 3, sh = nb * 8;
+                const uint64_t M = (Qhi << s8) | ((Qlo >> 1) >> (63 - s8));
+                br.C = (br.C << sh) | ((M >> 1) >> (63 - sh));
+                br.ptr -= nb;
+                br.k &= 7;
+                const U128U q = *(const U128U *)(sb + max(br.ptr - 16, -16));  // ONE 16-byte gather
+                Qlo = (uint64_t)q.x | ((uint64_t)q.y << 32);
+                Qhi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+            };
+            do {
+                uint32_t w[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    br.refill();  // k < 8 afterwards; 4 symbols * 11 bits + 11-bit window <= 57
+                    if ((g & 1) == 0) refill_first();
+                    else refill_second();
                     uint32_t acc = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -360,10 +395,11 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                     }
                     w[g] = acc;
                 }
-            }
-            U128U v{w[0], w[1], w[2], w[3]};
-            *(U128U *)(out + cnt) = v;
-            cnt += 16;
+                U128U v{w[0], w[1], w[2], w[3]};
+                *(U128U *)(out + cnt) = v;
+                cnt += 16;
+            } while (cnt + 16 <= want && rem >= 16 * 11);
+            br.D = br.load_below(br.ptr - 8);  // back to the 8-byte lookahead of the symbol-by-symbol tail
         }
         // tail: symbol by symbol
         while (cnt < want && rem > 0) {
