@@ -307,7 +307,8 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     }
     __syncthreads();
     // (all lanes still active here) largest MaxBits of the wavefront's tables: decides the bulk loop's refill spacing
-    const bool wide = __builtin_amdgcn_readfirstlane((int)wave_max_u32(t.max_bits)) <= 7;
+    const uint32_t mbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(t.max_bits));
+    const bool wide = mbw <= 7;
     if ((t.in_size | t.out_size) == 0) return;  // null task
 
     const uint16_t *tbl = tbl_all + (size_t)(lane >> 2) * slot_cells;
@@ -331,6 +332,25 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         //    consumed) and issues the next load.  Bytes below the stream's start may be in those 16; only indices
         //    >= 2 of them are ever taken.  (Config 3, MaxBits 11: 3.43 -> 3.18 ms; with eight symbols per refill
         //    the extra shifts cost more than the gathers saved: 25.5 -> 25.7 ms.)
+        if (mbw <= 5) {
+            // ELEVEN symbols between two refills (7 + 11 * 5 <= 64): 32 symbols per iteration with three refills
+            while (cnt + 32 <= want && rem >= 32 * 5) {
+                uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    if (j == 0 || j == 11 || j == 22) br.refill();
+                    uint32_t idx = (uint32_t)((br.C << br.k) >> (64 - mb));
+                    uint32_t e = tbl[idx];
+                    w[j >> 2] |= (e & 0xFF) << (8 * (j & 3));
+                    int nb = (int)(e >> 8);
+                    br.k += nb;
+                    rem -= nb;
+                }
+                *(U128U *)(out + cnt) = U128U{w[0], w[1], w[2], w[3]};
+                *(U128U *)(out + cnt + 16) = U128U{w[4], w[5], w[6], w[7]};
+                cnt += 32;
+            }
+        }
         if (wide) {
             while (cnt + 16 <= want && rem >= 16 * 11) {
                 uint32_t w[4];
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         }
         // tail: symbol by symbol
         while (cnt < want && rem > 0) {
-            br.refill();
+            if (br.k + mb > 56) br.refill();  // only when the window runs low: every refill is a gather
             uint32_t idx = (uint32_t)((br.C << br.k) >> (64 - mb));
             uint32_t e = tbl[idx];
             out[cnt++] = (uint8_t)(e & 0xFF);
