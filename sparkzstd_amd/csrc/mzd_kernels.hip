@@ -1528,6 +1528,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
+            uint64_t rr[kPipeBatch];
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
                 const uint32_t j = j0 + u;
@@ -1553,7 +1554,18 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                 outPos += act ? LL + ML : 0u;
                 err_size |= outPos > kBlockMax;  // a block regenerates <= 128 KiB
                 const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
-                if (act) myrec[j] = (uint64_t)lo | ((uint64_t)((hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32))) << 32);
+                rr[u] = (uint64_t)lo | ((uint64_t)((hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32))) << 32);
+            }
+            // the batch's records: two 16-byte stores per lane instead of four 8-byte ones (every store is a
+            // scatter over the chains' record streams through the CU's one address path)
+            if (j0 + (uint32_t)kPipeBatch <= my_n) {
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+                *(u64x2 *)(myrec + j0) = u64x2{rr[0], rr[1]};
+                *(u64x2 *)(myrec + j0 + 2) = u64x2{rr[2], rr[3]};
+            } else {
+#pragma unroll
+                for (int u = 0; u < kPipeBatch; u++)
+                    if (j0 + u < my_n) myrec[j0 + u] = rr[u];
             }
         }
         status = err_unsup ? MZD_ERR_UNSUPPORTED : (err_off ? MZD_ERR_OFFSET : (err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK));
