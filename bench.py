@@ -9,12 +9,18 @@ tables are resident in HBM before the timed region; outputs stay in HBM.
 
 Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
 time).  Frames are independent, so ranks simply take disjoint frame ranges: no data-path collective.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N ranks (child
+processes, before anything touches the GPU) and relays rank 0's line; under torchrun
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -25,6 +31,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SOURCES = ("sparkzstd_amd/csrc/mzd_kernels.hip", "sparkzstd_amd/csrc/mzd_api.hip", "sparkzstd_amd/csrc/mzd_device.h")
+
+
+def kernel_src_sha16():
+    """Identity of the device code a counter file was measured on (the GPU box has no .git): a traffic file
+    carries it and is only quoted when it matches the sources this run was built from."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -51,7 +68,32 @@ def parse():
                     help="host time budget for generating the synthetic batch; if all-distinct frames would "
                          "take longer, fewer distinct frames are generated and physically replicated")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--traffic-from", default="", help="JSON written by tools/profile_round.sh in the same gpurun "
+                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r2_traffic_cfg<N>.json. "
+                    "Quoted only if its kernel_src_sha16 and workload match this run")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the measured copy ceiling (mzd_measure_copy)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`bench.py --gpus N` outside torchrun: the parent spawns the N ranks as fresh child processes BEFORE it has
+    touched the GPU (never re-executes a process that initialised HIP), relays rank 0's JSON line, and exits with
+    the worst child's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def usable_cores():
@@ -131,21 +173,70 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
             _, okr = run(0, sample, cores)
             ok2 = ok2 and okr
         dt = (time.perf_counter() - t0) / reps
-    return {"value": round(sample * frame_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample} frames of the same batch, oracle (C restatement of the reference "
-                      f"algorithm) on {cores} host threads ({os.cpu_count()} hardware threads, cgroup quota "
-                      f"{quota}), {dt:.2f}s per pass", "ok": bool(ok and ok2)}
+    # the same port on ONE thread ("(i) 1 thread, (ii) all host cores")
+    n1 = int(max(8, min(n_total, rate / max(cores, 1) * min(3.0, budget_s / 3))))
+    dt1, ok1 = run(0, n1, 1)
+    res = {"value": round(sample * frame_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+           "sample": f"first {sample} frames of the same batch, oracle (C restatement of the reference "
+                     f"algorithm) on {cores} host threads ({os.cpu_count()} hardware threads, cgroup quota "
+                     f"{quota}), {dt:.2f}s per pass", "ok": bool(ok and ok2 and ok1),
+           "one_thread": {"value": round(n1 * frame_bytes / dt1 / 1e6, 1), "unit": "MB/s", "cores": 1,
+                          "sample": f"first {n1} frames, {dt1:.2f}s"}}
+    res["libzstd"] = libzstd_line(blob, off, ln, frame_bytes, n1, cores)
+    return res
+
+
+def libzstd_line(blob, off, ln, frame_bytes, n1, cores):
+    """Context only: libzstd through dlopen if the box has one -- third-party, NOT the
+    reference and not a port of it; null when absent."""
+    import ctypes
+    try:
+        Z = ctypes.CDLL("libzstd.so.1")
+        Z.ZSTD_decompress.restype = ctypes.c_size_t
+        Z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        Z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+        Z.ZSTD_versionNumber.restype = ctypes.c_uint
+    except (OSError, AttributeError):
+        return None
+
+    def run(first, count, nthreads):
+        per = (count + nthreads - 1) // nthreads
+        oks = []
+
+        def work(a, b):
+            dst = np.zeros(frame_bytes + 64, dtype=np.uint8)
+            good = True
+            for i in range(a, b):
+                r = Z.ZSTD_decompress(dst.ctypes.data, dst.size, blob.ctypes.data + int(off[i]), int(ln[i]))
+                good = good and r == frame_bytes
+            oks.append(good)
+        ths = [threading.Thread(target=work, args=(first + t * per, min(first + count, first + (t + 1) * per))) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return time.perf_counter() - t0, all(oks)
+    n = min(len(off), max(8, n1))
+    dt1, ok1 = run(0, n, 1)
+    nall = min(len(off), n * cores)
+    dta, oka = run(0, nall, cores)
+    return {"version": int(Z.ZSTD_versionNumber()), "one_thread_MBs": round(n * frame_bytes / dt1 / 1e6, 1),
+            "all_threads_MBs": round(nall * frame_bytes / dta / 1e6, 1), "cores": cores, "ok": bool(ok1 and oka),
+            "note": "context only: third-party libzstd via dlopen, not the reference"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1 and a.gpus == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
+    assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
     # test hooks (tests of the N>1 control flow on a 1-GPU box): MZD_BENCH_BACKEND=gloo, MZD_BENCH_DEVICE=0
     backend = os.environ.get("MZD_BENCH_BACKEND", "nccl")
@@ -246,6 +337,7 @@ def main():
     for _ in range(a.steps):
         rb.run(stream)
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0  # this rank's own K steps (before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -272,6 +364,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item())
 
+    # every rank's own figures (frames, own wall time per step, own path time from its HIP events, algorithmic GB/s)
+    kms_all = dict(kms)
+    my_path_ms = kms_all.get("path") or sum(v for k, v in kms_all.items() if v > 0)
+    my_alg = int(stats.compressed_bytes) + per * frame_bytes
+    mine = torch.tensor([float(rank), float(torch.cuda.current_device()), float(per), my_elapsed / a.steps * 1e3, my_path_ms,
+                         my_alg / (my_path_ms * 1e-3) / 1e9 if my_path_ms > 0 else 0.0, float(int(stats.compressed_bytes))],
+                        dtype=torch.float64, device=red_dev)
+    if world > 1:
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    else:
+        gathered = [mine]
+    per_gpu = [{"rank": int(g[0].item()), "device": int(g[1].item()), "frames": int(g[2].item()),
+                "ms_per_step": round(g[3].item(), 4), "path_ms": round(g[4].item(), 4),
+                "algorithmic_GBs": round(g[5].item(), 1), "hbm_frac": round(g[5].item() / HBM_PEAK_GBS, 4)} for g in gathered]
+    c_bytes_all = sum(int(g[6].item()) for g in gathered)
+
+    # measured copy ceiling: a plain 16 B/lane streaming kernel that reads C and writes D bytes (this rank's)
+    ceiling = None
+    if rank == 0 and not a.no_ceiling:
+        rb_bytes, wb_bytes = int(stats.compressed_bytes), per * frame_bytes
+        try:
+            cms = ctx.measure_copy(rb_bytes, wb_bytes, 10)
+            ceiling = {"GBs": round((rb_bytes + wb_bytes) / (cms * 1e-3) / 1e9, 1), "ms": round(cms, 4),
+                       "kernel": "k_copy_ceiling: plain 16 B/lane streaming copy, same C bytes read + D bytes written"}
+        except Exception as e:  # noqa: BLE001
+            ceiling = {"error": str(e)}
+
     if rank == 0:
         total_frames = per * world
         d_bytes = total_frames * frame_bytes
@@ -285,19 +405,29 @@ def main():
         xxh_ms = kms.pop("k_xxh64", None)  # optional extension, reported on its own below
         dom = max(kms, key=lambda k: kms[k]) if kms else None
         achieved = alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else None
-        # HBM traffic per launch from the committed PMC passes (profiles/r1_traffic.json): sum over the
-        # three kernels of FETCH_SIZE (raw, may under-count up to 2x) + WRITE_SIZE, only valid for the
-        # default workload / geometry it was measured on
-        traffic = None
+        # HBM traffic per launch from PMC passes (FETCH_SIZE + WRITE_SIZE, separate --pmc runs, tools/profile_round.sh):
+        # quoted only when the file was measured on THIS device code and THIS workload
+        traffic, traffic_note = None, None
+        tpath = a.traffic_from or os.path.join(ROOT, "profiles", f"r2_traffic_cfg{a.config}.json")
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if a.config == 4 and per == 65536:
+            tj = json.load(open(tpath))
+            if tj.get("kernel_src_sha16") != kernel_src_sha16():
+                traffic_note = f"{os.path.basename(tpath)} was measured on other device code ({tj.get('kernel_src_sha16')}): not quoted"
+            elif tj.get("config") != a.config or tj.get("frames_per_gpu") != per or tj.get("frame_bytes") != frame_bytes:
+                traffic_note = f"{os.path.basename(tpath)} is for another workload: not quoted"
+            else:
                 traffic = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in tj["kernels"].items() if k != "k_init")
-        except Exception:
-            traffic = None
+                traffic_note = (f"{os.path.basename(tpath)}: FETCH_SIZE (raw; gfx950 under-counts wide streaming reads up to 2x) + "
+                                f"WRITE_SIZE summed over the pass's kernels")
+        except FileNotFoundError:
+            traffic_note = "no counter file for this workload"
+        except Exception as e:  # noqa: BLE001
+            traffic_note = f"unreadable counter file: {e}"
         roof = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_note,
+                "copy_ceiling": ceiling,
+                "frac_of_copy_ceiling": round(achieved / ceiling["GBs"], 4) if achieved and ceiling and ceiling.get("GBs") else None,
                 "kernel": f"hot path = k_huf -> k_seq -> k_exec (k_seq tail round overlaps k_exec of the head frames); "
                           f"achieved = algorithmic bytes / path time; dominant {dom}",
                 "path_ms": round(path_ms, 4),
@@ -319,12 +449,13 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": names.get(a.config, str(a.config)), "frames_per_gpu": per,
-                       "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes,
+                       "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes, "compressed_bytes_all_gpus": c_bytes_all,
                        "sequences_per_frame": round(float(nseq.mean()), 1), "distinct_frames_per_gpu": distinct,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 128,
                        "exec_chunk": a.exec_chunk or 8192},
-            "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok,
+            "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok, "ranks_seen": len(per_gpu), "per_gpu": per_gpu,
+            "kernel_src_sha16": kernel_src_sha16(),
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 3), "upload": round(t_upload, 3),
                         "tables": "host" if a.host_tables else "device",

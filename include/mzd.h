@@ -327,6 +327,40 @@ int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_f
 /* the same for Huffman decode table `table` (1 << max_bits cells) */
 int mzd_batch_read_huf_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_huf_entry *out, uint32_t cap);
 
+/* ------------------------------------------------------------------ measurement and test hooks
+ * Not part of the seam: they exist so that bench.py can quote its roofline fraction against a MEASURED copy
+ * ceiling and so that the parity tests can look at the stage boundaries the reference exposes as
+ * Go values (literals.go:283-361 LiteralSection.Data, sequences.go:11-15 Sequence) and drive the device's bit
+ * reader like bitstream/reversebitstream_test.go drives Reversebitstream. */
+
+/* Plain streaming kernel (16 bytes per lane, grid-stride): reads read_bytes once and writes write_bytes once
+ * (device buffers allocated and freed inside the call), `iters` timed launches after one warm-up; *ms = average
+ * duration of one launch from HIP events on the context's stream.  (read_bytes + write_bytes) / *ms is the
+ * achievable ceiling for a pass whose algorithmic bytes are C = read_bytes in and D = write_bytes out. */
+int mzd_measure_copy(mzd_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, int iters, float *ms);
+
+/* Scratch of a resident batch after mzd_batch_run + mzd_sync, copied to the host.  `offset` and `bytes` are
+ * in bytes of the array; reading past its end gives MZD_ERR_INVALID_ARG. */
+enum {
+    MZD_DEBUG_LITERALS = 0,  /* regenerated Huffman literals; a block's start: mzd_debug_block.lit_src */
+    MZD_DEBUG_RECORDS = 1,   /* 8 bytes per sequence: LL:17 | ML:18 | offset:29 (bit 28 of the offset field set:
+                                symbolic "history slot (u & 3) at block start minus (u >> 2)", u = field & 0x0FFFFFFF) */
+    MZD_DEBUG_TILES = 2,     /* 8 bytes per 64 sequences: running (literal position, output position) of the block */
+    MZD_DEBUG_BLOCKS = 3     /* mzd_debug_block per block of the batch */
+};
+typedef struct mzd_debug_block {
+    uint64_t src_off, lit_src, rec_off; /* lit_src: offset in MZD_DEBUG_LITERALS (Huffman) or in the input blob (Raw / RLE literals) */
+    uint32_t size, lit_regen, n_seq, tile_off;
+    uint8_t type, lit_type, pad[6];
+} mzd_debug_block;
+int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset, void *dst, uint64_t bytes);
+
+/* The device's backward bit reader (row B0: bitstream/reversebitstream.go) on a raw stream: n_reads calls of
+ * Read(nbits[i]), nbits[i] <= 32; values[i] = what Read returned, bits_still[i] = BitsStillInStream() after it
+ * (reversebitstream.go:13-15: -1 == exactly empty, below: over-read, which reads zeros :23-27,67-75). */
+int mzd_debug_backbits(mzd_ctx *ctx, const uint8_t *stream, uint32_t len, const uint8_t *nbits, uint32_t n_reads,
+                       uint64_t *values, int64_t *bits_still);
+
 /* ------------------------------------------------------------------ host planner
  * C++ restatement of the reference's host side, exposed in C so that tests, the
  * bench and the Python mirror can drive the device without Go:

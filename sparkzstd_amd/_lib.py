@@ -24,7 +24,18 @@ EXPORTS = [
     "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table", "mzd_batch_read_huf_table",
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
+    "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits",
 ]
+
+MZD_DEBUG_LITERALS, MZD_DEBUG_RECORDS, MZD_DEBUG_TILES, MZD_DEBUG_BLOCKS = 0, 1, 2, 3
+
+
+class DebugBlock(ctypes.Structure):
+    _fields_ = [("src_off", ctypes.c_uint64), ("lit_src", ctypes.c_uint64), ("rec_off", ctypes.c_uint64),
+                ("size", ctypes.c_uint32), ("lit_regen", ctypes.c_uint32), ("n_seq", ctypes.c_uint32),
+                ("tile_off", ctypes.c_uint32), ("type", ctypes.c_uint8), ("lit_type", ctypes.c_uint8),
+                ("pad", ctypes.c_uint8 * 6)]
+
 
 
 class FrameDesc(ctypes.Structure):
@@ -149,6 +160,9 @@ def load():
         "mzd_plan_add_frames": (i32, [vp, vp, vp, vp, u32, u32]),
         "mzd_plan_finalize": (ctypes.POINTER(Batch), [vp]),
         "mzd_plan_frame_status": (i32, [vp, u32]),
+        "mzd_measure_copy": (i32, [vp, u64, u64, i32, ctypes.POINTER(ctypes.c_float)]),
+        "mzd_batch_debug_read": (i32, [vp, vp, i32, u64, vp, u64]),
+        "mzd_debug_backbits": (i32, [vp, vp, u32, vp, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

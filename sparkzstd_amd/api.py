@@ -127,6 +127,25 @@ class ResidentBatch:
             raise MzdError(-n, "mzd_batch_read_huf_table: " + self.ctx.last_error())
         return out[:n].copy()
 
+    def debug_read(self, what: int, dtype, offset_bytes: int = 0, count: int = None) -> np.ndarray:
+        """Scratch of the batch after run() (mzd_batch_debug_read): what = _lib.MZD_DEBUG_*; `count` items of
+        `dtype` from byte offset `offset_bytes`."""
+        out = np.empty(count, dtype=dtype)
+        rc = self.ctx._L.mzd_batch_debug_read(self.ctx._c, self._h, what, offset_bytes,
+                                              out.ctypes.data if out.size else None, out.nbytes)
+        if rc:
+            raise MzdError(rc, "mzd_batch_debug_read: " + self.ctx.last_error())
+        return out
+
+    def debug_blocks(self, n_blocks: int):
+        """The device view of every block (mzd_debug_block): where its literals / records / tiles are."""
+        arr = (_lib.DebugBlock * n_blocks)()
+        rc = self.ctx._L.mzd_batch_debug_read(self.ctx._c, self._h, _lib.MZD_DEBUG_BLOCKS, 0, ctypes.addressof(arr) if n_blocks else None,
+                                              ctypes.sizeof(arr))
+        if rc:
+            raise MzdError(rc, "mzd_batch_debug_read: " + self.ctx.last_error())
+        return arr
+
     def device_out_ptr(self):
         return self.ctx._L.mzd_batch_device_out(self._h)
 
@@ -216,6 +235,27 @@ class Context:
         if rc:
             raise MzdError(rc, "mzd_batch_upload_frames: " + self.last_error())
         return ResidentBatch(self, h, None, n_frames=off.size)
+
+    def measure_copy(self, read_bytes: int, write_bytes: int, iters: int = 10) -> float:
+        """ms per launch of the plain streaming kernel that reads read_bytes and writes write_bytes (the copy
+        ceiling roofline fractions are quoted against, mzd_measure_copy)."""
+        ms = ctypes.c_float()
+        rc = self._L.mzd_measure_copy(self._c, int(read_bytes), int(write_bytes), iters, ctypes.byref(ms))
+        if rc:
+            raise MzdError(rc, "mzd_measure_copy: " + self.last_error())
+        return float(ms.value)
+
+    def backbits(self, stream: bytes, reads):
+        """The device's backward bit reader on a raw stream (mzd_debug_backbits): -> (values, bits_still_in_stream)"""
+        nb = np.asarray(reads, dtype=np.uint8)
+        buf = np.frombuffer(bytes(stream), dtype=np.uint8) if len(stream) else np.zeros(1, dtype=np.uint8)
+        vals = np.zeros(nb.size, dtype=np.uint64)
+        left = np.zeros(nb.size, dtype=np.int64)
+        rc = self._L.mzd_debug_backbits(self._c, buf.ctypes.data, len(stream), nb.ctypes.data, nb.size, vals.ctypes.data,
+                                        left.ctypes.data)
+        if rc:
+            raise MzdError(rc, "mzd_debug_backbits: " + self.last_error())
+        return [int(v) for v in vals], [int(v) for v in left]
 
     def sync(self):
         rc = self._L.mzd_sync(self._c)

@@ -100,6 +100,7 @@ struct mzd_dbatch {
     std::vector<uint64_t> frame_in_lo, frame_in_hi;      // host: extent of the frame's sequence bitstreams in the blob (lo > hi: none)
     float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
     uint64_t out_size = 0;
+    uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
     mzd_batch_stats stats{};
 };
 
@@ -636,6 +637,9 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     HIP_OR_FAIL(hipMalloc((void **)&db->d_recs, std::max<uint64_t>(rec_total, 1) * 8));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_tiles, std::max<uint64_t>(tile_total, 1) * sizeof(TileBase)));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
+    db->n_recs = rec_total;
+    db->n_tiles = tile_total;
+    db->lit_bytes = lit_total;
     HIP_OR_FAIL(hipMalloc((void **)&db->d_status, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_out_len, std::max<size_t>(b->n_frames, 1) * sizeof(uint64_t)));
     HIP_OR_FAIL(hipMemset(db->d_status, 0xFF, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
@@ -833,6 +837,9 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     ENSURE(db->d_recs, db->cap.recs, std::max<uint64_t>(n_rec, 1) * 8);
     ENSURE(db->d_tiles, db->cap.tiles, std::max<uint64_t>(n_tile, 1) * sizeof(TileBase));
     ENSURE(db->d_litbuf, db->cap.lit, lit_total + 64);
+    db->n_recs = n_rec;
+    db->n_tiles = n_tile;
+    db->lit_bytes = lit_total;
     ENSURE(db->d_status, db->cap.status, nf1 * sizeof(int32_t));
     ENSURE(db->d_out_len, db->cap.out_len, nf1 * sizeof(uint64_t));
     HIP_OR_FAIL(hipMemsetAsync(db->d_status, 0xFF, nf1 * sizeof(int32_t), s));
@@ -1378,6 +1385,88 @@ void mzd_timing_reset(mzd_ctx *ctx, int enable)
     if (!ctx) return;
     ctx->runs = 0;
     ctx->timing = enable != 0;
+}
+
+int mzd_measure_copy(mzd_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, int iters, float *ms)
+{
+    if (!ctx || !ms || iters < 1 || write_bytes < 16) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_read = std::min(read_bytes, write_bytes) / 16, n_write = write_bytes / 16;
+    u32x4 *src = nullptr, *dst = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&src, std::max<uint64_t>(n_read, 1) * 16));
+    hipError_t e = hipMalloc((void **)&dst, n_write * 16);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (e == hipSuccess) e = hipMemsetAsync(src, 0x5A, std::max<uint64_t>(n_read, 1) * 16, ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&t0);
+    if (e == hipSuccess) e = hipEventCreate(&t1);
+    // grid: 8 workgroups of 256 threads per CU, the rest grid-stride
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_write + 255) / 256, (uint64_t)std::max(ctx->num_cus, 1) * 8);
+    if (e == hipSuccess) {
+        k_copy_ceiling<<<grid, 256, 0, ctx->stream>>>(src, dst, n_read, n_write);  // warm-up
+        e = hipEventRecord(t0, ctx->stream);
+        for (int i = 0; i < iters; i++) k_copy_ceiling<<<grid, 256, 0, ctx->stream>>>(src, dst, n_read, n_write);
+        if (e == hipSuccess) e = hipEventRecord(t1, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        float t = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, t0, t1);
+        *ms = t / (float)iters;
+    }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    HIP_TRY(ctx, e);
+    return MZD_OK;
+}
+
+static_assert(sizeof(mzd_debug_block) == sizeof(DBlock) && offsetof(mzd_debug_block, tile_off) == offsetof(DBlock, tile_off) &&
+              offsetof(mzd_debug_block, lit_type) == offsetof(DBlock, lit_type), "mzd_debug_block mirrors DBlock");
+
+int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset, void *dst, uint64_t bytes)
+{
+    if (!ctx || !db || (!dst && bytes)) return MZD_ERR_INVALID_ARG;
+    const void *base = nullptr;
+    uint64_t size = 0;
+    switch (what) {
+    case MZD_DEBUG_LITERALS: base = db->d_litbuf; size = db->lit_bytes; break;
+    case MZD_DEBUG_RECORDS: base = db->d_recs; size = db->n_recs * 8; break;
+    case MZD_DEBUG_TILES: base = db->d_tiles; size = db->n_tiles * sizeof(TileBase); break;
+    case MZD_DEBUG_BLOCKS: base = db->d_blocks; size = (uint64_t)db->n_blocks * sizeof(DBlock); break;
+    default: return MZD_ERR_INVALID_ARG;
+    }
+    if (offset > size || bytes > size - offset) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (bytes) HIP_TRY(ctx, hipMemcpy(dst, (const uint8_t *)base + offset, bytes, hipMemcpyDeviceToHost));
+    return MZD_OK;
+}
+
+int mzd_debug_backbits(mzd_ctx *ctx, const uint8_t *stream, uint32_t len, const uint8_t *nbits, uint32_t n_reads,
+                       uint64_t *values, int64_t *bits_still)
+{
+    if (!ctx || (!stream && len) || !nbits || !values || !bits_still || !n_reads) return MZD_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n_reads; i++)
+        if (nbits[i] > 32) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t kPad = 16;  // the reader's window loads reach 8 bytes below the stream and 8 above its end
+    uint8_t *d = nullptr;
+    const size_t sz = (size_t)kPad + len + kPad + n_reads + 8 + (size_t)n_reads * 16;
+    HIP_TRY(ctx, hipMalloc((void **)&d, sz));
+    uint8_t *d_stream = d + kPad, *d_nb = d_stream + len + kPad;
+    uint64_t *d_val = (uint64_t *)(d + ((kPad + len + kPad + n_reads + 7) & ~(size_t)7));
+    int64_t *d_left = (int64_t *)(d_val + n_reads);
+    hipError_t e = hipMemset(d, 0xEE, sz);  // slack bytes are NOT zero: the reader itself must mask below the start
+    if (e == hipSuccess && len) e = hipMemcpy(d_stream, stream, len, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_nb, nbits, n_reads, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_test_backbits<<<1, 64, 0, ctx->stream>>>(d_stream, len, d_nb, n_reads, d_val, d_left);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(values, d_val, (size_t)n_reads * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(bits_still, d_left, (size_t)n_reads * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(ctx, e);
+    return MZD_OK;
 }
 
 int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)

@@ -2284,4 +2284,55 @@ __global__ __launch_bounds__(64) void k_xxh64(const uint8_t *__restrict__ out_bl
     if ((uint32_t)h != fr.checksum) frame_status[f] = MZD_ERR_CHECKSUM;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_copy_ceiling: the achievable-copy ceiling the roofline fractions are quoted against next to the
+// 8 TB/s nominal peak.  Plain streaming kernel, 16 bytes per lane, grid-stride, four
+// independent loads in flight per lane: reads the first n_read 16-byte words of src once and writes
+// n_write words of dst once (words past n_read repeat the lane's last loaded value: a write-only
+// stream, like an RLE fill) -- the algorithmic bytes of a pass, C in and D out, and nothing else.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_ceiling(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst,
+                                                       uint64_t n_read, uint64_t n_write)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    u32x4 v[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_write; i += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t j = i + u * stride;
+            if (j < n_read) v[u] = __builtin_nontemporal_load(src + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t j = i + u * stride;
+            if (j < n_write) __builtin_nontemporal_store(v[u], dst + j);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_test_backbits: the device's backward bit reader (BackBits, row B0 of SURVEY 8a) driven like
+// bitstream/reversebitstream_test.go drives Reversebitstream: a list of Read(n) calls on a raw
+// stream (no padding marker), values and BitsStillInStream() back.  Test hook only; one lane.
+__global__ void k_test_backbits(const uint8_t *stream, uint32_t len, const uint8_t *nbits, uint32_t n_reads,
+                                uint64_t *values, int64_t *bits_still)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    BackBits br;
+    br.s = stream;
+    br.ptr = (int)len - 8;
+    br.C = br.load_below(br.ptr);
+    br.D = br.load_below(br.ptr - 8);
+    br.k = 0;
+    int64_t cursor = 8ll * len - 1;  // reversebitstream.go:9-11: index of the next bit
+    for (uint32_t i = 0; i < n_reads; i++) {
+        const int n = nbits[i];  // 0..32
+        if (br.k + n > 56) br.refill();
+        values[i] = br.peek(n);
+        br.k += n;
+        cursor -= n;
+        bits_still[i] = cursor;  // reversebitstream.go:13-15
+    }
+}
+
 }  // namespace mzd

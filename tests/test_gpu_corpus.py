@@ -489,7 +489,7 @@ def test_device_planner_edge_batches(ctx):
 # ---- streaming: batches pipelined through recycled device slots
 
 @pytest.mark.parametrize("depth,pinned", [(2, True), (3, False), (1, True)])
-def test_stream_of_batches_equals_one_shot_decode(corpus, ctx, depth, pinned):
+def test_stream_of_batches_equals_one_shot_decode(corpus, ctx, oracle, depth, pinned):
     """Seven batches of different sizes and content (corpus slices, synthetic frames, a batch with damaged
     frames, an empty batch) through a `depth`-slot stream: every frame's status and bytes equal the
     one-shot decode; slots are recycled (batch sizes go up and down)."""
@@ -500,6 +500,9 @@ def test_stream_of_batches_equals_one_shot_decode(corpus, ctx, depth, pinned):
     bad = [bytes(bytearray(f[:len(f) // 2])) for f in frames_all[10:14]] + [b"\x28\xb5\x2f\xfd"]
     batches = [frames_all[:30], syn[:25], frames_all[30:100] + syn[25:], [], bad + frames_all[5:9], syn[:3], frames_all[50:60]]
     want = [z.decode_frames(b, ctx) if b else ([], []) for b in batches]
+    # what the stream must deliver is pinned independently of the product: corpus frames by the golden manifest
+    # (length, sha256, verbatim bytes), synthetic frames by the oracle
+    golden = {comp: (name, length, sha, exp) for name, comp, length, sha, exp in corpus}
     st = z.Stream(ctx, depth=depth)
     bufs, inflight, results = [], [], {}
     for bi, b in enumerate(batches):
@@ -527,7 +530,16 @@ def test_stream_of_batches_equals_one_shot_decode(corpus, ctx, depth, pinned):
         for i in range(len(b)):
             if sts_w[i] == 0:
                 o, n = int(out_off[i]), int(out_len[i])
-                assert out[o:o + n].tobytes() == outs_w[i], (bi, i)
+                got = out[o:o + n].tobytes()
+                assert got == outs_w[i], (bi, i)
+                if b[i] in golden:
+                    name, length, sha, exp = golden[b[i]]
+                    check_expected(name, got, length, sha, exp)
+                else:
+                    rc, ref, _, _ = oracle.decode_frame(b[i], cap=n + 64)
+                    assert rc == 0 and got == ref, (bi, i)
+            else:
+                assert oracle.decode_frame(b[i], cap=4 << 20)[0] != 0, (bi, i)  # the oracle rejects it too
     st.close()
 
 
@@ -552,7 +564,7 @@ def test_stream_refuses_overcommit_and_small_output(corpus, ctx):
 
 
 @pytest.mark.parametrize("window_kib,device_plan", [(64, False), (64, True), (300, True), (1, False)])
-def test_input_blob_decoded_window_by_window(corpus, ctx, window_kib, device_plan):
+def test_input_blob_decoded_window_by_window(corpus, ctx, oracle, window_kib, device_plan):
     """k_seq_pipe addresses bitstreams with 32-bit offsets from a window of the blob; blobs of 4 GiB and more
     are decoded window by window.  With the window shrunk to a few KiB the corpus + synthetic batch takes many
     launches, and frames wider than a window take the two-wavefront kernel: same bytes either way."""
@@ -564,4 +576,9 @@ def test_input_blob_decoded_window_by_window(corpus, ctx, window_kib, device_pla
     outs, sts = z.decode_frames(frames, c, device_plan=device_plan)
     assert sts == sts_w == [0] * len(frames)
     assert outs == want
+    for (name, comp, length, sha, exp), got in zip(corpus, outs):  # the golden manifest, not only the product itself
+        check_expected(name, got, length, sha, exp)
+    for f, got in zip(frames[len(corpus):], outs[len(corpus):]):
+        rc, ref, _, _ = oracle.decode_frame(f, cap=len(got) + 64)
+        assert rc == 0 and got == ref
     c.close()

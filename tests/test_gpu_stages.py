@@ -1,0 +1,264 @@
+"""-m gpu: the STAGE boundaries of the hot path against the oracle, the device bit
+reader against the reference's own bit-reader vectors, the BASELINE configs at their stated sizes, and the
+self-launching multi-rank bench.  Everything goes through the C-ABI."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import sparkzstd_amd as z
+from sparkzstd_amd import _lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return z.Context(0)
+
+
+# ---- B0: the device's backward bit reader, driven like bitstream/reversebitstream_test.go
+
+def test_device_bit_reader_edge_vector(ctx, kat):
+    """bitstream/reversebitstream_test.go:172-229: {64,58,169,224}, reads that end on / cross byte borders, a
+    zero-bit read, and the last read running past the start of the stream."""
+    k = kat["rbs_edges"]
+    vals, left = ctx.backbits(bytes(k["data"]), k["reads"])
+    assert vals == k["expect"]
+    want_left, cur = [], 8 * len(k["data"]) - 1
+    for n in k["reads"]:
+        cur -= n
+        want_left.append(cur)
+    assert left == want_left
+
+
+def test_device_bit_reader_ramp_patterns(ctx, oracle):
+    """bitstream/reversebitstream_test.go:7-170: the 256-byte ramp read in the test's bit patterns; every value
+    equals the oracle's reader (itself pinned on the same vectors in tests/test_oracle.py) and the bit string."""
+    from tests.oracle_binding import Rbs
+    data = bytes(range(256))
+    bits = []
+    for b in reversed(data):
+        bits += [(b >> i) & 1 for i in range(7, -1, -1)]
+    for pattern in ([8], [4], [5] * 8 + [8], [3] * 8 + [8], [6, 3, 3, 3, 3, 6, 8], [7, 7, 7, 3, 8], [32, 1, 31, 0, 17], [11]):
+        reads, pos = [], 0
+        while pos + pattern[len(reads) % len(pattern)] <= len(bits):
+            reads.append(pattern[len(reads) % len(pattern)])
+            pos += reads[-1]
+        vals, left = ctx.backbits(data, reads)
+        r = Rbs()
+        oracle.lib.orc_rbs_init(ctypes.byref(r), data, len(data))
+        pos = 0
+        for n, v in zip(reads, vals):
+            want = 0
+            for b in bits[pos:pos + n]:
+                want = (want << 1) | b
+            assert v == want == oracle.lib.orc_rbs_read(ctypes.byref(r), n), (pattern, pos, n)
+            pos += n
+        assert left[-1] == 8 * len(data) - 1 - pos
+
+
+def test_device_bit_reader_reads_zeros_below_the_start(ctx, oracle):
+    """reversebitstream.go:23-27,67-75: past the start of the stream Read returns zero bits and the cursor keeps
+    decrementing.  The hook surrounds the stream with non-zero bytes, so the masking is the reader's own."""
+    from tests.oracle_binding import Rbs
+    rng = np.random.default_rng(5)
+    for ln in (1, 2, 7, 8, 9, 15, 16, 17, 40):
+        data = bytes(rng.integers(1, 256, ln, dtype=np.uint8))
+        reads = [int(x) for x in rng.integers(0, 33, 6 + ln)] + [32, 32, 7, 0, 1]
+        vals, left = ctx.backbits(data, reads)
+        r = Rbs()
+        oracle.lib.orc_rbs_init(ctypes.byref(r), data, len(data))
+        for i, n in enumerate(reads):
+            assert vals[i] == oracle.lib.orc_rbs_read(ctypes.byref(r), n), (ln, i, n)
+            assert left[i] == r.offset, (ln, i)
+        assert left[-1] < -1  # the sequence really over-read
+
+
+# ---- stage boundaries: regenerated literals and (LL, ML, resolved offset) per block, against the oracle's trace
+
+def _next_offset(hist, value, ll):
+    """sequence_execution.go:65-114 (the test's own restatement, used only to turn a symbolic record into a number)"""
+    if value > 3:
+        off = value - 3
+        hist[:] = [off, hist[0], hist[1]]
+        return off
+    idx = value - 1 + (1 if ll == 0 else 0)
+    if idx == 0:
+        return hist[0]
+    off = hist[idx] if idx < 3 else hist[0] - 1
+    if idx == 1:
+        hist[:] = [off, hist[0], hist[2]]
+    else:
+        hist[:] = [off, hist[0], hist[1]]
+    return off
+
+
+@pytest.mark.parametrize("seq_variant", [0, 1])
+def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle, seq_variant):
+    """After one pass over the whole corpus: for every compressed block, the literal bytes the Huffman stage
+    regenerated (literals.go:283-361 LiteralSection.Data) and every sequence's (LiteralLength, MatchLength,
+    resolved offset) (sequences.go:11-15 + sequence_execution.go:65-114) as the device holds them between its
+    stages equal the oracle's trace, block by block -- not only the final bytes."""
+    c = z.Context(0, seq_variant=seq_variant)
+    frames = [comp for _, comp, *_ in corpus]
+    plan = z.Plan(device_tables=True)
+    for f in frames:
+        assert plan.add_frame(f)[0] == 0
+    b = plan.finalize()
+    rb = c.upload(b)
+    try:
+        rb.run()
+        _, status, _ = rb.download(want_out=False)
+        assert (status == 0).all()
+        st = rb.stats()
+        dblocks = rb.debug_blocks(b.n_blocks)
+        n_rec = int(st.n_sequences)
+        recs = rb.debug_read(_lib.MZD_DEBUG_RECORDS, np.uint64, 0, n_rec)
+        lit_bytes = max((int(d.lit_src) + int(d.lit_regen) for d in dblocks if d.type == 2 and d.lit_type == 2), default=0)
+        lits = rb.debug_read(_lib.MZD_DEBUG_LITERALS, np.uint8, 0, lit_bytes)
+        tiles = rb.debug_read(_lib.MZD_DEBUG_TILES, np.uint32, 0, 2 * sum((int(d.n_seq) + 63) // 64 for d in dblocks))
+        blob = bytes(np.ctypeslib.as_array(ctypes.cast(b.in_, ctypes.POINTER(ctypes.c_uint8)), shape=(b.in_size,)))
+        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = 0
+        for fi, f in enumerate(frames):
+            rc, _, _, tr = oracle.decode_frame(f, cap=corpus[fi][2] + 64, want_trace=True)
+            assert rc == 0
+            fd = b.frames[fi]
+            assert fd.n_blocks == len(tr["blocks"])
+            lit_at = seq_at = 0
+            hist = [1, 4, 8]  # framedecompressor.go:48,59
+            for k, ob in enumerate(tr["blocks"]):
+                d = dblocks[fd.first_block + k]
+                assert d.type == ob["block_type"], (fi, k)
+                if ob["block_type"] != 2:
+                    continue
+                n_blocks_seen += 1
+                # literals
+                regen = ob["lit_regen"]
+                want_l = tr["literals"][lit_at:lit_at + regen]
+                lit_at += regen
+                assert d.lit_regen == regen
+                if d.lit_type == 2:
+                    got_l = lits[int(d.lit_src):int(d.lit_src) + regen].tobytes()
+                elif d.lit_type == 0:
+                    got_l = blob[int(d.lit_src):int(d.lit_src) + regen]
+                else:
+                    got_l = blob[int(d.lit_src):int(d.lit_src) + 1] * regen
+                assert got_l == want_l, (corpus[fi][0], k, "literals")
+                n_lit_seen += regen
+                # sequences
+                ns = ob["n_seq"]
+                assert d.n_seq == ns
+                h0 = list(hist)  # history at the start of the block: what a symbolic record refers to
+                lit_pos = out_pos = 0
+                for j in range(ns):
+                    ll, ml, raw, resolved = tr["seqs"][seq_at + j]
+                    r = int(recs[int(d.rec_off) + j])
+                    g_ll, g_ml, g_of = r & 0x1FFFF, (r >> 17) & 0x3FFFF, (r >> 35) & 0x1FFFFFFF
+                    if g_of & (1 << 28):
+                        u = g_of & 0x0FFFFFFF
+                        g_of = h0[u & 3] - (u >> 2)
+                        n_symbolic += 1
+                    assert (g_ll, g_ml, g_of) == (ll, ml, resolved), (corpus[fi][0], k, j)
+                    assert _next_offset(hist, raw, ll) == resolved  # the test's history agrees with the oracle's
+                    if j % 64 == 0:
+                        t = int(d.tile_off) + j // 64
+                        assert (int(tiles[2 * t]), int(tiles[2 * t + 1])) == (lit_pos, out_pos), (corpus[fi][0], k, j)
+                    lit_pos += ll
+                    out_pos += ll + ml
+                seq_at += ns
+                n_seq_seen += ns
+            assert lit_at == len(tr["literals"]) and seq_at == len(tr["seqs"])
+        assert n_blocks_seen > 1500 and n_seq_seen == n_rec > 1000000 and n_lit_seen > 2000000
+        assert n_symbolic > 0 or seq_variant == 1  # later blocks of a frame carry repeat offsets relative to the block start
+    finally:
+        rb.free()
+        plan.close()
+        c.close()
+
+
+# ---- BASELINE.json configs at their stated sizes: size-independent properties on every frame
+
+def _run_full_config(config, n_frames, ctx):
+    import torch
+    from tools import synth_binding as sb
+    frame_bytes = 131072
+    blob, off, ln, cks, nseq = sb.make_batch(config, 0, n_frames, frame_bytes, threads=0)
+    plan = z.Plan(device_tables=True)
+    assert plan.add_frames(blob, off, ln, threads=0) == 0
+    batch = plan.finalize()
+    assert batch.n_frames == n_frames
+    rb = ctx.upload(batch)
+    try:
+        rb.run()
+        rb.run()  # a resident batch is re-runnable: the second pass must leave the same bytes
+        _, status, out_len = rb.download(want_out=False)
+        assert (status == 0).all(), np.unique(status, return_counts=True)
+        assert (out_len == frame_bytes).all()
+        # position-weighted checksum of every frame, computed on the device from the regenerated bytes and
+        # compared with the one the generator took from the ORIGINAL content (tools/synth)
+        n = n_frames * frame_bytes
+        dptr = rb.device_out_ptr()
+        out = torch.empty(n, dtype=torch.uint8, device="cuda")
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(out.data_ptr(), dptr, n, 3) == 0  # device to device; frames are laid out back to back
+        words = frame_bytes // 8
+        wts = 2 * torch.arange(words, dtype=torch.int64, device="cuda") + 1
+        exp = torch.from_numpy(cks.view(np.int64)).cuda()
+        o64 = out.view(torch.int64).view(n_frames, words)
+        for c0 in range(0, n_frames, 4096):
+            got = (o64[c0:c0 + 4096] * wts).sum(dim=1)
+            assert bool((got == exp[c0:c0 + 4096]).all()), (config, c0)
+        return rb.stats()
+    finally:
+        rb.free()
+        plan.close()
+
+
+def test_config2_raw_rle_4096_frames_full_size(ctx):
+    """BASELINE configs[1]: 4096 single-block Raw / RLE frames of 128 KiB (framedecompressor.go:211-215,229-241)."""
+    st = _run_full_config(2, 4096, ctx)
+    assert list(st.n_blocks) == [2048, 2048, 0]
+
+
+def test_config3_huffman_only_4096_frames_full_size(ctx):
+    """BASELINE configs[2]: 4096 frames, 4-stream Huffman literals (MaxBits 11), no sequences."""
+    st = _run_full_config(3, 4096, ctx)
+    assert st.n_huf_streams == 4 * 4096 and st.n_sequences == 0
+
+
+def test_config4_full_frames_65536_full_size(ctx):
+    """BASELINE configs[3]: 65536 text-like single-block frames, Huffman literals + FSE sequences + match copy."""
+    st = _run_full_config(4, 65536, ctx)
+    assert st.n_huf_streams == 4 * 65536 and st.n_sequences > 65536 * 10000
+
+
+# ---- BASELINE configs[4]: the sharded bench, launched by bench.py itself
+
+@pytest.mark.parametrize("extra", [[], ["--strong"]])
+def test_bench_launches_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns two ranks before touching the GPU;
+    each decodes its own contiguous frame range (framedecompressor.go:42-52: frames share nothing), rank 0 prints
+    one line that names both ranks.  On a one-GPU box both ranks share device 0 and rendezvous over gloo."""
+    import torch
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env.update(MZD_BENCH_BACKEND="gloo", MZD_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames-per-gpu", "2048", "--cpu-seconds", "0", "--no-ceiling"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["bit_exact"] is True
+    assert sorted(p["rank"] for p in line["per_gpu"]) == [0, 1]
+    per = 1024 if extra else 2048
+    assert all(p["frames"] == per for p in line["per_gpu"]) and line["scaling"] == ("strong" if extra else "weak")
+    assert line["value"] > 0 and all(p["algorithmic_GBs"] > 0 for p in line["per_gpu"])

@@ -1,14 +1,24 @@
 #!/bin/bash
-# GPU box: tests, default bench, rocprofv3 kernel stats and HBM-traffic counters of the same command.
-# Outputs go to gpurun_out/ (scratch); copy what is to be kept into profiles/.
+# GPU box: rocprofv3 evidence for ONE bench configuration, all in the same gpurun:
+#   1. kernel trace + stats of `bench.py --config N`            -> gpurun_out/<tag>_cfg<N>_kernel_stats.csv
+#   2. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes    -> gpurun_out/<tag>_traffic_cfg<N>.json
+#      (stamped with the hash of the device sources and the workload, tools/summarize_profile.py)
+#   3. the bench line itself, quoting that traffic file          -> gpurun_out/<tag>_cfg<N>_bench.json
+# Copy what is to be kept into profiles/ (gpurun_out/ is scratch).
+# usage: tools/profile_round.sh <tag> <config> [extra bench flags]
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r1_v5}
-cd $R && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-cd $R && timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -1 gpurun_out/${TAG}_bench.json
+TAG=${1:-r2}
+CFG=${2:-4}
+shift 2
+EXTRA="$@"
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0"
-rm -rf $R/gpurun_out/${TAG}_stats $R/gpurun_out/${TAG}_fetch $R/gpurun_out/${TAG}_write
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats --output-format csv -- $B > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch --output-format csv -- $B > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write --output-format csv -- $B > /dev/null 2>&1
-ls $R/gpurun_out/${TAG}_stats/*/ | head
+B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --cpu-seconds 0 --no-ceiling $EXTRA"
+for k in stats fetch write; do rm -rf $R/gpurun_out/${TAG}_cfg${CFG}_$k; done
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_cfg${CFG}_stats --output-format csv -- $B > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_cfg${CFG}_fetch --output-format csv -- $B > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_cfg${CFG}_write --output-format csv -- $B > /dev/null 2>&1
+cd $R && python3 tools/summarize_profile.py $TAG $CFG 7 "$B"
+cd $R && timeout 900 python3 bench.py --config $CFG $EXTRA --traffic-from gpurun_out/${TAG}_traffic_cfg${CFG}.json \
+    > gpurun_out/${TAG}_cfg${CFG}_bench.json 2> gpurun_out/${TAG}_cfg${CFG}_bench.err
+tail -1 gpurun_out/${TAG}_cfg${CFG}_bench.json

@@ -1,42 +1,67 @@
 #!/usr/bin/env python3
-"""Turn the scratch outputs of tools/profile_round.sh (gpurun_out/<tag>_stats|fetch|write, <tag>_bench.json)
-into the committed summaries under profiles/: <tag>_kernel_stats.csv, <tag>_bench.json, r1_traffic.json."""
-import collections, csv, glob, json, os, sys
+"""Runs ON THE GPU BOX right after the rocprofv3 passes of tools/profile_round.sh: turns
+gpurun_out/<tag>_cfg<N>_{stats,fetch,write} into
+  gpurun_out/<tag>_cfg<N>_kernel_stats.csv   the rocprofv3 --stats summary (per-kernel calls / average ns)
+  gpurun_out/<tag>_traffic_cfg<N>.json       FETCH_SIZE / WRITE_SIZE per kernel and per bench step, stamped with
+                                             the hash of the device sources and the workload they were measured on
+                                             (bench.py quotes the file only when both match its own run).
+usage: summarize_profile.py <tag> <config> <launched steps incl. warmup> "<profiled command>" """
+import collections, csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1_v5"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7  # bench steps + warmup of the profiled command
-go, po = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+sys.path.insert(0, ROOT)
+from bench import kernel_src_sha16  # noqa: E402
 
-st = glob.glob(os.path.join(go, tag + "_stats", "*", "*_kernel_stats.csv"))[0]
-rows = list(csv.reader(open(st)))
-with open(os.path.join(po, tag + "_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0"
-            "   (default workload: 65536 frames, config 4; k_seq_pipe and k_exec are launched twice per step)\n")
-    f.write(f"# bench line of the same build: profiles/{tag}_bench.json\n")
-    w = csv.writer(f)
-    for r in rows:
-        w.writerow([c[:100] for c in r])
+tag, cfg, steps, cmd = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+go = os.path.join(ROOT, "gpurun_out")
+base = f"{tag}_cfg{cfg}"
+
+st = glob.glob(os.path.join(go, base + "_stats", "*", "*_kernel_stats.csv"))
+if st:
+    rows = list(csv.reader(open(st[0])))
+    with open(os.path.join(go, base + "_kernel_stats.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}\n")
+        f.write(f"# {steps} passes of the hot path per run (warm-up included); device sources {kernel_src_sha16()}\n")
+        w = csv.writer(f)
+        for r in rows:
+            w.writerow([c[:110] for c in r])
+
 
 def per_kernel(kind):
-    f = glob.glob(os.path.join(go, f"{tag}_{kind}", "*", "*_counter_collection.csv"))[0]
-    agg = collections.Counter()
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        name = next((n for n in ("k_init", "k_huf", "k_seq", "k_exec") if "mzd::" + n in k), None)
-        if name:
-            agg[name] += float(r["Counter_Value"])
-    return agg
+    fs = glob.glob(os.path.join(go, f"{base}_{kind}", "*", "*_counter_collection.csv"))
+    agg, calls = collections.Counter(), collections.Counter()
+    if not fs:
+        return None, None
+    for r in csv.DictReader(open(fs[0])):
+        m = re.search(r"mzd::(k_\w+)", r["Kernel_Name"])
+        if m:
+            agg[m.group(1)] += float(r["Counter_Value"])
+            calls[m.group(1)] += 1
+    return agg, calls
 
-fetch, write = per_kernel("fetch"), per_kernel("write")
-old = json.load(open(os.path.join(po, "r1_traffic.json")))
-kern = {}
-for k in ("k_init", "k_seq", "k_huf", "k_exec"):
-    fb = int(fetch[k] / steps * 1024)
-    kern[k] = {"fetch_bytes": fb, "fetch_bytes_x2": 2 * fb, "write_bytes": int(write[k] / steps * 1024)}
-old["kernels"] = kern
-old["command"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0"
-old["build"] = tag
-json.dump(old, open(os.path.join(po, "r1_traffic.json"), "w"), indent=1)
-line = open(os.path.join(go, tag + "_bench.json")).read().strip().splitlines()[-1]
-open(os.path.join(po, tag + "_bench.json"), "w").write(line + "\n")
-print(json.dumps(kern, indent=1))
+
+fetch, calls = per_kernel("fetch")
+write, _ = per_kernel("write")
+if fetch is not None and write is not None:
+    frames = {2: 4096, 3: 4096, 4: 65536}.get(cfg)
+    m = re.search(r"--frames-per-gpu (\d+)", cmd)
+    if m:
+        frames = int(m.group(1))
+    kern = {}
+    for k in sorted(set(fetch) | set(write)):
+        if k in ("k_fse_build", "k_huf_build", "k_parse", "k_copy_ceiling"):
+            continue  # once per upload / measurement utility: not part of a pass
+        fb = int(fetch[k] / steps * 1024)
+        kern[k] = {"fetch_bytes": fb, "fetch_bytes_x2": 2 * fb, "write_bytes": int(write[k] / steps * 1024),
+                   "launches_per_pass": round(calls[k] / steps, 2)}
+    out = {
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (kernel-trace only); totals per pass of the hot "
+                "path (a kernel launched twice per pass -- head + tail of a split batch -- is summed). Counter unit is KB (TCC_EA0 "
+                "requests x 64 B / 1024). Per /opt/skills/guides/MI355X_MICROARCH.md the gfx950 FETCH_SIZE under-counts wide coalesced "
+                "streaming reads by 2x and is uncalibrated for other access widths; Infinity-Cache hits are included. bytes = KB * "
+                "1024; fetch_bytes_x2 applies the guide's streaming correction as an upper bound.",
+        "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- {cmd}",
+        "round": 2, "build": tag, "kernel_src_sha16": kernel_src_sha16(), "config": cfg, "frames_per_gpu": frames,
+        "frame_bytes": 131072, "kernels": kern,
+    }
+    json.dump(out, open(os.path.join(go, f"{tag}_traffic_cfg{cfg}.json"), "w"), indent=1)
+    print(json.dumps(kern))
