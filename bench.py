@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--exec-chunk", type=int, default=0)
     ap.add_argument("--huf-min-lds", type=int, default=0)
+    ap.add_argument("--huf-variant", type=int, default=0, help="0 auto, 1 k_huf (lane per stream), 2 k_huf_seg (wavefront per stream)")
     ap.add_argument("--no-split", action="store_true", help="do not overlap k_seq(tail) with k_exec(head)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-threads", type=int, default=0)
@@ -301,7 +302,7 @@ def main():
     d_in[pad:pad + blob.size].copy_(torch.from_numpy(blob))
     d_out = torch.zeros(batch.out_size, dtype=torch.uint8, device="cuda")
     ctx = z.Context(local_rank, seq_variant=a.seq_variant, exec_threads=a.exec_threads, exec_chunk=a.exec_chunk, huf_min_lds=a.huf_min_lds, no_split=a.no_split,
-                    verify_checksum=a.verify_checksum)
+                    verify_checksum=a.verify_checksum, huf_variant=a.huf_variant)
     rb = ctx.upload(batch, device_in_ptr=d_in.data_ptr() + pad, device_out_ptr=d_out.data_ptr())
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t0

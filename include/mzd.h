@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 2
+#define MZD_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -213,6 +213,9 @@ typedef struct mzd_options {
     uint32_t seq_window_kib;  /* testing: k_seq_pipe launches cover at most this many KiB of the input blob (default:
                                  just under 4 GiB -- the kernel addresses bitstreams with 32-bit offsets from the
                                  window; larger blobs are decoded window by window) */
+    uint32_t huf_variant;     /* Huffman literal kernel: 0 = by the batch (k_huf_seg when streams are long and few, else
+                                 k_huf); 1 = k_huf (one lane per stream); 2 = k_huf_seg (one wavefront per stream, segments
+                                 decoded in parallel: Huffman codes self-synchronise) */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

@@ -1076,7 +1076,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 8192;
     exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
     const size_t seq_lds = (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16;
-    const size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
+    size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
+    if (const char *e = getenv("MZD_EXEC_MIN_LDS")) exec_lds = std::max<size_t>(exec_lds, (size_t)atoi(e));  // experiment: residency cap
     // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
     // overflow L2 and every refill goes to MALL/HBM; a minimum LDS request per workgroup limits the
     // number of resident wavefronts (opt.huf_min_lds bytes, default 48 KiB -> 3 wavefronts per CU)
@@ -1089,6 +1090,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_seg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_set = true;
     }
     // ---- split point: k_seq runs ceil(tasks / (chains per CU * CUs)) rounds of one chain latency each and
@@ -1097,12 +1099,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default): k_seq_pipe; 1: k_seq, the two-wavefront kernel.  k_seq_pipe addresses the
     // bitstreams with 32-bit offsets from the blob's front slack, so larger blobs take k_seq as well.
-    if (ctx->opt.seq_variant > 1) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 1 || ctx->opt.huf_variant > 2) return MZD_ERR_INVALID_ARG;
     const bool pipe = ctx->opt.seq_variant == 0;
     // k_seq_pipe: two chains fewer than fit, so that ~6 KiB of every CU's LDS stay free and the small
     // k_huf workgroups run in k_seq's shadow instead of queueing for whole CUs (measured with 54 chains of 56:
     // 28.6 ms per step; 55: 29.5; 56: 32.2; 53: 29.2; 51: 30.9)
-    const uint32_t nch = pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16;
+    uint32_t nch = pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16;
+    if (const char *e = getenv("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames;
     if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
@@ -1216,6 +1219,24 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     //   s  : k_init -> k_seq(head) -> k_seq(tail) -> [wait huf] k_exec(tail) -> [wait head done]
     //   s2 : [wait init] k_huf -> [wait k_seq(head)] k_exec(head)
     hipStream_t s2 = ctx->stream2;
+    if (db->n_huf_tasks == 0 && db->n_seq_tasks == 0 && db->stats.n_blocks[2] == 0) {
+        // Nothing but Raw / RLE blocks (BASELINE configs[1]): the pass IS the copy kernel -- no summaries to reset,
+        // no second stream, no cross-stream events in front of it (they cost more than the 0.2 ms copy itself).
+        if (ev) {
+            for (int i : {0, 1, 3, 9, 2, 4}) HIP_TRY(ctx, hipEventRecord(ev[i], s));
+            ctx->run_split[ctx->runs] = false;
+        }
+        launch_exec(s, 0, db->n_frames);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
+        launch_verify(s, 0, db->n_frames);
+        if (ev) {
+            HIP_TRY(ctx, hipEventRecord(ev[11], s));
+            HIP_TRY(ctx, hipEventRecord(ev[8], s));
+            ctx->runs++;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return MZD_OK;
+    }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
@@ -1226,9 +1247,23 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
     HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
-    if (db->n_huf_tasks)
-        k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
-                                                              db->d_litbuf, db->d_sums, db->huf_slot_cells);
+    if (db->n_huf_tasks) {
+        // Which Huffman kernel: a lane per stream (k_huf) needs >= 64 streams per wavefront and many wavefronts per CU
+        // to hide its ~190-cycle step; when the batch has few, long streams, a wavefront per stream decoding its
+        // segments in parallel (k_huf_seg) is the one that fills the chip.
+        const uint32_t hv = ctx->opt.huf_variant;
+        const uint64_t streams = std::max<uint64_t>(db->stats.n_huf_streams, 1);
+        const bool seg = hv == 2 || (hv == 0 && streams < 64ull * 8 * (uint64_t)std::max(ctx->num_cus, 1) &&
+                                     db->lit_bytes / streams >= 2048);
+        size_t seg_lds = (size_t)db->huf_slot_cells * 2;
+        if (const char *e = getenv("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
+        if (seg)
+            k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks,
+                                                                                      db->d_huf_entries, db->d_litbuf, db->d_sums);
+        else
+            k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
+                                                                  db->d_litbuf, db->d_sums, db->huf_slot_cells);
+    }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
     if (split) {
@@ -1264,6 +1299,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     return MZD_OK;
 }
 
+#ifdef MZD_HUF_SEG_STATS
+extern "C" int mzd_debug_huf_seg_stats(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_huf_seg_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_huf_seg_stats), z, sizeof z); }
+    return 0;
+}
+#endif
 #ifdef MZD_EXEC_STATS
 extern "C" int mzd_debug_exec_stats(unsigned long long *out, int reset)
 {

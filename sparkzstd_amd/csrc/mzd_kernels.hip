@@ -39,6 +39,7 @@ namespace mzd {
 struct __attribute__((packed, aligned(1))) U64U { uint64_t v; };
 struct __attribute__((packed, aligned(1))) U32U { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U128U { uint32_t x, y, z, w; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { return ((const U64U *)p)->v; }
 
@@ -441,6 +442,289 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     // (literals.go:299-361), and the literals before the sequences: lowest stream index wins, and
     // k_exec lets a literals error win over the sequence stage's status
     if (status != MZD_OK) atomicMin(&sums[t.block].huf_err, ((tid & 3u) << 8) | (uint32_t)status);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_huf_seg: Huffman literal streams with INTRA-STREAM parallelism (huffman.go:221-264, same results
+// and same end conditions as k_huf).  A stream is one serial chain of table lookups, so a batch of few
+// long streams (BASELINE configs[2]: 16 384 streams of 32 768 symbols) leaves a lane-per-stream kernel
+// with one wavefront per CU and ~190 cycles per symbol.  But Huffman codes SELF-SYNCHRONISE: a decoder
+// started at a wrong bit position falls into step with the true sequence of code boundaries after a
+// few symbols.  So: one WAVEFRONT per stream, the stream's R data bits cut into up to 64 segments of B
+// bits, one lane each;
+//   count pass   lane j starts kSegApproach bits BEFORE its segment (lane 0: at the exact start),
+//                notes the first code boundary t_j at or after the segment's start, counts the symbols
+//                that start in [t_j, end of segment) and notes where it leaves, e_j;
+//   validation   the chain must close: e_j == t_{j+1} for every j.  Lane 0 is exact, so by induction
+//                every lane then counted exactly its share of the true symbol sequence.  A lane whose
+//                start disagrees takes its neighbour's exit and recounts; repeated until the chain
+//                closes (each round fixes at least the first wrong lane: a code that never
+//                synchronises degrades to the serial time, never to a wrong result);
+//   write pass   an exclusive scan of the counts gives every lane its output offset; it decodes its
+//                c_j symbols again from t_j and stores them (16 or 20 per store group).
+// The status is the one the serial loop gives (huffman.go:248-261, literals.go:320,332,349,366):
+// all R bits decode to N symbols and leave rem = R - e_last <= 0 bits; N < want: rem < 0 ? "bits" :
+// "length"; N == want: rem < 0 ? "bits" : ok; N > want: the serial loop stops at want with bits left:
+// "length".  One workgroup = the (up to) four streams of a literals section = four wavefronts sharing the
+// section's decode table in LDS (<= 4 KiB): the kernel needs no other LDS, so a CU holds 8 workgroups.
+
+#ifdef MZD_HUF_SEG_STATS
+__device__ unsigned long long g_huf_seg_stats[8];  // streams, validation rounds, lanes recounted, active lanes, symbols
+#endif
+#ifndef MZD_SEG_APPROACH
+#define MZD_SEG_APPROACH 256
+#endif
+#ifndef MZD_SEG_BITS
+#define MZD_SEG_BITS 512
+#endif
+constexpr int kSegApproach = MZD_SEG_APPROACH;  // bits a lane decodes ahead of its segment to fall into step
+constexpr int kSegBits = MZD_SEG_BITS;          // a lane's segment; a round of 64 lanes covers 64 times as much
+
+// Bit window of one lane of k_huf_seg.  The bulk loops refill it from a 16-byte register buffer Q = the bytes
+// [ptr - 16, ptr) of the stream, loaded with ONE unaligned 16-byte load per PAIR of refills, a whole group of G
+// symbols before its first use: the memory latency is off the decode chain.  Bytes below the start of the stream
+// must read as zero (reversebitstream.go:23-27); they are masked when Q is USED, not when it is loaded (masking at
+// the load made every refill wait for its own load), and only if some lane of the wavefront is that close to the
+// start of its stream.
+template <int G>  // symbols between two refills: 7 + G * MaxBits <= 64
+struct SegDec {
+    const uint8_t *s;
+    const uint16_t *tbl;
+    uint64_t C, Qhi, Qlo;
+    u32x4 Q;  // destination of the 16-byte request in flight
+    int ptr, k, qat, mb;
+    uint32_t s8;
+
+    __device__ __forceinline__ static uint64_t mask_below(uint64_t v, int at)  // bytes [at, at + 8), zero below the stream
+    {
+        if (at < 0) {
+            const int z = -at;
+            v = z >= 8 ? 0ull : ((v >> (8 * z)) << (8 * z));
+        }
+        return v;
+    }
+    __device__ __forceinline__ uint64_t load_below(int at) const { return mask_below(ld64u(s + max(at, -8)), at); }
+    __device__ __forceinline__ void seek(const uint8_t *start, int len, int a)  // a = bits from the top of the last byte
+    {
+        s = start;
+        ptr = len - 8 - (a >> 3);
+        k = a & 7;
+        C = load_below(ptr);
+    }
+    __device__ __forceinline__ uint32_t sym()  // one lookup; returns the cell {symbol, nbits << 8}, advances the window
+    {
+        const uint32_t idx = (uint32_t)((C << k) >> (64 - mb));
+        const uint32_t e = tbl[idx];
+        k += (int)(e >> 8);
+        return e;
+    }
+    __device__ __forceinline__ uint32_t one()  // symbol by symbol (segment borders, tails): refills with a load of its own
+    {
+        if (k + mb > 57) {
+            const int nb = k >> 3, sh = nb * 8;
+            const uint64_t D = load_below(ptr - 8);
+            C = (C << sh) | ((D >> 1) >> (63 - sh));
+            ptr -= nb;
+            k &= 7;
+        }
+        return sym();
+    }
+    // Request the 16 bytes below the window.  The load is an asm statement so that it STAYS where it is written, a
+    // whole group of symbols ahead of its first use: hipcc merged the C++ load at the end of the loop body with the
+    // one in front of the loop into ONE load at the loop header, right in front of its use, and every pair of
+    // refills waited out a full memory latency.  hipcc does not count an asm load: q_wait() is its s_waitcnt.
+    __device__ __forceinline__ void load_q()
+    {
+        qat = ptr - 16;
+        const uint8_t *p = s + max(qat, -16);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q) : "v"(p) : "memory");
+    }
+    __device__ __forceinline__ void q_wait() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(Q) : : "memory"); }
+    __device__ __forceinline__ void refill_first()  // takes the top bytes of a fresh Q
+    {
+        q_wait();
+        Qlo = (uint64_t)Q.x | ((uint64_t)Q.y << 32);
+        Qhi = (uint64_t)Q.z | ((uint64_t)Q.w << 32);
+        if (__any(qat < 0)) {  // rare: a lane within 16 bytes of the start of its stream
+            Qlo = mask_below(Qlo, qat);
+            Qhi = mask_below(Qhi, qat + 8);
+        }
+        const int nb = k >> 3, sh = nb * 8;
+        C = (C << sh) | ((Qhi >> 1) >> (63 - sh));
+        ptr -= nb;
+        k &= 7;
+        s8 = (uint32_t)sh;
+    }
+    __device__ __forceinline__ void refill_second()  // takes the bytes s8 / 8 below the top of Q, then requests the next Q
+    {
+        const int nb = k >> 3, sh = nb * 8;
+        const uint64_t M = (Qhi << s8) | ((Qlo >> 1) >> (63 - s8));
+        C = (C << sh) | ((M >> 1) >> (63 - sh));
+        ptr -= nb;
+        k &= 7;
+        load_q();
+    }
+    // symbols that START in [pos, hi): returns how many, pos ends at the first boundary >= hi
+    __device__ __forceinline__ uint32_t count_until(int &pos, int hi)
+    {
+        uint32_t n = 0;
+        if (pos + 2 * G * mb <= hi) {  // all 2 G symbols of a pair of groups start below hi
+            load_q();
+            do {
+                refill_first();
+                int k0 = k;
+#pragma unroll
+                for (int g = 0; g < G; g++) sym();
+                pos += k - k0;
+                refill_second();
+                k0 = k;
+#pragma unroll
+                for (int g = 0; g < G; g++) sym();
+                pos += k - k0;
+                n += 2 * G;
+            } while (pos + 2 * G * mb <= hi);
+            q_wait();  // the last request is never used, but it must have landed before its registers are anybody else's
+        }
+        while (pos < hi) {
+            pos += (int)(one() >> 8);
+            n++;
+        }
+        return n;
+    }
+};
+
+template <int G>
+__device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, const HufTask &t, const uint16_t *tbl,
+                                               uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t stream_idx, int lane)
+{
+    const uint8_t *s = in + t.in_off;
+    const int len = (int)t.in_size, mb = (int)t.max_bits;
+    const uint32_t want = t.out_size;
+    // padding: zero bits above the marker and the marker itself (huffman.go:227-238)
+    const uint32_t last = len > 0 ? s[len - 1] : 0u;
+    int status = last == 0 ? MZD_ERR_BAD_PADDING : MZD_OK;
+    const int a0 = last ? (int)__builtin_clz(last) - 24 + 1 : 8;
+    const int R = 8 * len - a0;  // data bits
+    SegDec<G> d;
+    d.tbl = tbl;
+    d.mb = mb;
+    d.qat = 0;
+    // ROUNDS of 64 segments of kSegBits: a round reads one contiguous 4 KiB piece of the stream and writes one
+    // contiguous piece of the literals, so what the wavefront's lanes touch at any time is a few dozen cache lines
+    // (one segment per lane over the WHOLE stream made every lane stream its own lines: with thousands of
+    // wavefronts in flight nothing stayed cached and every 16-byte access cost a sector of DRAM traffic).
+    int p0 = 0;             // exact code boundary where the round starts
+    uint32_t out_done = 0;  // symbols written by earlier rounds
+    while (status == MZD_OK && p0 < R) {
+        const int lo = p0 + lane * kSegBits;
+        const bool act = lo < R;
+        const int hi = min(R, lo + kSegBits);
+        int tpos = 0, epos = 0;
+        uint32_t cnt = 0;
+        if (act) {
+            // ---- count pass: approach, first boundary at or after lo, symbols up to hi
+            int pos = max(lo - kSegApproach, p0);
+            d.seek(s, len, a0 + pos);
+            while (pos < lo) pos += (int)(d.one() >> 8);
+            tpos = pos;
+            cnt = d.count_until(pos, hi);
+            epos = pos;
+        }
+        // ---- validation: the chain of boundaries must close (lanes run in lockstep here)
+        for (int guard = 0; guard < 66; guard++) {
+            const int tnext = __shfl_down(tpos, 1, 64);
+            const bool nact = (bool)__shfl_down((int)act, 1, 64) && lane < 63;
+            const bool bad = act && nact && epos != tnext;
+            if (!__any(bad)) break;
+#ifdef MZD_HUF_SEG_STATS
+            { const unsigned long long bm = __ballot(bad); if (lane == 0) { atomicAdd(&g_huf_seg_stats[1], 1ull); atomicAdd(&g_huf_seg_stats[2], (unsigned long long)__popcll(bm)); } }
+#endif
+            const bool fix = (bool)__shfl_up((int)bad, 1, 64) && lane > 0;
+            const int newt = __shfl_up(epos, 1, 64);
+            if (fix) {
+                int pos = newt;
+                d.seek(s, len, a0 + pos);
+                tpos = pos;
+                cnt = pos < hi ? d.count_until(pos, hi) : 0u;
+                epos = pos;
+            }
+        }
+#ifdef MZD_HUF_SEG_STATS
+        { const unsigned long long bm = __ballot(act); if (lane == 0) { atomicAdd(&g_huf_seg_stats[0], 1ull); atomicAdd(&g_huf_seg_stats[3], (unsigned long long)__popcll(bm)); } }
+#endif
+        const uint32_t incl = wave_incl_scan_u32(act ? cnt : 0u, lane);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint64_t am = __ballot(act);
+        p0 = __shfl(epos, 63 - __builtin_clzll(am), 64);  // lane 0 is active: am != 0
+        if (out_done + total > want) {  // the serial loop stops at `want` symbols with bits left (literals.go:320,332,349,366)
+            status = MZD_ERR_HUF_LENGTH;
+            break;
+        }
+        // ---- write pass: exactly cnt symbols from tpos to out + (symbols of the rounds and lanes below)
+        if (act && cnt) {
+            uint8_t *out = litbuf + t.out_off + out_done + (incl - cnt);
+            d.seek(s, len, a0 + tpos);
+            uint32_t n = 0;
+            constexpr int PAIRS = G >= 8 ? 1 : 2, PER = 2 * G * PAIRS;  // symbols per store group: 16 (2 x 8) or 20 (4 x 5)
+            if (n + PER <= cnt) {
+                d.load_q();
+                do {
+                    uint32_t w[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int pr = 0; pr < PAIRS; pr++) {
+                        d.refill_first();
+#pragma unroll
+                        for (int j = 0; j < G; j++) {
+                            const int i = pr * 2 * G + j;
+                            w[i >> 2] |= (d.sym() & 0xFF) << (8 * (i & 3));
+                        }
+                        d.refill_second();
+#pragma unroll
+                        for (int j = 0; j < G; j++) {
+                            const int i = pr * 2 * G + G + j;
+                            w[i >> 2] |= (d.sym() & 0xFF) << (8 * (i & 3));
+                        }
+                    }
+                    *(U128U *)(out + n) = U128U{w[0], w[1], w[2], w[3]};
+                    if (PER == 20) *(U32U *)(out + n + 16) = U32U{w[4]};
+                    n += PER;
+                } while (n + PER <= cnt);
+                d.q_wait();  // see count_until
+            }
+            while (n < cnt) out[n++] = (uint8_t)(d.one() & 0xFF);
+        }
+        out_done += total;
+    }
+    // ---- status of the whole stream: what the serial loop gives (see the kernel comment)
+    if (status == MZD_OK) {
+        const int rem = R - p0;
+        if (out_done < want) status = rem < 0 ? MZD_ERR_HUF_BITS : MZD_ERR_HUF_LENGTH;
+        else if (rem < 0) status = MZD_ERR_HUF_BITS;
+    }
+    if (status != MZD_OK && lane == 0) atomicMin(&sums[t.block].huf_err, (stream_idx << 8) | (uint32_t)status);
+}
+
+__global__ __launch_bounds__(256) void k_huf_seg(const uint8_t *__restrict__ in, const HufTask *__restrict__ tasks,
+                                                 uint32_t n_tasks, const uint16_t *__restrict__ huf_entries,
+                                                 uint8_t *__restrict__ litbuf, BlockSum *sums)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *tbl = (uint16_t *)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tid = blockIdx.x * 4 + wave;  // tasks come in quads that share one table
+    HufTask t = tasks[min(tid, n_tasks - 1)];
+    if (tid >= n_tasks) { t.in_size = 0; t.out_size = 0; }
+    {
+        const HufTask t0 = tasks[blockIdx.x * 4];
+        const uint32_t n32 = (1u << t0.max_bits) >> 1;  // 2-byte cells, tables start on even cells, MaxBits >= 1
+        const uint32_t *src = (const uint32_t *)(huf_entries + t0.table_off);
+        uint32_t *dst = (uint32_t *)tbl;
+        for (uint32_t i = threadIdx.x; i < n32; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if ((t.in_size | t.out_size) == 0) return;  // null task (sections with one stream use the first wavefront only)
+    if (t.max_bits <= 7) huf_seg_stream<8>(in, t, tbl, litbuf, sums, tid & 3u, lane);
+    else huf_seg_stream<5>(in, t, tbl, litbuf, sums, tid & 3u, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2290,7 +2574,6 @@ __global__ __launch_bounds__(64) void k_xxh64(const uint8_t *__restrict__ out_bl
 // independent loads in flight per lane: reads the first n_read 16-byte words of src once and writes
 // n_write words of dst once (words past n_read repeat the lane's last loaded value: a write-only
 // stream, like an RLE fill) -- the algorithmic bytes of a pass, C in and D out, and nothing else.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_copy_ceiling(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst,
                                                        uint64_t n_read, uint64_t n_write)
 {

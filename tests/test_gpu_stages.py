@@ -99,13 +99,13 @@ def _next_offset(hist, value, ll):
     return off
 
 
-@pytest.mark.parametrize("seq_variant", [0, 1])
-def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle, seq_variant):
+@pytest.mark.parametrize("seq_variant,huf_variant", [(0, 1), (1, 1), (0, 2)])
+def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle, seq_variant, huf_variant):
     """After one pass over the whole corpus: for every compressed block, the literal bytes the Huffman stage
     regenerated (literals.go:283-361 LiteralSection.Data) and every sequence's (LiteralLength, MatchLength,
     resolved offset) (sequences.go:11-15 + sequence_execution.go:65-114) as the device holds them between its
     stages equal the oracle's trace, block by block -- not only the final bytes."""
-    c = z.Context(0, seq_variant=seq_variant)
+    c = z.Context(0, seq_variant=seq_variant, huf_variant=huf_variant)
     frames = [comp for _, comp, *_ in corpus]
     plan = z.Plan(device_tables=True)
     for f in frames:
@@ -180,6 +180,78 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
         rb.free()
         plan.close()
         c.close()
+
+
+# ---- k_huf_seg: one wavefront per Huffman stream, segments decoded in parallel (self-synchronising codes)
+
+def test_huf_seg_corpus_bit_exact_all_maxbits(corpus):
+    """The whole corpus (Huffman tables with MaxBits 1..11, 1- and 4-stream sections, Treeless tables, streams from
+    a few bytes to 40 KB) through k_huf_seg: golden bytes."""
+    from tests.conftest import check_expected
+    c = z.Context(0, huf_variant=2)
+    outs, sts = z.decode_frames([comp for _, comp, *_ in corpus], c)
+    assert sts == [0] * len(corpus)
+    for (name, comp, length, sha, exp), got in zip(corpus, outs):
+        check_expected(name, got, length, sha, exp)
+    outs_d, sts_d = z.decode_frames([comp for _, comp, *_ in corpus], c, device_plan=True)
+    assert sts_d == sts and outs_d == outs
+    c.close()
+
+
+def test_huf_seg_literal_heavy_frames_of_every_size(oracle):
+    """Literals-only and mixed frames whose streams range from one symbol to 32 768 (1 to 64 segments per stream,
+    segment borders everywhere), skewed (short codes, many symbols per segment) and flat (MaxBits 11) alphabets."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(11)
+    frames, want = [], []
+    sizes = [1, 2, 5, 63, 64, 65, 200, 511, 512, 513, 1000, 4097, 9000, 20000, 65535, 65536, 100000, 131071, 131072]
+    for i, n in enumerate(sizes + [int(x) for x in rng.integers(1, 131073, 40)]):
+        kind = [sb.EXP, sb.TEXT, sb.EXP][i % 3]
+        data = sb.generate(kind, 500 + i, n)
+        mode = sb.MODE_LITERALS if i % 2 == 0 else sb.MODE_FULL
+        frames.append(sb.compress(data, mode)[0])
+        want.append(data)
+    for hv in (2, 1):
+        c = z.Context(0, huf_variant=hv)
+        outs, sts = z.decode_frames(frames, c)
+        assert sts == [0] * len(frames), (hv, sts)
+        assert outs == want, hv
+        c.close()
+    for f, w in list(zip(frames, want))[::9]:
+        rc, ref, _, _ = oracle.decode_frame(f, cap=len(w) + 64)
+        assert rc == 0 and ref == w
+
+
+def test_huf_seg_reports_the_lane_kernels_status_on_damaged_streams(corpus, oracle):
+    """End conditions of huffman.go:248-261 / literals.go:320-366 under damage: every corpus frame and literal-heavy
+    synthetic frames, mutated (seeded byte flips) -- k_huf_seg and k_huf must give the SAME status and bytes frame for
+    frame, a frame either decodes under the oracle to the same bytes or is rejected by it too."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(20261002)
+    base = [comp for _, comp, *_ in corpus if len(comp) >= 24]
+    for i in range(30):
+        base.append(sb.compress(sb.generate(sb.EXP, 900 + i, int(rng.integers(2000, 131073))), sb.MODE_LITERALS)[0])
+    frames = []
+    for comp in base:
+        for k in range(4):
+            b = bytearray(comp)
+            for pos in rng.integers(8, len(b), size=1 + k % 3):
+                b[int(pos)] ^= int(rng.integers(1, 256))
+            frames.append(bytes(b))
+    res = {}
+    for hv in (1, 2):
+        c = z.Context(0, huf_variant=hv)
+        res[hv] = z.decode_frames(frames, c)
+        c.close()
+    assert res[1][1] == res[2][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[1][1], res[2][1])) if a != b][:20]
+    assert res[1][0] == res[2][0]
+    n_huf_err = sum(1 for s in res[2][1] if s in (8, 9, 10))
+    assert n_huf_err > 20  # the damage really reached the Huffman end conditions
+    for f, o, s in list(zip(frames, res[2][0], res[2][1]))[::5]:
+        rc, ref, _, _ = oracle.decode_frame(f, cap=4 << 20)
+        assert (rc == 0) == (s == 0) or s != 0  # the device may be stricter, never laxer
+        if s == 0:
+            assert rc == 0 and o == ref
 
 
 # ---- BASELINE.json configs at their stated sizes: size-independent properties on every frame
