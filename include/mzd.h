@@ -352,9 +352,12 @@ enum {
     MZD_DEBUG_BLOCKS = 3     /* mzd_debug_block per block of the batch */
 };
 typedef struct mzd_debug_block {
-    uint64_t src_off, lit_src, rec_off; /* lit_src: offset in MZD_DEBUG_LITERALS (Huffman) or in the input blob (Raw / RLE literals) */
+    uint64_t src_off, lit_src, rec_off; /* lit_src: offset in MZD_DEBUG_LITERALS (Huffman), in the input blob (Raw / RLE
+                                           literals), or -- lit_in_place -- in the OUTPUT blob */
     uint32_t size, lit_regen, n_seq, tile_off;
-    uint8_t type, lit_type, pad[6];
+    uint8_t type, lit_type;
+    uint8_t lit_in_place; /* a block without sequences whose literals the Huffman stage wrote straight to its output */
+    uint8_t pad[5];
 } mzd_debug_block;
 int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset, void *dst, uint64_t bytes);
 

@@ -34,7 +34,7 @@ class DebugBlock(ctypes.Structure):
     _fields_ = [("src_off", ctypes.c_uint64), ("lit_src", ctypes.c_uint64), ("rec_off", ctypes.c_uint64),
                 ("size", ctypes.c_uint32), ("lit_regen", ctypes.c_uint32), ("n_seq", ctypes.c_uint32),
                 ("tile_off", ctypes.c_uint32), ("type", ctypes.c_uint8), ("lit_type", ctypes.c_uint8),
-                ("pad", ctypes.c_uint8 * 6)]
+                ("lit_in_place", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 5)]
 
 
 

@@ -101,6 +101,7 @@ struct mzd_dbatch {
     float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
     uint64_t out_size = 0;
     uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
+    uint64_t huf_out_bytes = 0;                        // literals the Huffman stage regenerates (scratch or in place)
     mzd_batch_stats stats{};
 };
 
@@ -361,7 +362,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     std::vector<DBlock> blocks(b->n_blocks);
     std::vector<HufTask> huf_tasks;
     std::vector<SeqTask> seq_tasks;
-    uint64_t rec_total = 0, tile_total = 0, lit_total = 0;
+    uint64_t rec_total = 0, tile_total = 0, lit_total = 0, huf_out_total = 0;
     mzd_batch_stats st{};
     auto in_range = [&](uint64_t off, uint64_t n) { return off <= b->in_size && n <= b->in_size - off; };
     std::vector<uint32_t> frame_seq_task(b->n_frames + 1, 0);
@@ -388,6 +389,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         st.out_capacity_bytes += fd.out_capacity;
         bool seen_seq = false;
         uint64_t in_lo = ~0ull, in_hi = 0;
+        // where the block's output starts in the frame, as long as every earlier block's regenerated size is known
+        // without decoding (Raw / RLE blocks, compressed blocks without sequences: their output IS their literals)
+        bool pos_known = true;
+        uint64_t out_pos = 0;
         for (uint32_t k = 0; k < fd.n_blocks && df.plan_status == MZD_OK; k++) {
             const uint32_t bi = fd.first_block + k;
             const mzd_block_desc &bd = b->blocks[bi];
@@ -401,6 +406,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                 d.src_off = bd.src_off;
                 st.compressed_bytes += need;
                 st.n_blocks[bd.type]++;
+                out_pos += bd.size;
                 continue;
             }
             if (bd.type != MZD_BLOCK_COMPRESSED) { df.plan_status = MZD_ERR_BLOCK_TYPE; break; }
@@ -425,30 +431,40 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                 if (!in_range(bd.lit_off, csum)) { df.plan_status = MZD_ERR_TRUNCATED; break; }
                 const uint32_t normal = ns == 4 ? (bd.lit_regen + 3) / 4 : bd.lit_regen;  // literals.go:306-307
                 if (ns == 4 && 3ull * normal > bd.lit_regen) { df.plan_status = MZD_ERR_HUF_LENGTH; break; }
-                d.lit_src = lit_total;
+                // A block without sequences regenerates exactly its literals (sequence_execution.go:55-59).  When its
+                // place in the frame is known beforehand the Huffman stage writes them THERE and the execution stage has
+                // nothing to copy (BASELINE configs[2]: the whole 512 MiB of output once instead of twice).
+                const bool in_place = bd.n_seq == 0 && pos_known && out_pos + bd.lit_regen <= fd.out_capacity;
+                const uint64_t lit_base = in_place ? fd.out_offset + out_pos : lit_total;
+                d.lit_src = lit_base;
+                d.pad[0] = in_place ? 1 : 0;
                 uint64_t ioff = bd.lit_off;
                 for (int s = 0; s < 4; s++) {
                     HufTask t{};
+                    t.pad = in_place ? 1u : 0u;  // out_off is relative to the output blob (patched to the literal scratch's base below)
                     if (s < ns) {
                         t.in_off = ioff;
                         t.in_size = bd.lit_stream_size[s];
-                        t.out_off = lit_total + (uint64_t)s * normal;
+                        t.out_off = lit_base + (uint64_t)s * normal;
                         t.out_size = ns == 4 ? (s < 3 ? normal : bd.lit_regen - 3 * normal) : bd.lit_regen;
                         ioff += t.in_size;
                         st.n_huf_streams++;
+                        huf_out_total += t.out_size;
                     }
                     t.table_off = huf_dev_off[bd.huf_table];
                     t.max_bits = huf_bits[bd.huf_table];
                     t.block = bi;
                     huf_tasks.push_back(t);
                 }
-                lit_total += ((uint64_t)bd.lit_regen + 15) & ~15ull;
+                if (!in_place) lit_total += ((uint64_t)bd.lit_regen + 15) & ~15ull;
                 st.compressed_bytes += csum;
             } else {
                 df.plan_status = MZD_ERR_INVALID_ARG;
                 break;
             }
             d.n_seq = bd.n_seq;
+            if (bd.n_seq == 0) out_pos += bd.lit_regen;
+            else pos_known = false;
             if (bd.n_seq > 0) {
                 const uint32_t ti[3] = {bd.ll_table, bd.of_table, bd.ml_table};
                 bool ok = true;
@@ -548,6 +564,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         HIP_OR_FAIL(hipMalloc((void **)&db->d_out, std::max<uint64_t>(b->out_size, 16)));
         db->own_out = true;
     }
+    HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
+    // literals that go straight to their place in the output: the kernels address them from the literal scratch's base
+    for (HufTask &t : huf_tasks)
+        if (t.pad) t.out_off = (uint64_t)(uintptr_t)db->d_out + t.out_off - (uint64_t)(uintptr_t)db->d_litbuf;
     TRY_OR_FAIL(upload_vec(ctx, frames, &db->d_frames));
     TRY_OR_FAIL(upload_vec(ctx, blocks, &db->d_blocks));
     TRY_OR_FAIL(upload_vec(ctx, huf_tasks, &db->d_huf_tasks));
@@ -636,10 +656,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     }
     HIP_OR_FAIL(hipMalloc((void **)&db->d_recs, std::max<uint64_t>(rec_total, 1) * 8));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_tiles, std::max<uint64_t>(tile_total, 1) * sizeof(TileBase)));
-    HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
     db->n_recs = rec_total;
     db->n_tiles = tile_total;
     db->lit_bytes = lit_total;
+    db->huf_out_bytes = huf_out_total;
     HIP_OR_FAIL(hipMalloc((void **)&db->d_status, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_out_len, std::max<size_t>(b->n_frames, 1) * sizeof(uint64_t)));
     HIP_OR_FAIL(hipMemset(db->d_status, 0xFF, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
@@ -840,6 +860,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     db->n_recs = n_rec;
     db->n_tiles = n_tile;
     db->lit_bytes = lit_total;
+    db->huf_out_bytes = lit_total;
     ENSURE(db->d_status, db->cap.status, nf1 * sizeof(int32_t));
     ENSURE(db->d_out_len, db->cap.out_len, nf1 * sizeof(uint64_t));
     HIP_OR_FAIL(hipMemsetAsync(db->d_status, 0xFF, nf1 * sizeof(int32_t), s));
@@ -1254,12 +1275,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const uint32_t hv = ctx->opt.huf_variant;
         const uint64_t streams = std::max<uint64_t>(db->stats.n_huf_streams, 1);
         const bool seg = hv == 2 || (hv == 0 && streams < 64ull * 8 * (uint64_t)std::max(ctx->num_cus, 1) &&
-                                     db->lit_bytes / streams >= 2048);
-        size_t seg_lds = (size_t)db->huf_slot_cells * 2;
+                                     db->huf_out_bytes / streams >= 2048);
+        const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
+        size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = getenv("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
         if (seg)
-            k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks,
-                                                                                      db->d_huf_entries, db->d_litbuf, db->d_sums);
+            k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
+                                                               db->d_litbuf, db->d_sums, seg_tbl);
         else
             k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                   db->d_litbuf, db->d_sums, db->huf_slot_cells);

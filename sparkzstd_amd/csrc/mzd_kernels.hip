@@ -480,36 +480,69 @@ __device__ unsigned long long g_huf_seg_stats[8];  // streams, validation rounds
 constexpr int kSegApproach = MZD_SEG_APPROACH;  // bits a lane decodes ahead of its segment to fall into step
 constexpr int kSegBits = MZD_SEG_BITS;          // a lane's segment; a round of 64 lanes covers 64 times as much
 
-// Bit window of one lane of k_huf_seg.  The bulk loops refill it from a 16-byte register buffer Q = the bytes
-// [ptr - 16, ptr) of the stream, loaded with ONE unaligned 16-byte load per PAIR of refills, a whole group of G
-// symbols before its first use: the memory latency is off the decode chain.  Bytes below the start of the stream
-// must read as zero (reversebitstream.go:23-27); they are masked when Q is USED, not when it is loaded (masking at
-// the load made every refill wait for its own load), and only if some lane of the wavefront is that close to the
-// start of its stream.
-template <int G>  // symbols between two refills: 7 + G * MaxBits <= 64
-struct SegDec {
-    const uint8_t *s;
-    const uint16_t *tbl;
-    uint64_t C, Qhi, Qlo;
-    u32x4 Q;  // destination of the 16-byte request in flight
-    int ptr, k, qat, mb;
-    uint32_t s8;
+// Bit window of one lane of k_huf_seg.  A lane's share of a round -- approach run, segment and lookahead,
+// kSegLaneBytes of the stream -- is copied ONCE into the lane's own LDS strip (eight 16-byte loads per lane: the
+// only reads of the stream; bytes below the start of the stream become zeros there, reversebitstream.go:23-27)
+// and all passes read their bits from it with aligned dword reads.  (Refilling from global memory with per-lane
+// loads cost the kernel its time: every such load or store is a 64-line gather that keeps the CU's address unit
+// busy for ~80 cycles, and there were ~60 of them per lane and round: TA_BUSY = the kernel's duration.)
+// The window is 64 bits wide and refilled in whole dwords: C = strip bytes [p, p + 8), p a multiple of 4,
+// k = bits already consumed from its top; a refill shifts in the one or two dwords below once k >= 32.
+constexpr int kSegLaneBytes = 128;   // 256 + 512 bits of approach and segment, lookahead, alignment slack
+constexpr int kSegLaneDwords = 33;   // strip stride: the 64 strips start in different LDS banks
+constexpr int kSegTopByte = 123;     // strip byte that holds the first bit the lane looks at in a round
+static_assert(8 * (kSegTopByte - 8 - 4) >= kSegApproach + kSegBits + 11 + 7 + 32, "a lane's strip covers its approach run, segment and lookahead");
 
-    __device__ __forceinline__ static uint64_t mask_below(uint64_t v, int at)  // bytes [at, at + 8), zero below the stream
+template <int G>  // symbols between two refills: 31 + G * MaxBits <= 64
+struct SegDec {
+    const uint16_t *tbl;
+    uint32_t *strip;  // the lane's LDS strip
+    uint64_t C;
+    int p, k, mb;     // p: strip byte offset of the window's low end (multiple of 4); k: bits consumed from its top
+    int xb, len;      // strip byte r <-> stream byte xb + r
+
+    // copies stream bytes [xb, xb + kSegLaneBytes) into the strip; a_top = absolute bit (from the top of the last
+    // byte of the stream) the lane starts at.  The blob has MZD_IN_PAD readable bytes on both sides.
+    __device__ __forceinline__ void fill(const uint8_t *s, int stream_len, int a_top)
     {
-        if (at < 0) {
-            const int z = -at;
-            v = z >= 8 ? 0ull : ((v >> (8 * z)) << (8 * z));
+        len = stream_len;
+        xb = (len - 1 - (a_top >> 3)) - kSegTopByte;
+        U128U q[kSegLaneBytes / 16];
+#pragma unroll
+        for (int c = 0; c < kSegLaneBytes / 16; c++) {
+            const int x = min(max(xb + 16 * c, -16), len);  // chunks entirely outside the stream: any readable address
+            q[c] = *(const U128U *)(s + x);
         }
-        return v;
+#pragma unroll
+        for (int c = 0; c < kSegLaneBytes / 16; c++) {
+            const int x = xb + 16 * c;
+            uint64_t lo = (uint64_t)q[c].x | ((uint64_t)q[c].y << 32), hi = (uint64_t)q[c].z | ((uint64_t)q[c].w << 32);
+            if (x < 0) {  // bytes below the start of the stream read as zero
+                const int z = min(-x, 16);
+                if (z >= 8) { lo = 0; hi = z >= 16 ? 0ull : ((hi >> (8 * (z - 8))) << (8 * (z - 8))); }
+                else lo = (lo >> (8 * z)) << (8 * z);
+            }
+            strip[4 * c + 0] = (uint32_t)lo;
+            strip[4 * c + 1] = (uint32_t)(lo >> 32);
+            strip[4 * c + 2] = (uint32_t)hi;
+            strip[4 * c + 3] = (uint32_t)(hi >> 32);
+        }
     }
-    __device__ __forceinline__ uint64_t load_below(int at) const { return mask_below(ld64u(s + max(at, -8)), at); }
-    __device__ __forceinline__ void seek(const uint8_t *start, int len, int a)  // a = bits from the top of the last byte
+    __device__ __forceinline__ void seek(int a)  // a = absolute bit
     {
-        s = start;
-        ptr = len - 8 - (a >> 3);
-        k = a & 7;
-        C = load_below(ptr);
+        const int r = (len - 1 - (a >> 3)) - xb;  // strip byte that holds the bit
+        p = (r & ~3) - 4;
+        k = 8 * (p + 7 - r) + (a & 7);
+        C = (uint64_t)strip[p >> 2] | ((uint64_t)strip[(p >> 2) + 1] << 32);
+    }
+    __device__ __forceinline__ void refill()  // k < 32 afterwards
+    {
+        const uint32_t d1 = strip[(p >> 2) - 1], d2 = strip[(p >> 2) - 2];
+        const int n = k >> 5;  // 0, 1 or 2 dwords
+        const uint64_t c1 = (C << 32) | d1, c2 = ((uint64_t)d1 << 32) | d2;
+        C = n == 0 ? C : (n == 1 ? c1 : c2);
+        p -= 4 * n;
+        k &= 31;
     }
     __device__ __forceinline__ uint32_t sym()  // one lookup; returns the cell {symbol, nbits << 8}, advances the window
     {
@@ -518,72 +551,22 @@ struct SegDec {
         k += (int)(e >> 8);
         return e;
     }
-    __device__ __forceinline__ uint32_t one()  // symbol by symbol (segment borders, tails): refills with a load of its own
+    __device__ __forceinline__ uint32_t one()
     {
-        if (k + mb > 57) {
-            const int nb = k >> 3, sh = nb * 8;
-            const uint64_t D = load_below(ptr - 8);
-            C = (C << sh) | ((D >> 1) >> (63 - sh));
-            ptr -= nb;
-            k &= 7;
-        }
+        if (k >= 32) refill();
         return sym();
     }
-    // Request the 16 bytes below the window.  The load is an asm statement so that it STAYS where it is written, a
-    // whole group of symbols ahead of its first use: hipcc merged the C++ load at the end of the loop body with the
-    // one in front of the loop into ONE load at the loop header, right in front of its use, and every pair of
-    // refills waited out a full memory latency.  hipcc does not count an asm load: q_wait() is its s_waitcnt.
-    __device__ __forceinline__ void load_q()
-    {
-        qat = ptr - 16;
-        const uint8_t *p = s + max(qat, -16);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q) : "v"(p) : "memory");
-    }
-    __device__ __forceinline__ void q_wait() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(Q) : : "memory"); }
-    __device__ __forceinline__ void refill_first()  // takes the top bytes of a fresh Q
-    {
-        q_wait();
-        Qlo = (uint64_t)Q.x | ((uint64_t)Q.y << 32);
-        Qhi = (uint64_t)Q.z | ((uint64_t)Q.w << 32);
-        if (__any(qat < 0)) {  // rare: a lane within 16 bytes of the start of its stream
-            Qlo = mask_below(Qlo, qat);
-            Qhi = mask_below(Qhi, qat + 8);
-        }
-        const int nb = k >> 3, sh = nb * 8;
-        C = (C << sh) | ((Qhi >> 1) >> (63 - sh));
-        ptr -= nb;
-        k &= 7;
-        s8 = (uint32_t)sh;
-    }
-    __device__ __forceinline__ void refill_second()  // takes the bytes s8 / 8 below the top of Q, then requests the next Q
-    {
-        const int nb = k >> 3, sh = nb * 8;
-        const uint64_t M = (Qhi << s8) | ((Qlo >> 1) >> (63 - s8));
-        C = (C << sh) | ((M >> 1) >> (63 - sh));
-        ptr -= nb;
-        k &= 7;
-        load_q();
-    }
-    // symbols that START in [pos, hi): returns how many, pos ends at the first boundary >= hi
+    // decodes up to the first code boundary >= hi; returns the number of symbols that START in [pos, hi)
     __device__ __forceinline__ uint32_t count_until(int &pos, int hi)
     {
         uint32_t n = 0;
-        if (pos + 2 * G * mb <= hi) {  // all 2 G symbols of a pair of groups start below hi
-            load_q();
-            do {
-                refill_first();
-                int k0 = k;
+        while (pos + G * mb <= hi) {  // all G symbols start below hi
+            refill();
+            const int k0 = k;
 #pragma unroll
-                for (int g = 0; g < G; g++) sym();
-                pos += k - k0;
-                refill_second();
-                k0 = k;
-#pragma unroll
-                for (int g = 0; g < G; g++) sym();
-                pos += k - k0;
-                n += 2 * G;
-            } while (pos + 2 * G * mb <= hi);
-            q_wait();  // the last request is never used, but it must have landed before its registers are anybody else's
+            for (int g = 0; g < G; g++) sym();
+            pos += k - k0;
+            n += G;
         }
         while (pos < hi) {
             pos += (int)(one() >> 8);
@@ -593,9 +576,13 @@ struct SegDec {
     }
 };
 
+struct __attribute__((packed, aligned(1))) U96U { uint32_t x, y, z; };
+struct __attribute__((packed, aligned(1))) U16U { uint16_t v; };
+
 template <int G>
 __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, const HufTask &t, const uint16_t *tbl,
-                                               uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t stream_idx, int lane)
+                                               uint32_t *strip, uint8_t *__restrict__ litbuf, BlockSum *sums,
+                                               uint32_t stream_idx, int lane)
 {
     const uint8_t *s = in + t.in_off;
     const int len = (int)t.in_size, mb = (int)t.max_bits;
@@ -607,12 +594,10 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
     const int R = 8 * len - a0;  // data bits
     SegDec<G> d;
     d.tbl = tbl;
+    d.strip = strip;
     d.mb = mb;
-    d.qat = 0;
     // ROUNDS of 64 segments of kSegBits: a round reads one contiguous 4 KiB piece of the stream and writes one
-    // contiguous piece of the literals, so what the wavefront's lanes touch at any time is a few dozen cache lines
-    // (one segment per lane over the WHOLE stream made every lane stream its own lines: with thousands of
-    // wavefronts in flight nothing stayed cached and every 16-byte access cost a sector of DRAM traffic).
+    // contiguous piece of the literals.
     int p0 = 0;             // exact code boundary where the round starts
     uint32_t out_done = 0;  // symbols written by earlier rounds
     while (status == MZD_OK && p0 < R) {
@@ -622,9 +607,17 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
         int tpos = 0, epos = 0;
         uint32_t cnt = 0;
         if (act) {
-            // ---- count pass: approach, first boundary at or after lo, symbols up to hi
+            // ---- the lane's strip, then the count pass: approach, first boundary at or after lo, symbols up to hi
             int pos = max(lo - kSegApproach, p0);
-            d.seek(s, len, a0 + pos);
+            d.fill(s, len, a0 + pos);
+            d.seek(a0 + pos);
+            while (pos + G * mb <= lo) {
+                d.refill();
+                const int k0 = d.k;
+#pragma unroll
+                for (int g = 0; g < G; g++) d.sym();
+                pos += d.k - k0;
+            }
             while (pos < lo) pos += (int)(d.one() >> 8);
             tpos = pos;
             cnt = d.count_until(pos, hi);
@@ -641,9 +634,9 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
 #endif
             const bool fix = (bool)__shfl_up((int)bad, 1, 64) && lane > 0;
             const int newt = __shfl_up(epos, 1, 64);
-            if (fix) {
+            if (fix) {  // newt < lo + MaxBits: inside the lane's strip
                 int pos = newt;
-                d.seek(s, len, a0 + pos);
+                d.seek(a0 + pos);
                 tpos = pos;
                 cnt = pos < hi ? d.count_until(pos, hi) : 0u;
                 epos = pos;
@@ -663,35 +656,49 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
         // ---- write pass: exactly cnt symbols from tpos to out + (symbols of the rounds and lanes below)
         if (act && cnt) {
             uint8_t *out = litbuf + t.out_off + out_done + (incl - cnt);
-            d.seek(s, len, a0 + tpos);
+            d.seek(a0 + tpos);
             uint32_t n = 0;
-            constexpr int PAIRS = G >= 8 ? 1 : 2, PER = 2 * G * PAIRS;  // symbols per store group: 16 (2 x 8) or 20 (4 x 5)
-            if (n + PER <= cnt) {
-                d.load_q();
-                do {
-                    uint32_t w[5] = {0, 0, 0, 0, 0};
+            constexpr int PER = 12;  // symbols per store
+            while (n + PER <= cnt) {
+                uint32_t w[3] = {0, 0, 0};
 #pragma unroll
-                    for (int pr = 0; pr < PAIRS; pr++) {
-                        d.refill_first();
+                for (int g = 0; g < PER / G; g++) {
+                    d.refill();
 #pragma unroll
-                        for (int j = 0; j < G; j++) {
-                            const int i = pr * 2 * G + j;
-                            w[i >> 2] |= (d.sym() & 0xFF) << (8 * (i & 3));
-                        }
-                        d.refill_second();
-#pragma unroll
-                        for (int j = 0; j < G; j++) {
-                            const int i = pr * 2 * G + G + j;
-                            w[i >> 2] |= (d.sym() & 0xFF) << (8 * (i & 3));
-                        }
+                    for (int j = 0; j < G; j++) {
+                        const int i = g * G + j;
+                        w[i >> 2] |= (d.sym() & 0xFF) << (8 * (i & 3));
                     }
-                    *(U128U *)(out + n) = U128U{w[0], w[1], w[2], w[3]};
-                    if (PER == 20) *(U32U *)(out + n + 16) = U32U{w[4]};
-                    n += PER;
-                } while (n + PER <= cnt);
-                d.q_wait();  // see count_until
+                }
+                *(U96U *)(out + n) = U96U{w[0], w[1], w[2]};
+                n += PER;
             }
-            while (n < cnt) out[n++] = (uint8_t)(d.one() & 0xFF);
+            // the last r < 12 symbols: exactly r bytes leave (the next byte belongs to another lane)
+            const uint32_t r = cnt - n;
+            uint64_t acc = 0;
+            uint32_t acc2 = 0;
+            for (uint32_t i = 0; i < r; i++) {
+                const uint64_t sy = d.one() & 0xFF;
+                if (i < 8) acc |= sy << (8 * i);
+                else acc2 |= (uint32_t)sy << (8 * (i - 8));
+            }
+            uint8_t *o = out + n;
+            if (r & 8) {
+                *(U64U *)o = U64U{acc};
+                o += 8;
+                acc = acc2;
+            }
+            if (r & 4) {
+                *(U32U *)o = U32U{(uint32_t)acc};
+                o += 4;
+                acc >>= 32;
+            }
+            if (r & 2) {
+                *(U16U *)o = U16U{(uint16_t)acc};
+                o += 2;
+                acc >>= 16;
+            }
+            if (r & 1) *o = (uint8_t)acc;
         }
         out_done += total;
     }
@@ -704,12 +711,15 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
     if (status != MZD_OK && lane == 0) atomicMin(&sums[t.block].huf_err, (stream_idx << 8) | (uint32_t)status);
 }
 
+constexpr int kHufSegStripBytes = 4 * 64 * kSegLaneDwords * 4;  // four wavefronts of 64 strips
+
 __global__ __launch_bounds__(256) void k_huf_seg(const uint8_t *__restrict__ in, const HufTask *__restrict__ tasks,
                                                  uint32_t n_tasks, const uint16_t *__restrict__ huf_entries,
-                                                 uint8_t *__restrict__ litbuf, BlockSum *sums)
+                                                 uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t table_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t *tbl = (uint16_t *)smem;
+    uint16_t *tbl = (uint16_t *)smem;                       // the section's decode table (table_bytes, a multiple of 16)
+    uint32_t *strips = (uint32_t *)(smem + table_bytes);    // [wavefront][lane][kSegLaneDwords]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tid = blockIdx.x * 4 + wave;  // tasks come in quads that share one table
     HufTask t = tasks[min(tid, n_tasks - 1)];
@@ -723,8 +733,10 @@ __global__ __launch_bounds__(256) void k_huf_seg(const uint8_t *__restrict__ in,
     }
     __syncthreads();
     if ((t.in_size | t.out_size) == 0) return;  // null task (sections with one stream use the first wavefront only)
-    if (t.max_bits <= 7) huf_seg_stream<8>(in, t, tbl, litbuf, sums, tid & 3u, lane);
-    else huf_seg_stream<5>(in, t, tbl, litbuf, sums, tid & 3u, lane);
+    uint32_t *strip = strips + (wave * 64 + lane) * kSegLaneDwords;
+    if (t.max_bits <= 5) huf_seg_stream<6>(in, t, tbl, strip, litbuf, sums, tid & 3u, lane);
+    else if (t.max_bits <= 8) huf_seg_stream<4>(in, t, tbl, strip, litbuf, sums, tid & 3u, lane);
+    else huf_seg_stream<3>(in, t, tbl, strip, litbuf, sums, tid & 3u, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2448,8 +2460,9 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
             __syncthreads();  // flushed bytes are visible to the whole workgroup before the next chunk reads them
             t0 = t1;
         }
-        // ---- literals after the last sequence (sequence_execution.go:55-59): straight to HBM
-        {
+        // ---- literals after the last sequence (sequence_execution.go:55-59): straight to HBM (unless the Huffman
+        // stage already put them there: a block without sequences whose place in the frame was known beforehand)
+        if (!b.pad[0]) {
             const uint32_t rest = b.lit_regen - litTotal;
             uint8_t *d = bout + seqOut;
             if (litRle) {

@@ -114,17 +114,18 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
     rb = c.upload(b)
     try:
         rb.run()
-        _, status, _ = rb.download(want_out=False)
+        out_blob, status, _ = rb.download()
         assert (status == 0).all()
         st = rb.stats()
         dblocks = rb.debug_blocks(b.n_blocks)
         n_rec = int(st.n_sequences)
         recs = rb.debug_read(_lib.MZD_DEBUG_RECORDS, np.uint64, 0, n_rec)
-        lit_bytes = max((int(d.lit_src) + int(d.lit_regen) for d in dblocks if d.type == 2 and d.lit_type == 2), default=0)
+        lit_bytes = max((int(d.lit_src) + int(d.lit_regen) for d in dblocks if d.type == 2 and d.lit_type == 2 and not d.lit_in_place),
+                        default=0)
         lits = rb.debug_read(_lib.MZD_DEBUG_LITERALS, np.uint8, 0, lit_bytes)
         tiles = rb.debug_read(_lib.MZD_DEBUG_TILES, np.uint32, 0, 2 * sum((int(d.n_seq) + 63) // 64 for d in dblocks))
         blob = bytes(np.ctypeslib.as_array(ctypes.cast(b.in_, ctypes.POINTER(ctypes.c_uint8)), shape=(b.in_size,)))
-        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = 0
+        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = n_in_place = 0
         for fi, f in enumerate(frames):
             rc, _, _, tr = oracle.decode_frame(f, cap=corpus[fi][2] + 64, want_trace=True)
             assert rc == 0
@@ -143,7 +144,11 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
                 want_l = tr["literals"][lit_at:lit_at + regen]
                 lit_at += regen
                 assert d.lit_regen == regen
-                if d.lit_type == 2:
+                if d.lit_type == 2 and d.lit_in_place:  # no sequences: the Huffman stage wrote the block's output itself
+                    assert ob["n_seq"] == 0
+                    got_l = out_blob[int(d.lit_src):int(d.lit_src) + regen].tobytes()
+                    n_in_place += 1
+                elif d.lit_type == 2:
                     got_l = lits[int(d.lit_src):int(d.lit_src) + regen].tobytes()
                 elif d.lit_type == 0:
                     got_l = blob[int(d.lit_src):int(d.lit_src) + regen]
