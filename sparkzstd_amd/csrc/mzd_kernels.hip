@@ -1282,6 +1282,12 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(has ? t.n_seq : 0u));
     int status = MZD_OK;
 
+#ifndef MZD_PIPE_PRIO
+#define MZD_PIPE_PRIO 0
+#endif
+    // Issue priority over whatever else shares the CU (k_huf, the persistent k_exec): the chain wavefront's step IS the
+    // kernel's duration, every issue slot it loses to a bulk wavefront is lost for good; the bulk wavefronts have slack.
+    if (MZD_PIPE_PRIO) { if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
     if (wave == 0) {
         // ================= stage A: the serial chain =================
         const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
@@ -1967,7 +1973,7 @@ struct ExecShared {
     int error;
     uint32_t next_tile;  // first tile of the next chunk (written by thread 0)
     uint32_t chunk_end;  // block-relative output position where the current chunk ends
-    uint32_t pad;
+    uint32_t frame;      // persistent form: the frame this workgroup drew from the ticket counter
 };
 
 __device__ __forceinline__ int sel3(uint32_t k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
@@ -2096,7 +2102,8 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
                                                const TileBase *__restrict__ tiles, const uint8_t *__restrict__ litbuf,
-                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap)
+                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap,
+                                               uint32_t n_frames, uint32_t *ticket)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *buf = smem;                                        // cap + 32 bytes
@@ -2104,7 +2111,20 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
     ExecShared *sh = (ExecShared *)(smem + cap + 32 + (cap / 32 + 4) * 4);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-    const DFrame fr = frames[blockIdx.x];
+    // Two launch forms.  ticket == nullptr: one workgroup per frame (frame = blockIdx.x).  Otherwise PERSISTENT: a
+    // fixed number of workgroups per CU, each drawing frames from a ticket counter until the range is used up -- the
+    // form that runs BESIDE k_seq_pipe: no workgroup of this kernel is ever pending, so whatever LDS a finishing
+    // k_seq_pipe workgroup frees goes to the next k_seq_pipe workgroup, never to this kernel.
+    for (;;) {
+    uint32_t fi = blockIdx.x;
+    if (ticket) {
+        __syncthreads();  // everybody is done with the previous frame's shared state
+        if (tid == 0) sh->frame = atomicAdd(ticket, 1u);
+        __syncthreads();
+        fi = sh->frame;
+        if (fi >= n_frames) return;
+    }
+    const DFrame fr = frames[fi];
     uint8_t *out = out_blob + fr.out_offset;
 
     if (tid == 0) sh->error = fr.plan_status;
@@ -2490,9 +2510,11 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
     if (tid == 0) {
         int e = sh->error;
         if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
-        frame_status[blockIdx.x] = e;
-        frame_out_len[blockIdx.x] = outPos;
+        frame_status[fi] = e;
+        frame_out_len[fi] = outPos;
     }
+    if (!ticket) return;
+    }  // persistent form: next frame
 }
 
 

@@ -1,0 +1,559 @@
+// mzd_seq_q4.hip -- k_seq_q4: the FSE sequence decode (structure/sequences.go:126-206) with FOUR LANES PER CHAIN.
+//
+// Why.  What bounds the sequence decode is the step latency of the chain wavefront: LDS capacity fixes the
+// number of chains a CU can hold (their tables), a lone wavefront issues one instruction every ~5-6 cycles
+// whatever its kind, so the number of instructions of a step IS the step (k_seq_pipe: ~66 -> ~460 cycles).
+// A third of them is the same small computation done three times, once per FSE state (cell address, cell
+// read, next / code split, highbit, extra-bit count, state field, new state).  Here the three states of a
+// chain sit in three adjacent LANES, so that computation is issued once, and the sums that couple the
+// states (bits of the extra fields, running sum of the state fields) are five DPP adds inside the quad:
+//   lane 4c + 0: literal-length state   lane 4c + 1: match-length state   lane 4c + 2: offset state
+//   lane 4c + 3: the chain's bit window: it alone reads the bitstream ring (a byte-misaligned 8-byte LDS
+//                read costs the LDS pipe a cycle per ACTIVE lane) and hands the window to stage B.
+// Its own table cell is a constant (next = 1, code 0): zero state bits, zero extra bits -- which is also what
+// row_shr:1 brings into lane 4c + 0 from the quad below, so the running sums need no masks.
+// The window is no longer kept in registers and refilled: every step reads the 8 bytes at its cursor
+// straight from the ring (the read is issued at the end of the step before, behind that step's work).
+// 14 chains per chain wavefront, FOUR chain wavefronts per workgroup (56 chains at most; LDS holds 54),
+// stage B / C / P as in k_seq_pipe (one lane per chain): 7 wavefronts per workgroup.
+//
+// Results are k_seq_pipe's, record for record: same cells (next:10 | c6:6), same escapes, same general
+// step for the rare cases (window too short, stream end, last sequence, escape), same stage C.
+#pragma once
+
+namespace mzd {
+
+constexpr int kQ4ChainsPerWave = 14;  // quads 14 and 15 of a chain wavefront are parked
+constexpr int kQ4ChainWaves = 4;
+constexpr int kQ4Threads = 64 * (kQ4ChainWaves + 3);
+
+struct Q4Shared {
+    uint32_t head1[4];                 // steps produced by each chain wavefront (0xFFFFFFFF: has no chains)
+    uint32_t tail1, head2, tail2, pad0;
+    uint32_t progress[64];             // per chain: byte offset of the window (from in - MZD_IN_PAD), published per batch
+    int32_t stC[64];                   // final status of stage C
+    int32_t stA[64];                   // final status of stage A
+    uint32_t ring_low[64];             // per chain: lowest offset wave P has put in the ring
+    uint64_t q1w[kPipeDepth][64];      // mode 0: the 8 bytes at the cursor; mode 1: LL:17 | ML:18 | offset value:29
+    uint16_t q1c[kPipeDepth][64][4];   // mode 0: LL cell, ML cell, OF cell, bits consumed of q1w (0..7); mode 1: [3] = 0x8000
+    uint64_t q2[kPipeDepth][64];
+    uint8_t ring[kQ4ChainWaves * kQ4ChainsPerWave][kPipeRing + 8];
+    uint16_t dummy[8];                 // dummy[1] = 1: the cell of parked lanes and of every quad's fourth lane
+};
+constexpr int kQ4FixedLds = (512 + (int)sizeof(Q4Shared) + 15) & ~15;
+constexpr int kQ4MaxChains = (160 * 1024 - kQ4FixedLds) / (kSeqCellsPerChain * 2);
+static_assert(kQ4MaxChains >= 54 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v)  // quad_perm, all rows and banks, out-of-range lanes read 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+
+__global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
+                                                       uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
+                                                       uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
+                                                       BlockSum *sums, uint32_t nch, uint64_t in_base)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *CTc = (uint32_t *)smem;  // [2][64] by c6: base(24) | extra(8)   (predefined.go:5-20,36-50)
+    Q4Shared *shs = (Q4Shared *)(smem + 512);
+    uint16_t *cells = (uint16_t *)(smem + kQ4FixedLds);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4: B; 5: C; 6: P
+    const bool chainw = wave < kQ4ChainWaves;
+    // the chain this lane works for: chain wavefronts 4 lanes per chain, the others one lane per chain
+    const uint32_t quad = (uint32_t)lane >> 2, role = (uint32_t)lane & 3u;
+    // (quads 14 and 15 of a chain wavefront have no chain: they are parked and write their queue entries to slot 63,
+    // which no workgroup uses: nch <= kQ4MaxChains)
+    const uint32_t ch = chainw ? (quad < (uint32_t)kQ4ChainsPerWave ? (uint32_t)wave * kQ4ChainsPerWave + quad : 63u) : (uint32_t)lane;
+    const uint32_t tid = blockIdx.x * nch + ch;
+    const bool has = ch < nch && tid < n_tasks;
+    SeqTask t;
+    if (has) {
+        t = tasks[tid];
+        t.in_off -= in_base;  // the launch's window of the blob: bitstreams are addressed with 32-bit offsets from it
+    } else {
+        t.n_seq = 0; t.in_size = 0; t.ll_off = t.of_off = t.ml_off = 0; t.ll_log = t.of_log = t.ml_log = 0;
+        t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
+    }
+    in += in_base;
+    if (wave == 6) {
+        CTc[lane] = 0;
+        CTc[64 + lane] = 0;
+        shs->progress[lane] = (uint32_t)t.in_off + MZD_IN_PAD + t.in_size;
+        shs->ring_low[lane] = (has && t.n_seq > 0) ? 0xFFFFFFFFu : 0u;  // nothing in the ring yet / nothing needed
+        shs->stC[lane] = MZD_OK;
+        shs->stA[lane] = MZD_OK;
+        if (lane < 8) shs->dummy[lane] = 1;
+        if (lane == 0) { shs->tail1 = 0; shs->head2 = 0; shs->tail2 = 0; }
+        // a chain wavefront without chains never produces anything: nobody waits for it
+        if (lane < 4) shs->head1[lane] = (uint32_t)lane * kQ4ChainsPerWave < min(nch, n_tasks - blockIdx.x * nch) ? 0u : 0xFFFFFFFFu;
+        __builtin_amdgcn_s_waitcnt(0);  // the zero fill above before the scattered fill below (same wavefront: LDS is in order)
+        if (lane < 36 && seq_code6(0, lane) != kPipeEscape) CTc[seq_code6(0, lane)] = c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24);
+        if (lane < 53 && seq_code6(1, lane) != kPipeEscape) CTc[64 + seq_code6(1, lane)] = c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24);
+    }
+    // ---- stage the three tables of every chain of this workgroup (as k_seq_pipe: one flat loop, 8 loads in flight)
+    {
+        uint32_t *desc = (uint32_t *)&shs->q1w[0][0];  // [chain][4]: ll_off, ml_off, of_off, logs
+        if (wave == 4) {
+            desc[4 * lane + 0] = t.ll_off;
+            desc[4 * lane + 1] = t.ml_off;
+            desc[4 * lane + 2] = t.of_off;
+            desc[4 * lane + 3] = has ? ((uint32_t)t.ll_log | ((uint32_t)t.ml_log << 8) | ((uint32_t)t.of_log << 16)) : 0x00FFFFFFu;
+        }
+        __syncthreads();
+        const uint32_t ncell = min(nch, n_tasks - blockIdx.x * nch) * kSeqCellsPerChain;
+        constexpr int UNR = 8;
+        for (uint32_t idx0 = threadIdx.x; idx0 < ncell; idx0 += kQ4Threads * UNR) {
+            uint32_t e[UNR], n[UNR], c6k[UNR];
+            bool ok[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const uint32_t idx = idx0 + kQ4Threads * u;
+                const uint32_t c = idx / kSeqCellsPerChain, r = idx - c * kSeqCellsPerChain;
+                const uint32_t kind = r >= 1024 ? 2u : (r >> 9);
+                const uint32_t i = r - (kind << 9);
+                const uint32_t lg = (desc[4 * min(c, 63u) + 3] >> (8 * kind)) & 0xFF;
+                n[u] = 1u << (lg & 31);
+                ok[u] = idx < ncell && lg <= 9 && i < n[u];
+                c6k[u] = kind;
+                e[u] = ok[u] ? fse_entries[desc[4 * min(c, 63u) + kind] + i] : 0u;  // baseline(16) | nbits(8) | symbol(8)
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const uint32_t baseline = e[u] & 0xFFFF, nb = (e[u] >> 16) & 0xFF, sym = e[u] >> 24;
+                const uint32_t c6 = c6k[u] == 2 ? sym : seq_code6((int)c6k[u], sym);
+                if (ok[u])
+                    cells[idx0 + kQ4Threads * u] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n[u]) >> (nb & 31)) | (c6 << 10));
+            }
+        }
+    }
+    __syncthreads();
+
+    // trip count of every stage: the longest chain of the workgroup (the q2 descriptors are gone: ask every lane of B)
+    uint32_t nmax;
+    {
+        uint32_t *nm = (uint32_t *)&shs->q2[0][0];
+        if (wave == 4) {
+            const uint32_t m = wave_max_u32(has ? t.n_seq : 0u);
+            if (lane == 0) nm[0] = m;
+        }
+        __syncthreads();
+        nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nm[0]);
+        __syncthreads();
+    }
+
+    if (chainw) {
+        // ================= stage A: four lanes per chain =================
+        const uint8_t *inb = in - MZD_IN_PAD;
+        const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
+        const uint32_t sizeL = 1u << alL, sizeM = 1u << alM, sizeO = 1u << alO;
+        const uint32_t slot = ch * kSeqCellsPerChain;
+        const bool spare = role == 3;
+        const uint32_t dummy_addr = 512u + (uint32_t)offsetof(Q4Shared, dummy);  // byte address of dummy[0]; dummy[1] is the cell
+        // ---- per chain (its fourth lane): padding, initial states in the order LL, OF, ML (sequences.go:133-159)
+        uint64_t C = 0, D = 0;
+        uint32_t off = 0;  // general step only: offset of D's bytes
+        int k = 0, rem = 0;
+        int status = MZD_OK;
+        auto refill = [&]() {
+            const int nb = k >> 3, sh = nb * 8;
+            C = (C << sh) | ((D >> 1) >> (63 - sh));
+            off -= (uint32_t)nb;
+            k &= 7;
+            asm volatile("" ::"v"((uint32_t)C), "v"((uint32_t)(C >> 32)) : "memory");  // see SeqBits::refill
+            D = ld64u(inb + off);
+        };
+        auto peek = [&](int n) -> uint32_t { return (uint32_t)(((C << k) >> 1) >> (63 - n)); };
+        uint32_t sL = 0, sM = 0, sO = 0;
+        bool live = has && t.n_seq > 0;
+        if (live && spare) {
+            SeqBits br;
+            rem = br.init(in + t.in_off, (int)t.in_size);
+            C = br.C; D = br.D; k = br.k; off = (uint32_t)(br.pd - inb);
+            if (rem < 0) {
+                status = MZD_ERR_BAD_PADDING;  // sequences.go:141-143
+            } else {
+                sL = peek(alL); k += alL;
+                sO = peek(alO); k += alO;
+                refill();
+                sM = peek(alM); k += alM;
+                rem -= alL + alO + alM;
+                if (rem < 0) status = MZD_ERR_SEQ_BITS;
+            }
+        }
+        // the hot loop's view of the cursor: woff = offset of the 8 bytes that hold the next bit (bit 63 - wk of them)
+        uint32_t woff = off + 8u;
+        uint32_t wk = (uint32_t)k;
+        uint32_t rem1 = (uint32_t)rem + 1u;
+        uint32_t last_i = t.n_seq - 1;
+        live = live && (bool)__shfl((int)(status == MZD_OK), lane | 3, 64);
+        // ---- hand the chain's state to its four lanes
+        auto from_spare = [&](uint32_t v) -> uint32_t { return (uint32_t)__shfl((int)v, lane | 3, 64); };
+        uint32_t st;  // this lane's FSE state, pre-biased by the table size
+        uint32_t cb, shr, Kc, nbK;
+        {
+            const uint32_t l = from_spare(sL) + sizeL, m = from_spare(sM) + sizeM, o = from_spare(sO) + sizeO;
+            st = role == 0 ? l : (role == 1 ? m : (role == 2 ? o : 1u));
+            const uint32_t base = (uint32_t)kQ4FixedLds;
+            cb = role == 0 ? base + 2u * (slot - sizeL)
+                           : (role == 1 ? base + 2u * (slot + 512 - sizeM) : (role == 2 ? base + 2u * (slot + 1024 - sizeO) : dummy_addr));
+            shr = role == 2 ? 10u : 12u;
+            Kc = role == 0 ? 3u : (role == 1 ? 7u : 0u);
+            nbK = role == 0 ? 31u - (uint32_t)alL : (role == 1 ? 31u - (uint32_t)alM : (role == 2 ? 31u - (uint32_t)alO : 31u));
+            woff = from_spare(woff);
+            wk = from_spare(wk);
+            rem1 = from_spare(rem1);
+        }
+        uint32_t left = last_i;  // steps before the chain's last sequence
+        auto park = [&]() {  // the whole quad: constant cell, cursor 0 (the readable front slack; the ring check is always true for it)
+            st = 1; cb = dummy_addr; nbK = 31; woff = 0; wk = 0; rem1 = 0x7FFFFFFFu; left = 0x7FFFFFFFu; live = false;
+        };
+        if (!live) park();
+        const uint32_t ringl = 512u + (uint32_t)offsetof(Q4Shared, ring) + ch * (kPipeRing + 8);
+        uint16_t *q1c_lane = &shs->q1c[0][min(ch, 63u)][role];
+        uint64_t *q1w_chain = &shs->q1w[0][min(ch, 63u)];
+
+        uint32_t tail_seen = 0;
+        auto wait_space = [&](uint32_t at) {  // slot of step `at` is free once at - tail1 < depth
+            while (at - tail_seen >= (uint32_t)kPipeDepth) {
+                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->tail1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (at - tail_seen >= (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
+            }
+        };
+        // (symbol, next, base | extra << 24) of a literal-length / match-length cell, escape or not
+        auto full_cell = [&](int kind, uint32_t x, uint32_t idx, uint32_t toff, uint32_t size, uint32_t &next, uint32_t &ct) {
+            next = x & 1023;
+            ct = CTc[kind * 64 + (x >> 10)];
+            if (next == 0) {  // escape: the symbol is only in the host cell
+                const uint32_t e = fse_entries[toff + idx];
+                const uint32_t sym = e >> 24;
+                next = ((e & 0xFFFF) + size) >> ((e >> 16) & 0xFF);
+                ct = kind == 0 ? (c_ll_base[min(sym, 35u)] | ((uint32_t)c_ll_extra[min(sym, 35u)] << 24))
+                               : (c_ml_base[min(sym, 52u)] | ((uint32_t)c_ml_extra[min(sym, 52u)] << 24));
+            }
+        };
+        const uint16_t *cL = cells + slot - sizeL;
+        const uint16_t *cM = cells + slot + 512 - sizeM;
+        const uint16_t *cO = cells + slot + 1024 - sizeO;
+        // General step of sequence `idx` for the chains in `mine` (their queue entries of this step are rewritten as
+        // mode 1), run by the chain's fourth lane on the chain's three states, as k_seq_pipe's.
+        auto general_step = [&](uint32_t idx, bool mine) {
+            const uint32_t b0 = (uint32_t)lane & ~3u;
+            uint32_t gL = (uint32_t)__shfl((int)st, b0, 64), gM = (uint32_t)__shfl((int)st, b0 + 1, 64), gO = (uint32_t)__shfl((int)st, b0 + 2, 64);
+            bool parkq = false;
+            if (mine && spare) {
+                const bool lastseq = idx == last_i;
+                // the window as the general step keeps it: C = the 8 bytes at the cursor, D = the 8 below
+                off = woff - 8u;
+                k = (int)wk;
+                C = ld64u(inb + woff);
+                D = ld64u(inb + off);
+                const uint32_t xl = cL[gL], xm = cM[gM], xo = cO[gO];
+                uint32_t nl = 1, nm = 1, cl = 0, cm = 0;
+                full_cell(0, xl, gL - sizeL, t.ll_off, sizeL, nl, cl);
+                full_cell(1, xm, gM - sizeM, t.ml_off, sizeM, nm, cm);
+                const uint32_t no = xo & 1023, exO = xo >> 10;
+                uint32_t nbL = (uint32_t)(alL - 31) + (uint32_t)__builtin_clz(nl | 1);
+                uint32_t nbM = (uint32_t)(alM - 31) + (uint32_t)__builtin_clz(nm | 1);
+                uint32_t nbO = (uint32_t)(alO - 31) + (uint32_t)__builtin_clz(no | 1);
+                if (lastseq) { nbL = 0; nbM = 0; nbO = 0; }  // sequences.go:178
+                const uint32_t exL = cl >> 24, exM = cm >> 24;
+                const int total = (int)(exO + exM + exL + nbL + nbM + nbO);
+                int remi = (int)(rem1 - 1u);
+                bool ok = true;
+                if (total > remi) {  // the cursor would pass the start of the stream
+                    status = MZD_ERR_SEQ_BITS;
+                    ok = false;
+                }
+                if (ok) {
+                    const uint32_t ofx = peek((int)exO); k += (int)exO; refill();
+                    const uint32_t mlx = peek((int)exM); k += (int)exM;
+                    const uint32_t llx = peek((int)exL); k += (int)exL; refill();
+                    const uint32_t aL = peek((int)nbL); k += (int)nbL;
+                    const uint32_t aM = peek((int)nbM); k += (int)nbM;
+                    const uint32_t aO = peek((int)nbO); k += (int)nbO;
+                    remi -= total;
+                    gL = (nl << nbL) + aL; gM = (nm << nbM) + aM; gO = (no << nbO) + aO;  // fse.go:282-290
+                    const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
+                    shs->q1w[idx % kPipeDepth][ch] = (uint64_t)((cl & 0xFFFFFF) + llx) |
+                                                     ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                                     ((uint64_t)ofv << kRecOffShift);
+                    shs->q1c[idx % kPipeDepth][ch][3] = 0x8000u;
+                    woff = off + 8u;
+                    wk = (uint32_t)k;
+                    rem1 = (uint32_t)remi + 1u;
+                }
+                if (lastseq || !ok) {
+                    if (ok && remi != 0) status = MZD_ERR_SEQ_BITS;  // sequences.go:197-204
+                    parkq = true;
+                }
+            }
+            // back to the chain's four lanes (the cursor normalised: wk < 8)
+            const bool minech = (bool)__shfl((int)(mine && spare), lane | 3, 64);
+            const uint32_t nL = from_spare(gL), nM = from_spare(gM), nO = from_spare(gO);
+            const uint32_t nwoff = from_spare(woff), nwk = from_spare(wk), nrem1 = from_spare(rem1);
+            if (minech) {
+                st = role == 0 ? nL : (role == 1 ? nM : (role == 2 ? nO : 1u));
+                woff = nwoff - (nwk >> 3);
+                wk = nwk & 7u;
+                rem1 = nrem1;
+            }
+            if ((bool)__shfl((int)parkq, lane | 3, 64)) park();
+        };
+
+        // ---- the hot loop (C++ statement of the step; the cursor is normalised at the END of a step: wk < 8)
+        uint32_t i = 0;
+        {
+            const uint32_t nb = wk >> 3;
+            woff -= nb;
+            wk &= 7;
+        }
+        while (i < nmax) {
+            uint64_t smask = 0;
+            bool entry = true;  // (re-)entering the loop: a general step may have moved the cursor by more than a hot step
+            do {
+                wait_space(i);
+                if ((i & 3) == 0 || entry) {
+                    entry = false;
+                    // cursor to wave P; the ring must reach 40 bytes below it (a batch of four steps reads at most 32 + 8)
+                    if (role == 3) shs->progress[min(ch, 63u)] = woff;
+                    for (;;) {
+                        const uint32_t rl = __hip_atomic_load(&shs->ring_low[min(ch, 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!__any(rl > woff - 40u)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const uint32_t x = *(const uint16_t *)(smem + cb + 2u * st);
+                uint64_t W = 0;
+                if (spare) W = ((const U64U *)(smem + ringl + (woff & (kPipeRing - 1))))->v;
+                const uint32_t Wlo = dpp_quad<QP(3, 3, 3, 3)>((uint32_t)W), Whi = dpp_quad<QP(3, 3, 3, 3)>((uint32_t)(W >> 32));
+                const uint32_t c = x >> shr, n = x & 0x3ffu;
+                const uint32_t ex = sub_sat(c, Kc);
+                // escape: next = 0 -> ffbh = 0xFFFFFFFF; capped at 2^26 so that the sums below cannot wrap back into
+                // the range of a valid step (three escapes + every other term stay below 2^32 and above any limit)
+                const uint32_t nb = min(ffbh_raw(n), 1u << 26) - nbK;
+                const uint32_t t1 = ex + dpp_quad<QP(1, 0, 3, 2)>(ex);
+                const uint32_t o3 = t1 + dpp_quad<QP(2, 3, 0, 1)>(t1);
+                const uint32_t a1 = nb + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nb, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+                const uint32_t P = a1 + dpp_quad<QP(3, 3, 0, 3)>(nb);
+                const uint32_t tot = dpp_quad<QP(2, 2, 2, 2)>(P) + o3;
+                const uint32_t lim = min(min(64u - wk, rem1), left);
+                const bool go = tot < lim;
+                const uint64_t Wq = (uint64_t)Wlo | ((uint64_t)Whi << 32);
+                const uint32_t Xhi = (uint32_t)((Wq << ((wk + o3) & 63)) >> 32);
+                const uint32_t fld = __builtin_amdgcn_ubfe(Xhi, (0u - P) & 31u, nb & 31u);
+                const uint32_t snew = (n << (nb & 31u)) + fld;
+                q1c_lane[(i % kPipeDepth) * 64 * 4] = (uint16_t)(spare ? wk : x);
+                if (spare) q1w_chain[(i % kPipeDepth) * 64] = Wq;
+                const uint32_t adv = go ? tot : 0u;
+                st = go ? snew : st;
+                wk += adv;
+                rem1 -= adv;
+                left -= 1u;
+                woff -= wk >> 3;
+                wk &= 7;
+                smask = __builtin_amdgcn_ballot_w64(!go);
+                i++;
+                if (!smask) {
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } while (i < nmax && !smask);
+            // i has moved past the step; chains in smask have not done it yet (their `left` has been counted down: undo)
+            if (smask) {
+                const bool mine = ((smask >> lane) & 1) != 0;
+                if (mine) left += 1u;
+                general_step(i - 1, mine);
+                if (mine && live) left -= 1u;
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (spare && has && t.n_seq > 0) shs->stA[ch] = status;
+    } else if (wave == 4) {
+        // ================= stage B: field extraction and values, four steps at a time =================
+        uint32_t head_seen = 0, tail_seen = 0;
+        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+            const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+            while (head_seen < need) {
+                const uint32_t h0 = __hip_atomic_load(&shs->head1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t h1 = __hip_atomic_load(&shs->head1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t h2 = __hip_atomic_load(&shs->head1[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t h3 = __hip_atomic_load(&shs->head1[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                head_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(min(h0, h1), min(h2, h3)));
+                if (head_seen < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            uint64_t T[kPipeBatch], Cq[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) {
+                T[u] = shs->q1w[(j0 + u) % kPipeDepth][lane];
+                Cq[u] = *(const uint64_t *)&shs->q1c[(j0 + u) % kPipeDepth][lane][0];
+            }
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->tail1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint64_t q[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) {
+                const uint32_t xl = (uint32_t)Cq[u] & 0xFFFF, xm = (uint32_t)(Cq[u] >> 16) & 0xFFFF, xo = (uint32_t)(Cq[u] >> 32) & 0xFFFF;
+                const uint32_t kk = (uint32_t)(Cq[u] >> 48);
+                const uint32_t cl = CTc[xl >> 10];
+                const uint32_t cm = CTc[64 + (xm >> 10)];
+                const uint32_t exO = xo >> 10;
+                const uint64_t Tw = T[u] << (kk & 7u);
+                const uint32_t hi = (uint32_t)(Tw >> 32);
+                const uint32_t exL = cl >> 24, exM = cm >> 24;
+                const uint32_t ofx = __builtin_amdgcn_ubfe(hi, 32u - exO, exO);
+                const uint32_t Y = (uint32_t)((Tw << exO) >> 32);
+                const uint32_t mlx = __builtin_amdgcn_ubfe(Y, 32u - exM, exM);
+                const uint32_t llx = __builtin_amdgcn_ubfe(Y, 32u - exM - exL, exL);
+                const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
+                const uint64_t v = (uint64_t)((cl & 0xFFFFFF) + llx) | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                   ((uint64_t)ofv << kRecOffShift);
+                q[u] = (kk & 0x8000u) ? T[u] : v;
+            }
+            while (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) {
+                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->tail2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][lane] = q[u];
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->head2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (wave == 5) {
+        // ================= stage C: sums, offset history, records (as k_seq_pipe) =================
+        int h0, h1, h2;
+        if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
+        else { h0 = -1; h1 = -2; h2 = -3; }
+        uint32_t litPos = 0, outPos = 0;
+        uint32_t err_unsup = 0, err_off = 0, err_size = 0;
+        uint64_t *myrec = recs + t.rec_off;
+        TileBase *mytile = tiles + t.tile_off;
+        const uint32_t my_n = has ? t.n_seq : 0u;
+        uint32_t head_seen = 0;
+        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+            const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+            while (head_seen < need) {
+                head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->head2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head_seen < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            uint64_t q[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][lane];
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
+            uint64_t rr[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) {
+                const uint32_t j = j0 + u;
+                const bool act = j < my_n;
+                const uint32_t lo = (uint32_t)q[u], hi = (uint32_t)(q[u] >> 32);
+                const uint32_t LL = lo & kRecLlMask;
+                const uint32_t ML = __builtin_amdgcn_alignbit(hi, lo, kRecMlShift) & kRecMlMask;
+                const uint32_t ofv = hi >> (kRecOffShift - 32);
+                // 0 = not active (history untouched), 1..4 = repeat cases 0..3, 5 = new offset
+                uint32_t idx = ofv > 3 ? 5u : ofv + (LL == 0 ? 1u : 0u);
+                idx = act ? idx : 0u;
+                int off = (int)(ofv - 3);                 // idx 5
+                off = idx == 4 ? hist_dec(h0) : off;      // sequence_execution.go:65-114
+                off = idx == 3 ? h2 : off;
+                off = idx == 2 ? h1 : off;
+                off = idx <= 1 ? h0 : off;
+                h2 = idx >= 3 ? h1 : h2;
+                h1 = idx >= 2 ? h0 : h1;
+                h0 = idx >= 2 ? off : h0;
+                err_unsup |= act && ofv >= kRecOffSymbolic;  // offset value >= 2^28
+                err_off |= act && off == 0;
+                litPos += act ? LL : 0u;
+                outPos += act ? LL + ML : 0u;
+                err_size |= outPos > kBlockMax;  // a block regenerates <= 128 KiB
+                const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
+                rr[u] = (uint64_t)lo | ((uint64_t)((hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32))) << 32);
+            }
+            if (j0 + (uint32_t)kPipeBatch <= my_n) {
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+                *(u64x2 *)(myrec + j0) = u64x2{rr[0], rr[1]};
+                *(u64x2 *)(myrec + j0 + 2) = u64x2{rr[2], rr[3]};
+            } else {
+#pragma unroll
+                for (int u = 0; u < kPipeBatch; u++)
+                    if (j0 + u < my_n) myrec[j0 + u] = rr[u];
+            }
+        }
+        const int status = err_unsup ? MZD_ERR_UNSUPPORTED : (err_off ? MZD_ERR_OFFSET : (err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK));
+        if (has && t.n_seq > 0) {
+            BlockSum *bs = &sums[t.block];
+            bs->lit_total = litPos;
+            bs->out_total = outPos;
+            bs->hist[0] = h0;
+            bs->hist[1] = h1;
+            bs->hist[2] = h2;
+        }
+        shs->stC[lane] = status;
+    } else {
+        // ================= wave P: the chains' bitstreams, ahead of stage A (as k_seq_pipe) =================
+        const uint8_t *inb = in - MZD_IN_PAD;
+        const uint8_t *sbase = in + t.in_off;
+        const bool work = has && t.n_seq > 0;
+        int low = (int)t.in_size;  // prefetch touches: everything at or above `low` has been requested
+        constexpr int kAhead = MZD_PIPE_AHEAD, kLine = 128;
+        uint32_t rlow = ((uint32_t)t.in_off + MZD_IN_PAD + t.in_size + 31u) & ~31u;  // ring: nothing yet
+        uint8_t *ring = shs->ring[lane];
+        uint32_t iter = 0;
+        for (;;) {
+            const uint32_t h0 = __hip_atomic_load(&shs->head1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t h1 = __hip_atomic_load(&shs->head1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t h2 = __hip_atomic_load(&shs->head1[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t h3 = __hip_atomic_load(&shs->head1[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(min(h0, h1), min(h2, h3)));
+            // the chain's window offset; stage A reads the 8 bytes AT it (k_seq_pipe's stage A read the 8 bytes at its
+            // refill offset = 8 below its window: the same protocol with the same numbers)
+            const uint32_t raw = __hip_atomic_load(&shs->progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int cur = (int)(raw - ((uint32_t)t.in_off + MZD_IN_PAD));
+            const bool inside = cur >= -56 && cur <= (int)t.in_size;
+            if (work && inside) {
+                for (int g = 0; g < 4 && raw <= rlow + 88u && rlow >= 32u; g++) {
+                    const uint32_t u = rlow - 32u;
+                    const uint64_t w0 = ld64u(inb + u), w1 = ld64u(inb + u + 8), w2 = ld64u(inb + u + 16), w3 = ld64u(inb + u + 24);
+                    uint64_t *d = (uint64_t *)(ring + (u & (kPipeRing - 1)));
+                    d[0] = w0; d[1] = w1; d[2] = w2; d[3] = w3;
+                    if ((u & (kPipeRing - 1)) == 0) *(uint64_t *)(ring + kPipeRing) = w0;
+                    rlow = u;
+                }
+                asm volatile("" ::: "memory");
+                __hip_atomic_store(&shs->ring_low[lane], rlow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(&shs->ring_low[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            {
+                const int target = inside ? max(cur - kAhead, 0) : low;
+                for (int g = 0; g < MZD_PIPE_TOUCHES && has && low > target && (iter & MZD_PIPE_TOUCH_EVERY) == 0; g++) {
+                    low = max(low - kLine, 0);
+                    touch_line(sbase + (low & ~3));
+                }
+            }
+            if (hd >= nmax) break;
+            iter++;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    // decode-stage errors come first, as in the reference, where DecodeSequences runs to its end
+    // before ExecuteSequences starts
+    if (wave == 5 && has && t.n_seq > 0) {
+        int st = shs->stA[lane];
+        if (st == MZD_OK) st = shs->stC[lane];
+        if (st != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, st);
+    }
+}
+
+}  // namespace mzd
