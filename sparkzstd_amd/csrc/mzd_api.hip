@@ -1366,6 +1366,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     return MZD_OK;
 }
 
+#ifdef MZD_Q4_STATS
+extern "C" int mzd_debug_q4_stats(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_q4_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_q4_stats), z, sizeof z); }
+    return 0;
+}
+#endif
 #ifdef MZD_HUF_SEG_STATS
 extern "C" int mzd_debug_huf_seg_stats(unsigned long long *out, int reset)
 {

@@ -44,6 +44,9 @@ constexpr int kQ4FixedLds = (512 + (int)sizeof(Q4Shared) + 15) & ~15;
 constexpr int kQ4MaxChains = (160 * 1024 - kQ4FixedLds) / (kSeqCellsPerChain * 2);
 static_assert(kQ4MaxChains >= 54 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
 
+#ifdef MZD_Q4_STATS
+__device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps
+#endif
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_quad(uint32_t v)  // quad_perm, all rows and banks, out-of-range lanes read 0
 {
@@ -305,15 +308,27 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             if ((bool)__shfl((int)parkq, lane | 3, 64)) park();
         };
 
-        // ---- the hot loop (C++ statement of the step; the cursor is normalised at the END of a step: wk < 8)
+        // ---- the hot loop.  The cursor is normalised at the END of a step (wk < 8 on entry).  Runs steps until a chain
+        // needs the general step (returns the mask of its lanes; its step is NOT done, everybody's queue entry IS
+        // written, head1 not yet moved) or nmax is reached.
         uint32_t i = 0;
         {
             const uint32_t nb = wk >> 3;
             woff -= nb;
             wk &= 7;
         }
+        const uint64_t sparemask = 0x8888888888888888ull;
+        const uint32_t vzero = 0;
+        const uint32_t qca = (min(ch, 63u) * 4u + role) * 2u, qwa = min(ch, 63u) * 8u, chan4 = min(ch, 63u) * 4u;
+        const uint32_t heada = 512u + (uint32_t)offsetof(Q4Shared, head1) + 4u * (uint32_t)wave;
+        uint32_t polls = 0;
+#ifdef MZD_Q4_STATS
+        const long long stats_t0 = clock64();
+        uint32_t n_general = 0;
+#endif
         while (i < nmax) {
             uint64_t smask = 0;
+#ifdef MZD_Q4_CXX_STEP
             bool entry = true;  // (re-)entering the loop: a general step may have moved the cursor by more than a hot step
             do {
                 wait_space(i);
@@ -363,9 +378,196 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } while (i < nmax && !smask);
+#else
+            {
+                // The same step, hand-scheduled (~43 instructions; k_seq_pipe's: ~66).  The loop body is the step EIGHT times,
+                // one instance per queue slot, as in k_seq_pipe: slot addresses are immediates, queue space / the ring / the
+                // cursor for wave P are dealt with once per batch of four steps, head1 is published and nmax checked at the
+                // end of a batch.  DPP reads of a VGPR keep two instructions' distance from the VALU write of it (the
+                // hardware does not interlock that; nothing inside an asm statement is padded by the compiler).
+                // Temporaries are fixed registers v200..v236 / s86.
+                static_assert(kPipeDepth == 8 && kPipeBatch == 4 && kPipeRing == 128, "the unrolled loop assumes 2 batches of 4 slots, a 128-byte ring");
+                uint32_t stb = st;  // the states alternate between two register sets
+                // (wave-uniform by construction; said explicitly, or the "s" operands below are refused)
+                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_seen);
+                polls = (uint32_t)__builtin_amdgcn_readfirstlane((int)polls);
+#define Q4_RINGCHK(TAG)                                                                                     \
+    "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n"                                                      \
+    "L_q4_ring" TAG "_%=:\n\t"                                                                              \
+    "ds_read_b32 v200, %[chan4] offset:%[o_rlow]\n\t"                                                       \
+    "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_cmp_gt_u32 vcc, v200, v201\n\t"                                                                      \
+    "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
+    "s_add_u32 %[polls], %[polls], 0x10000\n\t"                                                             \
+    "s_sleep 1\n\t"                                                                                         \
+    "s_branch L_q4_ring" TAG "_%=\n"
+#define Q4_CHECK(TAG)                                                                                       \
+    "L_q4_top" TAG "_%=:\n\t"                                                                               \
+    "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
+    "s_cmp_lt_u32 s86, 5\n\t" /* i + 3 - tail1 < depth */                                                   \
+    "s_cbranch_scc1 L_q4_spc" TAG "_%=\n"                                                                   \
+    "L_q4_poll" TAG "_%=:\n\t"                                                                              \
+    "ds_read_b32 v200, %[vzero] offset:%[o_tail1]\n\t"                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_readfirstlane_b32 %[tail], v200\n\t"                                                                 \
+    "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
+    "s_cmp_lt_u32 s86, 5\n\t"                                                                               \
+    "s_cbranch_scc1 L_q4_spc" TAG "_%=\n\t"                                                                 \
+    "s_add_u32 %[polls], %[polls], 1\n\t"                                                                   \
+    "s_sleep 1\n\t"                                                                                         \
+    "s_branch L_q4_poll" TAG "_%=\n"                                                                        \
+    "L_q4_spc" TAG "_%=:\n\t"                                                                               \
+    /* fast path: ring_low as read during the previous step (v236; it only ever decreases) */               \
+    "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_cmp_gt_u32 vcc, v236, v201\n\t"                                                                      \
+    "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n\t"                                                    \
+    "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
+    Q4_RINGCHK(TAG)
+// DMl/DMh: the 8 bytes at the cursor, read by the fourth lane at the end of the step before; DL: where the next step's go
+#define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW)                                               \
+    "L_q4_go" TAG "_%=:\n\t"                                                                                \
+    "v_lshl_add_u32 v200, %[s" SA "], 1, %[cb]\n\t"                                                         \
+    "ds_read_u16 v203, v200\n\t"                    /* the lane's cell */                                   \
+    "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
+    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t"   /* limit = min(64 - k, rem + 1, steps before the last) */ \
+    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
+    "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+    "v_lshrrev_b32 v215, %[shr], v203\n\t"          /* code field */                                        \
+    "v_and_b32 v217, 0x3ff, v203\n\t"               /* next */                                              \
+    "v_mov_b32_dpp v210, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_ffbh_u32 v220, v217\n\t"                                                                             \
+    "v_sub_u32_e64 v215, v215, %[Kc] clamp\n\t"     /* ex */                                                \
+    "v_mov_b32_dpp v211, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_min_u32 v220, 0x4000000, v220\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
+    "v_cndmask_b32_e64 v231, v203, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
+    "v_sub_u32 v220, v220, %[nbK]\n\t"              /* nb */                                                \
+    "v_add_u32_dpp v221, v215, v215 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+    "ds_write_b16 %[qca], v231 offset:" QC "\n\t"                                                           \
+    "v_sub_u32 v229, 0, %[k]\n\t"                   /* (filler with a use: -k) */                           \
+    "v_add_u32_dpp v222, v220, v220 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
+    "v_add_u32_dpp v223, v221, v221 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
+    "v_add_u32_dpp v224, v220, v222 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
+    "v_sub_u32 v229, v223, v229\n\t"                /* k + o3 */                                            \
+    "v_sub_u32 v225, 0, v224\n\t"                   /* -P */                                                \
+    "v_lshlrev_b64 v[212:213], v229, v[210:211]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
+    "v_add_u32_dpp v230, v224, v223 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
+    "v_bfe_u32 v226, v213, v225, v220\n\t"          /* the lane's state field */                            \
+    "v_cmp_lt_u32 vcc, v230, v228\n\t"              /* go (the same in the four lanes of a chain) */        \
+    "v_lshl_add_u32 %[s" SB "], v217, v220, v226\n\t" /* new state, in the OTHER register set */            \
+    "v_cndmask_b32 v230, 0, v230, vcc\n\t"                                                                  \
+    "v_sub_u32 %[rem1], %[rem1], v230\n\t"                                                                  \
+    "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
+    "v_lshrrev_b32 v207, 3, %[k]\n\t"               /* normalise the cursor for the next step */            \
+    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
+    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
+    "v_and_b32 v209, 127, %[off]\n\t"                                                                       \
+    "v_add_u32 v209, v209, %[ringl]\n\t"                                                                    \
+    RLOW                                                                                                    \
+    "s_andn2_b64 %[smask], exec, vcc\n\t"           /* chains that need the general step; SCC = any */      \
+    "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
+    "ds_write_b64 %[qwa], v[210:211] offset:" QW "\n\t" /* this step's window for stage B */                \
+    "ds_read_b64 " DL ", v209\n\t"                  /* the next step's window */                            \
+    "s_mov_b64 exec, -1\n\t"                                                                                \
+    "s_cbranch_scc1 " OUT "\n\t"
+#define Q4_PUBLISH(OUT)                                                                                     \
+    "v_mov_b32 v202, %[i]\n\t"                                                                              \
+    "ds_write_b32 %[heada], v202\n\t"                                                                       \
+    "s_cmp_lt_u32 %[i], %[nmax]\n\t"                                                                        \
+    "s_cbranch_scc0 " OUT "\n\t"
+#define Q4_OUTE "L_q4_oute_%="
+#define Q4_OUTO "L_q4_outo_%="
+#define Q4_RLOW "ds_read_b32 v236, %[chan4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
+#define Q4_A "v232", "v233", "v[232:233]"
+#define Q4_B "v234", "v235", "v[234:235]"
+                asm volatile(
+                    // prologue: the window at the cursor into both pairs (fourth lanes), the entry's ring check, then the
+                    // instance of slot i % 8
+                    "v_and_b32 v209, 127, %[off]\n\t"
+                    "v_add_u32 v209, v209, %[ringl]\n\t"
+                    "v_mov_b32 v236, -1\n\t"  // no ring_low read ahead yet: the first batch check takes the slow path
+                    // the ring must hold the bytes at the cursor BEFORE they are read here (the very first entry: wave P may
+                    // not have filled anything yet; after a general step: the cursor has moved by more than a hot step)
+                    Q4_RINGCHK("e")
+                    "L_q4_goe_%=:\n\t"
+                    "s_mov_b64 exec, %[spare]\n\t"
+                    "ds_read_b64 v[232:233], v209\n\t"
+                    "ds_read_b64 v[234:235], v209\n\t"
+                    "s_mov_b64 exec, -1\n\t"
+                    "s_and_b32 s86, %[i], 7\n\t"
+                    "s_cmp_eq_u32 s86, 0\n\t"
+                    "s_cbranch_scc1 L_q4_top0_%=\n\t"
+                    "s_cmp_eq_u32 s86, 1\n\t"
+                    "s_cbranch_scc1 L_q4_go1_%=\n\t"
+                    "s_cmp_eq_u32 s86, 2\n\t"
+                    "s_cbranch_scc1 L_q4_go2_%=\n\t"
+                    "s_cmp_eq_u32 s86, 3\n\t"
+                    "s_cbranch_scc1 L_q4_go3_%=\n\t"
+                    "s_cmp_eq_u32 s86, 4\n\t"
+                    "s_cbranch_scc1 L_q4_top4_%=\n\t"
+                    "s_cmp_eq_u32 s86, 5\n\t"
+                    "s_cbranch_scc1 L_q4_go5_%=\n\t"
+                    "s_cmp_eq_u32 s86, 6\n\t"
+                    "s_cbranch_scc1 L_q4_go6_%=\n\t"
+                    "s_branch L_q4_go7_%=\n"
+                    Q4_CHECK("0")
+                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_OUTE, "")
+                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_OUTO, "")
+                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_OUTE, "")
+                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_OUTO, Q4_RLOW)
+                    Q4_PUBLISH(Q4_OUTO)
+                    Q4_CHECK("4")
+                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_OUTE, "")
+                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_OUTO, "")
+                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_OUTE, "")
+                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_OUTO, Q4_RLOW)
+                    Q4_PUBLISH(Q4_OUTO)
+                    "s_branch L_q4_top0_%=\n"
+                    "L_q4_oute_%=:\n\t"  // left after an even slot: the new states are in set b
+                    "v_cndmask_b32 %[sa], %[sa], %[sb], vcc\n\t"  // vcc is still the last step's "go"
+                    "s_branch L_q4_done_%=\n"
+                    "L_q4_outo_%=:\n\t"  // after an odd slot: old states in set b, new ones in set a
+                    "v_cndmask_b32 %[sa], %[sb], %[sa], vcc\n"
+                    "L_q4_done_%=:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"  // the last step's ring read is still on its way into v232..v235
+                    : [sa] "+v"(st), [sb] "+v"(stb), [k] "+v"(wk), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(woff), [i] "+s"(i),
+                      [tail] "+s"(tail_seen), [polls] "+s"(polls), [smask] "=&s"(smask)
+                    : [cb] "v"(cb), [shr] "v"(shr), [Kc] "v"(Kc), [nbK] "v"(nbK), [ringl] "v"(ringl), [qca] "v"(qca), [qwa] "v"(qwa),
+                      [chan4] "v"(chan4), [heada] "v"(heada), [vzero] "v"(vzero), [nmax] "s"(nmax), [spare] "s"(sparemask),
+                      [o_tail1] "n"(512 + offsetof(Q4Shared, tail1)), [o_prog] "n"(512 + offsetof(Q4Shared, progress)),
+                      [o_rlow] "n"(512 + offsetof(Q4Shared, ring_low)),
+#define Q4_QC(S) (512 + offsetof(Q4Shared, q1c) + (S) * 512)
+#define Q4_QW(S) (512 + offsetof(Q4Shared, q1w) + (S) * 512)
+                      [qc0] "n"(Q4_QC(0)), [qc1] "n"(Q4_QC(1)), [qc2] "n"(Q4_QC(2)), [qc3] "n"(Q4_QC(3)),
+                      [qc4] "n"(Q4_QC(4)), [qc5] "n"(Q4_QC(5)), [qc6] "n"(Q4_QC(6)), [qc7] "n"(Q4_QC(7)),
+                      [qw0] "n"(Q4_QW(0)), [qw1] "n"(Q4_QW(1)), [qw2] "n"(Q4_QW(2)), [qw3] "n"(Q4_QW(3)),
+                      [qw4] "n"(Q4_QW(4)), [qw5] "n"(Q4_QW(5)), [qw6] "n"(Q4_QW(6)), [qw7] "n"(Q4_QW(7))
+                    : "memory", "vcc", "scc", "s86",
+                      "v200", "v201", "v202", "v203", "v207", "v209", "v210", "v211", "v212", "v213",
+                      "v215", "v217", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
+                      "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236");
+#undef Q4_STEP
+#undef Q4_CHECK
+#undef Q4_RINGCHK
+#undef Q4_PUBLISH
+#undef Q4_OUTE
+#undef Q4_OUTO
+#undef Q4_RLOW
+#undef Q4_A
+#undef Q4_B
+#undef Q4_QC
+#undef Q4_QW
+            }
+#endif
             // i has moved past the step; chains in smask have not done it yet (their `left` has been counted down: undo)
             if (smask) {
                 const bool mine = ((smask >> lane) & 1) != 0;
+#ifdef MZD_Q4_STATS
+                n_general++;
+#endif
                 if (mine) left += 1u;
                 general_step(i - 1, mine);
                 if (mine && live) left -= 1u;
@@ -373,6 +575,17 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+#ifdef MZD_Q4_STATS
+        if (lane == 0) {
+            atomicAdd(&g_q4_stats[0], 1ull);
+            atomicAdd(&g_q4_stats[1], (unsigned long long)nmax);
+            atomicAdd(&g_q4_stats[2], (unsigned long long)(clock64() - stats_t0));
+            atomicAdd(&g_q4_stats[3], (unsigned long long)(polls & 0xFFFF));
+            atomicAdd(&g_q4_stats[4], (unsigned long long)(polls >> 16));
+            atomicAdd(&g_q4_stats[5], (unsigned long long)n_general);
+        }
+#endif
+        (void)wait_space; (void)polls; (void)q1c_lane; (void)q1w_chain; (void)vzero; (void)qca; (void)qwa; (void)chan4; (void)heada; (void)sparemask;
         if (spare && has && t.n_seq > 0) shs->stA[ch] = status;
     } else if (wave == 4) {
         // ================= stage B: field extraction and values, four steps at a time =================
