@@ -103,8 +103,6 @@ struct mzd_dbatch {
     uint64_t out_size = 0;
     uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
     uint64_t huf_out_bytes = 0;                        // literals the Huffman stage regenerates (scratch or in place)
-    uint32_t *d_tickets = nullptr;                     // persistent k_exec: frame ticket counters
-    bool warm = false;                                 // the batch has been run at least once (experiments)
     mzd_batch_stats stats{};
 };
 
@@ -243,7 +241,6 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_litbuf);
     (void)hipFree(db->d_status);
     (void)hipFree(db->d_out_len);
-    (void)hipFree(db->d_tickets);
     free_parse_temps(db->tmp);
     delete db;
 }
@@ -1239,7 +1236,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (!count || no_exec) return;
         k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames + first, db->d_blocks, db->d_sums,
                                                      db->d_recs, db->d_tiles, db->d_litbuf, db->d_status + first,
-                                                     db->d_out_len + first, exec_cap, count, nullptr);
+                                                     db->d_out_len + first, exec_cap);
     };
     // optional integrity check of the regenerated frames (extension: the reference never verifies it)
     auto launch_verify = [&](hipStream_t st, uint32_t first, uint32_t count) {
@@ -1252,39 +1249,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     //   s  : k_init -> k_seq(head) -> k_seq(tail) -> [wait huf] k_exec(tail) -> [wait head done]
     //   s2 : [wait init] k_huf -> [wait k_seq(head)] k_exec(head)
     hipStream_t s2 = ctx->stream2;
-    if (const char *xe = getenv("MZD_EXP_OVERLAP")) {
-        // EXPERIMENT (timing only, results unchanged because a resident batch decodes to the same records every pass):
-        // k_seq_pipe over the whole batch on s with `nch` chains per workgroup, and AT THE SAME TIME the persistent form
-        // of k_exec over the whole batch on s2, R workgroups per CU, reading the records of the PREVIOUS pass.  Measures
-        // what the two kernels cost each other when they share the CUs.  "nch,R,threads"
-        unsigned xn = 40, xr = 5, xt = 256;
-        sscanf(xe, "%u,%u,%u", &xn, &xr, &xt);
-        if (db->warm && pipe && xn >= 1 && xr >= 1 && (xt == 64 || xt == 128 || xt == 192 || xt == 256)) {
-            if (!db->d_tickets) HIP_TRY(ctx, hipMalloc((void **)&db->d_tickets, 64 * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMemsetAsync(db->d_tickets, 0, 64 * sizeof(uint32_t), s));
-            if (ev) { HIP_TRY(ctx, hipEventRecord(ev[0], s)); HIP_TRY(ctx, hipEventRecord(ev[1], s)); ctx->run_split[ctx->runs] = true; }
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_init_done, s));
-            nch = std::min<uint32_t>(xn, (uint32_t)kPipeMaxChains);
-            launch_seq(0, db->n_frames);
-            if (ev) { HIP_TRY(ctx, hipEventRecord(ev[3], s)); HIP_TRY(ctx, hipEventRecord(ev[4], s)); HIP_TRY(ctx, hipEventRecord(ev[5], s)); }
-            HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
-            if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
-            if (db->n_huf_tasks)
-                k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
-                                                                      db->d_litbuf, db->d_sums, db->huf_slot_cells);
-            if (ev) { HIP_TRY(ctx, hipEventRecord(ev[2], s2)); HIP_TRY(ctx, hipEventRecord(ev[6], s2)); }
-            k_exec<<<xr * (uint32_t)std::max(ctx->num_cus, 1), xt, exec_lds, s2>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
-                                                                                  db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
-                                                                                  db->d_out_len, exec_cap, db->n_frames, db->d_tickets);
-            if (ev) { HIP_TRY(ctx, hipEventRecord(ev[7], s2)); HIP_TRY(ctx, hipEventRecord(ev[10], s2)); }
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s2));
-            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_head_done, 0));
-            if (ev) { HIP_TRY(ctx, hipEventRecord(ev[11], s)); HIP_TRY(ctx, hipEventRecord(ev[8], s)); ctx->runs++; }
-            HIP_TRY(ctx, hipGetLastError());
-            return MZD_OK;
-        }
-    }
-    db->warm = true;
     if (db->n_huf_tasks == 0 && db->n_seq_tasks == 0 && db->stats.n_blocks[2] == 0) {
         // Nothing but Raw / RLE blocks (BASELINE configs[1]): the pass IS the copy kernel -- no summaries to reset,
         // no second stream, no cross-stream events in front of it (they cost more than the 0.2 ms copy itself).

@@ -1282,12 +1282,6 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(has ? t.n_seq : 0u));
     int status = MZD_OK;
 
-#ifndef MZD_PIPE_PRIO
-#define MZD_PIPE_PRIO 0
-#endif
-    // Issue priority over whatever else shares the CU (k_huf, the persistent k_exec): the chain wavefront's step IS the
-    // kernel's duration, every issue slot it loses to a bulk wavefront is lost for good; the bulk wavefronts have slack.
-    if (MZD_PIPE_PRIO) { if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
     if (wave == 0) {
         // ================= stage A: the serial chain =================
         const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
@@ -1534,35 +1528,35 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "ds_write_b32 %[lane4], %[off] offset:%[o_prog]\n\t"                                                    \
     "s_cbranch_vccz L_pipe_go" TAG "_%=\n\t"                                                                \
     MZD_PIPE_RINGCHK(TAG)
+// The step, ordered so that the LDS round trip of the NEXT step's cell reads runs behind this step's bookkeeping: a
+// lone wavefront issues one instruction per ~4 cycles and nothing while it waits, so every instruction placed between
+// the reads and their s_waitcnt is latency hidden.  On entry the three cells of this step are on their way (requested
+// at the end of the step before, or by the prologue), the window C is normalised (k < 8), v228 holds the limit.
+//   1. the recurrence: cells -> bit counts -> state fields -> new states -> the next step's cell reads (speculative: a
+//      lane that does not "go" reads with a meaningless state; LDS reads outside the allocation return zero);
+//   2. in their shadow: go / advance, the queue entry for stage B, then what used to open the next step: cursor,
+//      ring read, refill of C with the bytes the step before read from the ring (DM), the next limit.
 // DM: the 8 bytes the previous step read from the ring; DL: where this step's go
-#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT, RLOW, NLATE)                                                    \
+#ifdef MZD_ABL_NOWAIT  /* ablations: timing experiments only, wrong results */
+#define MZD_ABL_W3 "s_nop 0\n\t"
+#define MZD_ABL_W6 "s_nop 0\n\t"
+#else
+#define MZD_ABL_W3 "s_waitcnt lgkmcnt(3)\n\t"
+#define MZD_ABL_W6 "s_waitcnt lgkmcnt(6)\n\t"
+#endif
+#ifdef MZD_ABL_NORING
+#define MZD_ABL_RING(DL) "s_nop 0\n\t"
+#else
+#define MZD_ABL_RING(DL) "ds_read_b64 " DL ", v209\n\t"
+#endif
+#ifdef MZD_ABL_NOQW
+#define MZD_ABL_QW(X) "s_nop 0\n\t"
+#else
+#define MZD_ABL_QW(X) X
+#endif
+#define MZD_PIPE_STEP(DM, DL, SA, SB, TAG, QT, QP, OUT, RLOW)                                               \
     "L_pipe_go" TAG "_%=:\n\t"                                                                              \
-    "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
-    "v_lshl_add_u32 v200, %[sL" SA "], 1, %[cbL]\n\t"                                                       \
-    "v_lshl_add_u32 v201, %[sM" SA "], 1, %[cbM]\n\t"                                                       \
-    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
-    "v_lshl_add_u32 v202, %[sO" SA "], 1, %[cbO]\n\t"                                                       \
-    "ds_read_u16 v203, v200\n\t" /* xl */                                                                   \
-    "v_and_b32 v209, 127, %[off]\n\t"                                                                       \
-    "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
-    "v_add_u32 v209, v209, %[ringl]\n\t"                                                                    \
-    "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
-    "ds_read_b64 " DL ", v209\n\t" /* the 8 bytes below the window, for the next step */                    \
-    RLOW                                                                                                    \
-    /* C <<= 8 * (k >> 3); k &= 7; then the bytes that come in from DM: C += (DM >> 1) >> (63 - 8nb) */    \
-    "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
-    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
-    "v_sub_u32 v208, 63, v206\n\t"                                                                          \
-    "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
-    "s_waitcnt lgkmcnt(3+" NLATE ")\n\t" /* everything older than this step's reads: the ring read of the step before */ \
-    "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
-    "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
-    "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
-    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
-    "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
-    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
-    /* the three cells only: the (byte-misaligned, a cycle per lane) ring read behind them is for the next step */ \
-    "s_waitcnt lgkmcnt(" NLATE ")\n\t"                                                                      \
+    MZD_ABL_W3                              /* the three cells (behind them: two queue writes, a ring read) */ \
     "v_lshrrev_b32 v215, 12, v203\n\t"                                                                      \
     "v_lshrrev_b32 v216, 12, v204\n\t"                                                                      \
     "v_and_b32 v217, 0x3ff, v203\n\t"       /* nl */                                                        \
@@ -1582,31 +1576,56 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
     "v_sub_u32 v224, 0, v220\n\t"           /* -nbL */                                                      \
     "v_add_u32 v229, v223, %[k]\n\t"        /* k + o3 */                                                    \
     "v_sub_u32 v225, v224, v221\n\t"        /* -(nbL + nbM) */                                              \
-    "v_sub_u32 v226, v225, v222\n\t"        /* -(nbL + nbM + nbO) */                                        \
-    "v_sub_u32 v230, v223, v226\n\t"        /* total */                                                     \
-    "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
-    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
-    "v_cmp_lt_u32 vcc, v227, v228\n\t"                  /* go (= advance; never at the last sequence) */    \
     "v_lshlrev_b64 v[210:211], v229, %[C]\n\t"          /* X = C << (k + o3): state bits from bit 63 */     \
-    "s_andn2_b64 %[smask], %[live], vcc\n\t"            /* special = live & ~go */                          \
-    "v_cndmask_b32 v230, 0, v230, vcc\n\t"                                                                  \
-    "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T = C << k */                                    \
-    "v_sub_u32 %[rem1], %[rem1], v230\n\t"                                                                  \
-    "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
-    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"                                                              \
+    "v_sub_u32 v226, v225, v222\n\t"        /* -(nbL + nbM + nbO) */                                        \
+    "v_perm_b32 v231, v204, v203, %[sel1]\n\t"                                                              \
     "v_bfe_u32 v224, v211, v224, v220\n\t" /* aL */                                                         \
     "v_bfe_u32 v225, v211, v225, v221\n\t" /* aM */                                                         \
+    "v_sub_u32 v230, v223, v226\n\t"        /* total */                                                     \
     "v_bfe_u32 v226, v211, v226, v222\n\t" /* aO */                                                         \
-    "ds_write_b64 %[lane8], v[212:213] offset:" QT "\n\t"                                                   \
     /* the new states go to the OTHER register set (a lane that does not advance is special: the exit     */ \
     /* code picks per lane; a parked lane's state is never used)                                          */ \
     "v_lshl_add_u32 %[sL" SB "], v217, v220, v224\n\t"                                                      \
     "v_lshl_add_u32 %[sM" SB "], v218, v221, v225\n\t"                                                      \
     "v_lshl_add_u32 %[sO" SB "], v219, v222, v226\n\t"                                                      \
-    "ds_write_b32 %[lane4], v231 offset:" QP "\n\t"                                                         \
+    "v_perm_b32 v231, v205, v231, %[sel2]\n\t"          /* (the cells' high bytes for stage B: before the reads below overwrite them) */ \
+    "v_or3_b32 v227, v230, v220, v221\n\t"                                                                  \
+    "v_lshl_add_u32 v200, %[sL" SB "], 1, %[cbL]\n\t"                                                       \
+    "v_lshl_add_u32 v201, %[sM" SB "], 1, %[cbM]\n\t"                                                       \
+    "v_lshl_add_u32 v202, %[sO" SB "], 1, %[cbO]\n\t"                                                       \
+    "ds_read_u16 v203, v200\n\t" /* the NEXT step's xl */                                                   \
+    "ds_read_u16 v204, v201\n\t" /* xm */                                                                   \
+    "ds_read_u16 v205, v202\n\t" /* xo */                                                                   \
+    /* ---- in the shadow of those reads */                                                                 \
+    "v_cmp_lt_u32 vcc, v227, v228\n\t"                  /* go (= advance; never at the last sequence) */    \
+    "v_lshlrev_b64 v[212:213], %[k], %[C]\n\t"          /* T = C << k */                                    \
+    "s_andn2_b64 %[smask], %[live], vcc\n\t"            /* special = live & ~go */                          \
+    "v_cndmask_b32 v230, 0, v230, vcc\n\t"                                                                  \
+    MZD_ABL_QW("ds_write_b64 %[lane8], v[212:213] offset:" QT "\n\t")                                       \
+    "v_sub_u32 %[rem1], %[rem1], v230\n\t"                                                                  \
+    "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
+    MZD_ABL_QW("ds_write_b32 %[lane4], v231 offset:" QP "\n\t")                                             \
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "s_cmp_lg_u64 %[smask], 0\n\t"                                                                          \
-    "s_cbranch_scc1 " OUT "\n\t"
+    "s_cbranch_scc1 " OUT "\n\t"                                                                            \
+    /* the cursor and the window for the next step: C <<= 8 * (k >> 3); k &= 7; the bytes that come in from DM */ \
+    "v_lshrrev_b32 v207, 3, %[k]\n\t"                                                                       \
+    "v_and_b32 v206, -8, %[k]\n\t"                                                                          \
+    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
+    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
+    "v_and_b32 v209, 127, %[off]\n\t"                                                                       \
+    "v_sub_u32 v208, 63, v206\n\t"                                                                          \
+    "v_add_u32 v209, v209, %[ringl]\n\t"                                                                    \
+    "v_lshlrev_b64 %[C], v206, %[C]\n\t"                                                                    \
+    MZD_ABL_RING(DL)               /* the 8 bytes below the new window, for the refill after the next step */ \
+    MZD_ABL_W6                     /* DM: everything older than the six operations of this step */          \
+    "v_lshrrev_b64 v[210:211], 1, " DM "\n\t"                                                               \
+    "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
+    "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"                                                        \
+    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t" /* limit = min(64 - k, rem + 1, steps before the last) */ \
+    "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"                                                          \
+    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
+    RLOW
 #define MZD_PIPE_PUBLISH(OUT)                                                                               \
     "v_mov_b32 v202, %[i]\n\t"                                                                              \
     "ds_write_b32 %[vzero], v202 offset:%[o_head1]\n\t"                                                     \
@@ -1618,18 +1637,38 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
 #define MZD_DA "v[232:233]"
 #define MZD_DB "v[234:235]"
                 asm volatile(
-                    // prologue: both lookahead pairs = the 8 bytes below the window (D, which the C++ side keeps
-                    // valid); the entry's ring check; then the instance of slot i % 8
-                    "v_mov_b32 v232, %[Dlo]\n\t"
-                    "v_mov_b32 v233, %[Dhi]\n\t"
-                    "v_mov_b32 v234, %[Dlo]\n\t"
-                    "v_mov_b32 v235, %[Dhi]\n\t"
+                    // prologue = what the shadow of a step before would have done: the ring holds the bytes at the cursor
+                    // (checked first: the very first entry, or a general step that moved the cursor far), cursor and window
+                    // normalised and refilled from D (which the C++ side keeps valid), both lookahead pairs = the 8 bytes below
+                    // the new window, the limit, and this step's cells requested; then the instance of slot i % 8
                     "v_mov_b32 v236, -1\n\t"  // no ring_low read ahead yet: the first batch check takes the slow path
-                    "s_and_b32 s86, %[i], 3\n\t"
-                    "s_cmp_eq_u32 s86, 0\n\t"
-                    "s_cbranch_scc1 L_pipe_goe_%=\n\t"  // slots 0 and 4 make the check themselves
                     MZD_PIPE_RINGCHK("e")
                     "L_pipe_goe_%=:\n\t"
+                    "v_lshrrev_b32 v207, 3, %[k]\n\t"
+                    "v_and_b32 v206, -8, %[k]\n\t"
+                    "v_sub_u32 %[off], %[off], v207\n\t"
+                    "v_and_b32 %[k], 7, %[k]\n\t"
+                    "v_and_b32 v209, 127, %[off]\n\t"
+                    "v_sub_u32 v208, 63, v206\n\t"
+                    "v_add_u32 v209, v209, %[ringl]\n\t"
+                    "v_lshlrev_b64 %[C], v206, %[C]\n\t"
+                    "ds_read_b64 v[232:233], v209\n\t"
+                    "ds_read_b64 v[234:235], v209\n\t"
+                    "v_mov_b32 v210, %[Dlo]\n\t"
+                    "v_mov_b32 v211, %[Dhi]\n\t"
+                    "v_lshrrev_b64 v[210:211], 1, v[210:211]\n\t"
+                    "v_sub_u32 v228, 64, %[k]\n\t"
+                    "v_lshrrev_b64 v[210:211], v208, v[210:211]\n\t"
+                    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t"
+                    "v_lshl_add_u64 %[C], %[C], 0, v[210:211]\n\t"
+                    "v_add_u32 %[left], -1, %[left]\n\t"
+                    "v_lshl_add_u32 v200, %[sLa], 1, %[cbL]\n\t"
+                    "v_lshl_add_u32 v201, %[sMa], 1, %[cbM]\n\t"
+                    "v_lshl_add_u32 v202, %[sOa], 1, %[cbO]\n\t"
+                    "ds_read_u16 v203, v200\n\t"
+                    "ds_read_u16 v204, v201\n\t"
+                    "ds_read_u16 v205, v202\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
                     "s_and_b32 s86, %[i], 7\n\t"
                     "s_cmp_eq_u32 s86, 0\n\t"
                     "s_cbranch_scc1 L_pipe_top0_%=\n\t"
@@ -1647,16 +1686,16 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                     "s_cbranch_scc1 L_pipe_go6_%=\n\t"
                     "s_branch L_pipe_go7_%=\n"
                     MZD_PIPE_CHECK("0")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE, "", "1")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO, "", "1")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE, "", "1")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO, MZD_RLOW, "2")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "0", "%[qt0]", "%[qp0]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "1", "%[qt1]", "%[qp1]", MZD_OUTO, "")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "2", "%[qt2]", "%[qp2]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "3", "%[qt3]", "%[qp3]", MZD_OUTO, MZD_RLOW)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     MZD_PIPE_CHECK("4")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE, "", "1")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO, "", "1")
-                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE, "", "1")
-                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO, MZD_RLOW, "2")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "4", "%[qt4]", "%[qp4]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "5", "%[qt5]", "%[qp5]", MZD_OUTO, "")
+                    MZD_PIPE_STEP(MZD_DA, MZD_DB, "a", "b", "6", "%[qt6]", "%[qp6]", MZD_OUTE, "")
+                    MZD_PIPE_STEP(MZD_DB, MZD_DA, "b", "a", "7", "%[qt7]", "%[qp7]", MZD_OUTO, MZD_RLOW)
                     MZD_PIPE_PUBLISH(MZD_OUTO)
                     "s_branch L_pipe_top0_%=\n"
                     "L_pipe_oute_%=:\n\t"  // left after an even slot: the new states are in set b
@@ -1758,6 +1797,10 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             uint64_t q[kPipeBatch];
+#ifdef MZD_EXP_FAST_BC  // timing experiment only (wrong results): what stage A can do when nothing holds it up
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) q[u] = T[u] ^ P[u];
+#else
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
                 const uint32_t cl = CTc[__builtin_amdgcn_ubfe(P[u], 2, 6)];
@@ -1774,6 +1817,7 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
                                    ((uint64_t)ofv << kRecOffShift);
                 q[u] = (P[u] >> 31) ? T[u] : v;
             }
+#endif
 #ifdef MZD_PIPE_PROF
             const long long w1 = clock64();
 #endif
@@ -1829,6 +1873,10 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
             for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][lane];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MZD_EXP_FAST_BC
+            litPos += (uint32_t)(q[0] ^ q[1] ^ q[2] ^ q[3]);
+            continue;
+#endif
             if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
             uint64_t rr[kPipeBatch];
 #pragma unroll
@@ -1973,7 +2021,7 @@ struct ExecShared {
     int error;
     uint32_t next_tile;  // first tile of the next chunk (written by thread 0)
     uint32_t chunk_end;  // block-relative output position where the current chunk ends
-    uint32_t frame;      // persistent form: the frame this workgroup drew from the ticket counter
+    uint32_t pad;
 };
 
 __device__ __forceinline__ int sel3(uint32_t k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
@@ -2102,8 +2150,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
                                                const TileBase *__restrict__ tiles, const uint8_t *__restrict__ litbuf,
-                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap,
-                                               uint32_t n_frames, uint32_t *ticket)
+                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *buf = smem;                                        // cap + 32 bytes
@@ -2111,20 +2158,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
     ExecShared *sh = (ExecShared *)(smem + cap + 32 + (cap / 32 + 4) * 4);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-    // Two launch forms.  ticket == nullptr: one workgroup per frame (frame = blockIdx.x).  Otherwise PERSISTENT: a
-    // fixed number of workgroups per CU, each drawing frames from a ticket counter until the range is used up -- the
-    // form that runs BESIDE k_seq_pipe: no workgroup of this kernel is ever pending, so whatever LDS a finishing
-    // k_seq_pipe workgroup frees goes to the next k_seq_pipe workgroup, never to this kernel.
-    for (;;) {
-    uint32_t fi = blockIdx.x;
-    if (ticket) {
-        __syncthreads();  // everybody is done with the previous frame's shared state
-        if (tid == 0) sh->frame = atomicAdd(ticket, 1u);
-        __syncthreads();
-        fi = sh->frame;
-        if (fi >= n_frames) return;
-    }
-    const DFrame fr = frames[fi];
+    const DFrame fr = frames[blockIdx.x];
     uint8_t *out = out_blob + fr.out_offset;
 
     if (tid == 0) sh->error = fr.plan_status;
@@ -2510,11 +2544,9 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
     if (tid == 0) {
         int e = sh->error;
         if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
-        frame_status[fi] = e;
-        frame_out_len[fi] = outPos;
+        frame_status[blockIdx.x] = e;
+        frame_out_len[blockIdx.x] = outPos;
     }
-    if (!ticket) return;
-    }  // persistent form: next frame
 }
 
 

@@ -610,6 +610,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             uint64_t q[kPipeBatch];
+#ifdef MZD_EXP_FAST_BC  // timing experiment only (wrong results): what stage A can do when nothing holds it up
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) q[u] = T[u] ^ Cq[u];
+#else
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
                 const uint32_t xl = (uint32_t)Cq[u] & 0xFFFF, xm = (uint32_t)(Cq[u] >> 16) & 0xFFFF, xo = (uint32_t)(Cq[u] >> 32) & 0xFFFF;
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                                    ((uint64_t)ofv << kRecOffShift);
                 q[u] = (kk & 0x8000u) ? T[u] : v;
             }
+#endif
             while (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) {
                 tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
                     (int)__hip_atomic_load(&shs->tail2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -663,6 +668,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][lane];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MZD_EXP_FAST_BC
+            litPos += (uint32_t)(q[0] ^ q[1] ^ q[2] ^ q[3]);
+            continue;
+#endif
             if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
             uint64_t rr[kPipeBatch];
 #pragma unroll
