@@ -1129,7 +1129,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // k_seq_pipe: two chains fewer than fit, so that ~6 KiB of every CU's LDS stay free and the small
     // k_huf workgroups run in k_seq's shadow instead of queueing for whole CUs (measured with 54 chains of 56:
     // 28.6 ms per step; 55: 29.5; 56: 32.2; 53: 29.2; 51: 30.9)
-    uint32_t nch = q4 ? (uint32_t)std::min(kQ4MaxChains - 1, 54) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
+    uint32_t nch = q4 ? (uint32_t)kQ4Chains : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
     if (const char *e = getenv("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
     const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames;

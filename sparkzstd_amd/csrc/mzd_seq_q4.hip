@@ -25,24 +25,29 @@ namespace mzd {
 
 constexpr int kQ4ChainsPerWave = 14;  // quads 14 and 15 of a chain wavefront are parked
 constexpr int kQ4ChainWaves = 4;
-constexpr int kQ4Threads = 64 * (kQ4ChainWaves + 3);
+constexpr int kQ4Threads = 64 * (kQ4ChainWaves + 5);  // + stage B (two wavefronts, alternate batches), C1, C2, P
+constexpr int kQ4Cols = 56;  // queue columns: one per chain (<= 54) + the column parked quads write to (55)
 
 struct Q4Shared {
     uint32_t head1[4];                 // steps produced by each chain wavefront (0xFFFFFFFF: has no chains)
-    uint32_t tail1, head2, tail2, pad0;
+    uint32_t tailB[2];                 // steps of ITS batches each stage-B wavefront has consumed (even / odd batches of four)
+    uint32_t head2[2];                 // steps each stage-B wavefront has handed to stage C1
+    uint32_t head3, tail2, pad0[2];    // steps stage C1 has finished (records complete in q2) / stage C2 has stored
     uint32_t progress[64];             // per chain: byte offset of the window (from in - MZD_IN_PAD), published per batch
-    int32_t stC[64];                   // final status of stage C
+    int32_t stC[64];                   // final status of stage C1 (offsets)
+    int32_t stC2[64];                  // final status of stage C2 (sizes)
     int32_t stA[64];                   // final status of stage A
     uint32_t ring_low[64];             // per chain: lowest offset wave P has put in the ring
-    uint64_t q1w[kPipeDepth][64];      // mode 0: the 8 bytes at the cursor; mode 1: LL:17 | ML:18 | offset value:29
-    uint16_t q1c[kPipeDepth][64][4];   // mode 0: LL cell, ML cell, OF cell, bits consumed of q1w (0..7); mode 1: [3] = 0x8000
-    uint64_t q2[kPipeDepth][64];
+    uint64_t q1w[kPipeDepth][kQ4Cols];      // mode 0: the 8 bytes at the cursor; mode 1: LL:17 | ML:18 | offset value:29
+    uint16_t q1c[kPipeDepth][kQ4Cols][4];   // mode 0: LL cell, ML cell, OF cell, bits consumed of q1w (0..7); mode 1: [3] = 0x8000
+    uint64_t q2[kPipeDepth][kQ4Cols];       // B -> C1: LL:17 | ML:18 | offset value:29; C1 -> C2: the finished record, in place
     uint8_t ring[kQ4ChainWaves * kQ4ChainsPerWave][kPipeRing + 8];
     uint16_t dummy[8];                 // dummy[1] = 1: the cell of parked lanes and of every quad's fourth lane
 };
 constexpr int kQ4FixedLds = (512 + (int)sizeof(Q4Shared) + 15) & ~15;
 constexpr int kQ4MaxChains = (160 * 1024 - kQ4FixedLds) / (kSeqCellsPerChain * 2);
-static_assert(kQ4MaxChains >= 54 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
+constexpr int kQ4Chains = 54;  // chains per workgroup: what LDS holds next to a k_huf workgroup, and < kQ4Cols - 1
+static_assert(kQ4MaxChains >= kQ4Chains + 1 && kQ4Chains < kQ4Cols - 1 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
 
 #ifdef MZD_Q4_STATS
 __device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps
@@ -64,13 +69,13 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     Q4Shared *shs = (Q4Shared *)(smem + 512);
     uint16_t *cells = (uint16_t *)(smem + kQ4FixedLds);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4: B; 5: C; 6: P
+    const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4, 5: stage B (even / odd batches); 6: C1; 7: C2; 8: P
     const bool chainw = wave < kQ4ChainWaves;
     // the chain this lane works for: chain wavefronts 4 lanes per chain, the others one lane per chain
     const uint32_t quad = (uint32_t)lane >> 2, role = (uint32_t)lane & 3u;
-    // (quads 14 and 15 of a chain wavefront have no chain: they are parked and write their queue entries to slot 63,
-    // which no workgroup uses: nch <= kQ4MaxChains)
-    const uint32_t ch = chainw ? (quad < (uint32_t)kQ4ChainsPerWave ? (uint32_t)wave * kQ4ChainsPerWave + quad : 63u) : (uint32_t)lane;
+    // (quads 14 and 15 of a chain wavefront have no chain: they are parked and write their queue entries to column 55,
+    // which no workgroup uses: nch <= 54)
+    const uint32_t ch = chainw ? (quad < (uint32_t)kQ4ChainsPerWave ? (uint32_t)wave * kQ4ChainsPerWave + quad : (uint32_t)kQ4Cols - 1u) : (uint32_t)lane;
     const uint32_t tid = blockIdx.x * nch + ch;
     const bool has = ch < nch && tid < n_tasks;
     SeqTask t;
@@ -82,15 +87,16 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
     }
     in += in_base;
-    if (wave == 6) {
+    if (wave == 8) {
         CTc[lane] = 0;
         CTc[64 + lane] = 0;
         shs->progress[lane] = (uint32_t)t.in_off + MZD_IN_PAD + t.in_size;
         shs->ring_low[lane] = (has && t.n_seq > 0) ? 0xFFFFFFFFu : 0u;  // nothing in the ring yet / nothing needed
         shs->stC[lane] = MZD_OK;
+        shs->stC2[lane] = MZD_OK;
         shs->stA[lane] = MZD_OK;
         if (lane < 8) shs->dummy[lane] = 1;
-        if (lane == 0) { shs->tail1 = 0; shs->head2 = 0; shs->tail2 = 0; }
+        if (lane == 0) { shs->tailB[0] = 0; shs->tailB[1] = 0; shs->head2[0] = 0; shs->head2[1] = 0; shs->head3 = 0; shs->tail2 = 0; }
         // a chain wavefront without chains never produces anything: nobody waits for it
         if (lane < 4) shs->head1[lane] = (uint32_t)lane * kQ4ChainsPerWave < min(nch, n_tasks - blockIdx.x * nch) ? 0u : 0xFFFFFFFFu;
         __builtin_amdgcn_s_waitcnt(0);  // the zero fill above before the scattered fill below (same wavefront: LDS is in order)
@@ -216,18 +222,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         };
         if (!live) park();
         const uint32_t ringl = 512u + (uint32_t)offsetof(Q4Shared, ring) + ch * (kPipeRing + 8);
-        uint16_t *q1c_lane = &shs->q1c[0][min(ch, 63u)][role];
-        uint64_t *q1w_chain = &shs->q1w[0][min(ch, 63u)];
 
-        uint32_t tail_seen = 0;
-        auto wait_space = [&](uint32_t at) {  // slot of step `at` is free once at - tail1 < depth
-            while (at - tail_seen >= (uint32_t)kPipeDepth) {
-                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
-                    (int)__hip_atomic_load(&shs->tail1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (at - tail_seen >= (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
-            }
-        };
-        // (symbol, next, base | extra << 24) of a literal-length / match-length cell, escape or not
         auto full_cell = [&](int kind, uint32_t x, uint32_t idx, uint32_t toff, uint32_t size, uint32_t &next, uint32_t &ct) {
             next = x & 1023;
             ct = CTc[kind * 64 + (x >> 10)];
@@ -319,8 +314,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         }
         const uint64_t sparemask = 0x8888888888888888ull;
         const uint32_t vzero = 0;
-        const uint32_t qca = (min(ch, 63u) * 4u + role) * 2u, qwa = min(ch, 63u) * 8u, chan4 = min(ch, 63u) * 4u;
+        const uint32_t qca = (ch * 4u + role) * 2u, qwa = ch * 8u, chan4 = ch * 4u;  // ch <= 55
         const uint32_t heada = 512u + (uint32_t)offsetof(Q4Shared, head1) + 4u * (uint32_t)wave;
+        uint32_t tail0 = 0, tail1 = 0;  // what this wavefront last saw of the two stage-B wavefronts' progress
         uint32_t polls = 0;
 #ifdef MZD_Q4_STATS
         const long long stats_t0 = clock64();
@@ -328,175 +324,135 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #endif
         while (i < nmax) {
             uint64_t smask = 0;
-#ifdef MZD_Q4_CXX_STEP
-            bool entry = true;  // (re-)entering the loop: a general step may have moved the cursor by more than a hot step
-            do {
-                wait_space(i);
-                if ((i & 3) == 0 || entry) {
-                    entry = false;
-                    // cursor to wave P; the ring must reach 40 bytes below it (a batch of four steps reads at most 32 + 8)
-                    if (role == 3) shs->progress[min(ch, 63u)] = woff;
-                    for (;;) {
-                        const uint32_t rl = __hip_atomic_load(&shs->ring_low[min(ch, 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (!__any(rl > woff - 40u)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                const uint32_t x = *(const uint16_t *)(smem + cb + 2u * st);
-                uint64_t W = 0;
-                if (spare) W = ((const U64U *)(smem + ringl + (woff & (kPipeRing - 1))))->v;
-                const uint32_t Wlo = dpp_quad<QP(3, 3, 3, 3)>((uint32_t)W), Whi = dpp_quad<QP(3, 3, 3, 3)>((uint32_t)(W >> 32));
-                const uint32_t c = x >> shr, n = x & 0x3ffu;
-                const uint32_t ex = sub_sat(c, Kc);
-                // escape: next = 0 -> ffbh = 0xFFFFFFFF; capped at 2^26 so that the sums below cannot wrap back into
-                // the range of a valid step (three escapes + every other term stay below 2^32 and above any limit)
-                const uint32_t nb = min(ffbh_raw(n), 1u << 26) - nbK;
-                const uint32_t t1 = ex + dpp_quad<QP(1, 0, 3, 2)>(ex);
-                const uint32_t o3 = t1 + dpp_quad<QP(2, 3, 0, 1)>(t1);
-                const uint32_t a1 = nb + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nb, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-                const uint32_t P = a1 + dpp_quad<QP(3, 3, 0, 3)>(nb);
-                const uint32_t tot = dpp_quad<QP(2, 2, 2, 2)>(P) + o3;
-                const uint32_t lim = min(min(64u - wk, rem1), left);
-                const bool go = tot < lim;
-                const uint64_t Wq = (uint64_t)Wlo | ((uint64_t)Whi << 32);
-                const uint32_t Xhi = (uint32_t)((Wq << ((wk + o3) & 63)) >> 32);
-                const uint32_t fld = __builtin_amdgcn_ubfe(Xhi, (0u - P) & 31u, nb & 31u);
-                const uint32_t snew = (n << (nb & 31u)) + fld;
-                q1c_lane[(i % kPipeDepth) * 64 * 4] = (uint16_t)(spare ? wk : x);
-                if (spare) q1w_chain[(i % kPipeDepth) * 64] = Wq;
-                const uint32_t adv = go ? tot : 0u;
-                st = go ? snew : st;
-                wk += adv;
-                rem1 -= adv;
-                left -= 1u;
-                woff -= wk >> 3;
-                wk &= 7;
-                smask = __builtin_amdgcn_ballot_w64(!go);
-                i++;
-                if (!smask) {
-                    asm volatile("" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } while (i < nmax && !smask);
-#else
             {
-                // The same step, hand-scheduled (~43 instructions; k_seq_pipe's: ~66).  The loop body is the step EIGHT times,
-                // one instance per queue slot, as in k_seq_pipe: slot addresses are immediates, queue space / the ring / the
+                // The step, hand-scheduled (~44 instructions; k_seq_pipe's: ~66; a lone wavefront issues one instruction
+                // per ~6 cycles whatever its kind, so the count IS the step).  The loop body is the step EIGHT times, one
+                // instance per queue slot, as in k_seq_pipe: slot addresses are immediates, queue space / the ring / the
                 // cursor for wave P are dealt with once per batch of four steps, head1 is published and nmax checked at the
-                // end of a batch.  DPP reads of a VGPR keep two instructions' distance from the VALU write of it (the
-                // hardware does not interlock that; nothing inside an asm statement is padded by the compiler).
-                // Temporaries are fixed registers v200..v236 / s86.
+                // end of a batch.  A step requests the NEXT step's cell as soon as it has the new state (speculatively: a
+                // chain that does not "go" reads with a meaningless state; LDS reads outside the allocation return zero)
+                // and does its bookkeeping behind that read.  DPP reads of a VGPR keep two instructions' distance from
+                // the VALU write of it (the hardware does not interlock that; nothing inside an asm statement is padded
+                // by the compiler).  Temporaries are fixed registers v100..v136 / s86.
                 static_assert(kPipeDepth == 8 && kPipeBatch == 4 && kPipeRing == 128, "the unrolled loop assumes 2 batches of 4 slots, a 128-byte ring");
                 uint32_t stb = st;  // the states alternate between two register sets
                 // (wave-uniform by construction; said explicitly, or the "s" operands below are refused)
                 i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-                tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_seen);
+                tail0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail0);
+                tail1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail1);
                 polls = (uint32_t)__builtin_amdgcn_readfirstlane((int)polls);
 #define Q4_RINGCHK(TAG)                                                                                     \
     "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n"                                                      \
     "L_q4_ring" TAG "_%=:\n\t"                                                                              \
-    "ds_read_b32 v200, %[chan4] offset:%[o_rlow]\n\t"                                                       \
-    "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    "ds_read_b32 v100, %[chan4] offset:%[o_rlow]\n\t"                                                       \
+    "v_add_u32 v101, -40, %[off]\n\t"                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_cmp_gt_u32 vcc, v200, v201\n\t"                                                                      \
+    "v_cmp_gt_u32 vcc, v100, v101\n\t"                                                                      \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     "s_add_u32 %[polls], %[polls], 0x10000\n\t"                                                             \
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_q4_ring" TAG "_%=\n"
-#define Q4_CHECK(TAG)                                                                                       \
+// TL / OTL: the progress of the stage-B wavefront that owns the four slots this batch goes to
+#define Q4_CHECK(TAG, TL, OTL)                                                                              \
     "L_q4_top" TAG "_%=:\n\t"                                                                               \
-    "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
-    "s_cmp_lt_u32 s86, 5\n\t" /* i + 3 - tail1 < depth */                                                   \
+    "s_sub_u32 s86, %[i], " TL "\n\t"                                                                       \
+    "s_cmp_lt_u32 s86, 5\n\t" /* the batch that used these slots before (i - 8) has been consumed */        \
     "s_cbranch_scc1 L_q4_spc" TAG "_%=\n"                                                                   \
     "L_q4_poll" TAG "_%=:\n\t"                                                                              \
-    "ds_read_b32 v200, %[vzero] offset:%[o_tail1]\n\t"                                                      \
+    "ds_read_b32 v100, %[vzero] offset:" OTL "\n\t"                                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_readfirstlane_b32 %[tail], v200\n\t"                                                                 \
-    "s_sub_u32 s86, %[i], %[tail]\n\t"                                                                      \
+    "v_readfirstlane_b32 " TL ", v100\n\t"                                                                  \
+    "s_sub_u32 s86, %[i], " TL "\n\t"                                                                       \
     "s_cmp_lt_u32 s86, 5\n\t"                                                                               \
     "s_cbranch_scc1 L_q4_spc" TAG "_%=\n\t"                                                                 \
     "s_add_u32 %[polls], %[polls], 1\n\t"                                                                   \
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_q4_poll" TAG "_%=\n"                                                                        \
     "L_q4_spc" TAG "_%=:\n\t"                                                                               \
-    /* fast path: ring_low as read during the previous step (v236; it only ever decreases) */               \
-    "v_add_u32 v201, -40, %[off]\n\t"                                                                       \
+    /* fast path: ring_low as read during the previous step (v136; it only ever decreases) */               \
+    "v_add_u32 v101, -40, %[off]\n\t"                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_cmp_gt_u32 vcc, v236, v201\n\t"                                                                      \
+    "v_cmp_gt_u32 vcc, v136, v101\n\t"                                                                      \
     "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n\t"                                                    \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     Q4_RINGCHK(TAG)
-// DMl/DMh: the 8 bytes at the cursor, read by the fourth lane at the end of the step before; DL: where the next step's go
+// On entry: this step's cell is on its way into v103 (requested by the step before, or the prologue), DMl/DMh get the
+// 8 bytes at the cursor (read by the fourth lane at the end of the step before), v128 holds the limit.  DL: where the
+// next step's window goes.
 #define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW)                                               \
     "L_q4_go" TAG "_%=:\n\t"                                                                                \
-    "v_lshl_add_u32 v200, %[s" SA "], 1, %[cb]\n\t"                                                         \
-    "ds_read_u16 v203, v200\n\t"                    /* the lane's cell */                                   \
-    "v_sub_u32 v228, 64, %[k]\n\t"                                                                          \
-    "v_min3_u32 v228, v228, %[rem1], %[left]\n\t"   /* limit = min(64 - k, rem + 1, steps before the last) */ \
-    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
+    "s_waitcnt lgkmcnt(3)\n\t"                      /* the cell (behind it: two queue writes, the ring read) */ \
+    "v_lshrrev_b32 v115, %[shr], v103\n\t"          /* code field */                                        \
+    "v_and_b32 v117, 0x3ff, v103\n\t"               /* next */                                              \
+    "v_cndmask_b32_e64 v131, v103, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
+    "v_ffbh_u32 v120, v117\n\t"                                                                             \
+    "v_sub_u32_e64 v115, v115, %[Kc] clamp\n\t"     /* ex */                                                \
+    "v_sub_u32 v129, 0, %[k]\n\t"                   /* -k */                                                \
+    "v_min_u32 v120, 0x4000000, v120\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
     "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_lshrrev_b32 v215, %[shr], v203\n\t"          /* code field */                                        \
-    "v_and_b32 v217, 0x3ff, v203\n\t"               /* next */                                              \
-    "v_mov_b32_dpp v210, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
-    "v_ffbh_u32 v220, v217\n\t"                                                                             \
-    "v_sub_u32_e64 v215, v215, %[Kc] clamp\n\t"     /* ex */                                                \
-    "v_mov_b32_dpp v211, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
-    "v_min_u32 v220, 0x4000000, v220\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
-    "v_cndmask_b32_e64 v231, v203, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
-    "v_sub_u32 v220, v220, %[nbK]\n\t"              /* nb */                                                \
-    "v_add_u32_dpp v221, v215, v215 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
-    "ds_write_b16 %[qca], v231 offset:" QC "\n\t"                                                           \
-    "v_sub_u32 v229, 0, %[k]\n\t"                   /* (filler with a use: -k) */                           \
-    "v_add_u32_dpp v222, v220, v220 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
-    "v_add_u32_dpp v223, v221, v221 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
-    "v_add_u32_dpp v224, v220, v222 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
-    "v_sub_u32 v229, v223, v229\n\t"                /* k + o3 */                                            \
-    "v_sub_u32 v225, 0, v224\n\t"                   /* -P */                                                \
-    "v_lshlrev_b64 v[212:213], v229, v[210:211]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
-    "v_add_u32_dpp v230, v224, v223 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
-    "v_bfe_u32 v226, v213, v225, v220\n\t"          /* the lane's state field */                            \
-    "v_cmp_lt_u32 vcc, v230, v228\n\t"              /* go (the same in the four lanes of a chain) */        \
-    "v_lshl_add_u32 %[s" SB "], v217, v220, v226\n\t" /* new state, in the OTHER register set */            \
-    "v_cndmask_b32 v230, 0, v230, vcc\n\t"                                                                  \
-    "v_sub_u32 %[rem1], %[rem1], v230\n\t"                                                                  \
-    "v_add_u32 %[k], %[k], v230\n\t"                                                                        \
-    "v_lshrrev_b32 v207, 3, %[k]\n\t"               /* normalise the cursor for the next step */            \
+    "v_sub_u32 v120, v120, %[nbK]\n\t"              /* nb */                                                \
+    "v_add_u32_dpp v121, v115, v115 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+    "s_waitcnt lgkmcnt(0)\n\t"                      /* the window */                                        \
+    "v_mov_b32_dpp v110, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_add_u32_dpp v122, v120, v120 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
+    "v_add_u32_dpp v123, v121, v121 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
+    "v_mov_b32_dpp v111, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_add_u32_dpp v124, v120, v122 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
+    "v_sub_u32 v129, v123, v129\n\t"                /* k + o3 */                                            \
+    "v_sub_u32 v125, 0, v124\n\t"                   /* -P */                                                \
+    "v_lshlrev_b64 v[112:113], v129, v[110:111]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
+    "v_add_u32_dpp v130, v124, v123 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
+    "v_bfe_u32 v126, v113, v125, v120\n\t"          /* the lane's state field */                            \
+    "v_lshl_add_u32 %[s" SB "], v117, v120, v126\n\t" /* new state, in the OTHER register set */            \
+    "v_cmp_lt_u32 vcc, v130, v128\n\t"              /* go (the same in the four lanes of a chain) */        \
+    "v_lshl_add_u32 v100, %[s" SB "], 1, %[cb]\n\t"                                                         \
+    "ds_read_u16 v103, v100\n\t"                    /* the NEXT step's cell; the rest of the step runs behind it */ \
+    "ds_write_b16 %[qca], v131 offset:" QC "\n\t"                                                           \
+    "v_cndmask_b32 v130, 0, v130, vcc\n\t"                                                                  \
+    "v_sub_u32 %[rem1], %[rem1], v130\n\t"                                                                  \
+    "v_add_u32 %[k], %[k], v130\n\t"                                                                        \
+    "v_lshrrev_b32 v107, 3, %[k]\n\t"               /* normalise the cursor for the next step */            \
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
-    "v_sub_u32 %[off], %[off], v207\n\t"                                                                    \
-    "v_and_b32 v209, 127, %[off]\n\t"                                                                       \
-    "v_add_u32 v209, v209, %[ringl]\n\t"                                                                    \
-    RLOW                                                                                                    \
+    "v_sub_u32 %[off], %[off], v107\n\t"                                                                    \
+    "v_sub_u32 v128, 64, %[k]\n\t"                                                                          \
+    "v_and_b32 v109, 127, %[off]\n\t"                                                                       \
+    "v_min3_u32 v128, v128, %[rem1], %[left]\n\t"   /* the next limit = min(64 - k, rem + 1, steps before the last) */ \
+    "v_add_u32 v109, v109, %[ringl]\n\t"                                                                    \
+    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
     "s_andn2_b64 %[smask], exec, vcc\n\t"           /* chains that need the general step; SCC = any */      \
     "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
-    "ds_write_b64 %[qwa], v[210:211] offset:" QW "\n\t" /* this step's window for stage B */                \
-    "ds_read_b64 " DL ", v209\n\t"                  /* the next step's window */                            \
+    "ds_write_b64 %[qwa], v[110:111] offset:" QW "\n\t" /* this step's window for stage B */                \
+    "ds_read_b64 " DL ", v109\n\t"                  /* the next step's window */                            \
     "s_mov_b64 exec, -1\n\t"                                                                                \
+    RLOW                                                                                                    \
     "s_cbranch_scc1 " OUT "\n\t"
 #define Q4_PUBLISH(OUT)                                                                                     \
-    "v_mov_b32 v202, %[i]\n\t"                                                                              \
-    "ds_write_b32 %[heada], v202\n\t"                                                                       \
+    "v_mov_b32 v102, %[i]\n\t"                                                                              \
+    "ds_write_b32 %[heada], v102\n\t"                                                                       \
     "s_cmp_lt_u32 %[i], %[nmax]\n\t"                                                                        \
     "s_cbranch_scc0 " OUT "\n\t"
 #define Q4_OUTE "L_q4_oute_%="
 #define Q4_OUTO "L_q4_outo_%="
-#define Q4_RLOW "ds_read_b32 v236, %[chan4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
-#define Q4_A "v232", "v233", "v[232:233]"
-#define Q4_B "v234", "v235", "v[234:235]"
+#define Q4_RLOW "ds_read_b32 v136, %[chan4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
                 asm volatile(
-                    // prologue: the window at the cursor into both pairs (fourth lanes), the entry's ring check, then the
-                    // instance of slot i % 8
-                    "v_and_b32 v209, 127, %[off]\n\t"
-                    "v_add_u32 v209, v209, %[ringl]\n\t"
-                    "v_mov_b32 v236, -1\n\t"  // no ring_low read ahead yet: the first batch check takes the slow path
-                    // the ring must hold the bytes at the cursor BEFORE they are read here (the very first entry: wave P may
-                    // not have filled anything yet; after a general step: the cursor has moved by more than a hot step)
+                    // prologue = what the tail of a step before would have done.  The ring must hold the bytes at the
+                    // cursor BEFORE they are read (the very first entry: wave P may not have filled anything yet; after a
+                    // general step: the cursor has moved by more than a hot step).
+                    "v_mov_b32 v136, -1\n\t"  // no ring_low read ahead yet: the first batch check takes the slow path
                     Q4_RINGCHK("e")
                     "L_q4_goe_%=:\n\t"
+                    "v_and_b32 v109, 127, %[off]\n\t"
+                    "v_sub_u32 v128, 64, %[k]\n\t"
+                    "v_add_u32 v109, v109, %[ringl]\n\t"
+                    "v_min3_u32 v128, v128, %[rem1], %[left]\n\t"
+                    "v_lshl_add_u32 v100, %[sa], 1, %[cb]\n\t"
+                    "v_add_u32 %[left], -1, %[left]\n\t"
+                    "ds_read_u16 v103, v100\n\t"
                     "s_mov_b64 exec, %[spare]\n\t"
-                    "ds_read_b64 v[232:233], v209\n\t"
-                    "ds_read_b64 v[234:235], v209\n\t"
+                    "ds_read_b64 v[132:133], v109\n\t"
+                    "ds_read_b64 v[134:135], v109\n\t"
                     "s_mov_b64 exec, -1\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
                     "s_and_b32 s86, %[i], 7\n\t"
                     "s_cmp_eq_u32 s86, 0\n\t"
                     "s_cbranch_scc1 L_q4_top0_%=\n\t"
@@ -513,17 +469,17 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     "s_cmp_eq_u32 s86, 6\n\t"
                     "s_cbranch_scc1 L_q4_go6_%=\n\t"
                     "s_branch L_q4_go7_%=\n"
-                    Q4_CHECK("0")
-                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_OUTE, "")
-                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_OUTO, "")
-                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_OUTE, "")
-                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_OUTO, Q4_RLOW)
+                    Q4_CHECK("0", "%[tail0]", "%[o_tail0]")
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_OUTE, "")
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_OUTO, "")
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_OUTE, "")
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_OUTO, Q4_RLOW)
                     Q4_PUBLISH(Q4_OUTO)
-                    Q4_CHECK("4")
-                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_OUTE, "")
-                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_OUTO, "")
-                    Q4_STEP("v232", "v233", "v[234:235]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_OUTE, "")
-                    Q4_STEP("v234", "v235", "v[232:233]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_OUTO, Q4_RLOW)
+                    Q4_CHECK("4", "%[tail1]", "%[o_tail1]")
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_OUTE, "")
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_OUTO, "")
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_OUTE, "")
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_OUTO, Q4_RLOW)
                     Q4_PUBLISH(Q4_OUTO)
                     "s_branch L_q4_top0_%=\n"
                     "L_q4_oute_%=:\n\t"  // left after an even slot: the new states are in set b
@@ -532,23 +488,25 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     "L_q4_outo_%=:\n\t"  // after an odd slot: old states in set b, new ones in set a
                     "v_cndmask_b32 %[sa], %[sb], %[sa], vcc\n"
                     "L_q4_done_%=:\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"  // the last step's ring read is still on its way into v232..v235
+                    "s_waitcnt lgkmcnt(0)\n\t"  // the speculative cell read and the ring read are still on their way
+                    // the limit computation of the last step counted `left` down for a step that was not done
+                    "v_add_u32 %[left], 1, %[left]\n\t"
                     : [sa] "+v"(st), [sb] "+v"(stb), [k] "+v"(wk), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(woff), [i] "+s"(i),
-                      [tail] "+s"(tail_seen), [polls] "+s"(polls), [smask] "=&s"(smask)
+                      [tail0] "+s"(tail0), [tail1] "+s"(tail1), [polls] "+s"(polls), [smask] "=&s"(smask)
                     : [cb] "v"(cb), [shr] "v"(shr), [Kc] "v"(Kc), [nbK] "v"(nbK), [ringl] "v"(ringl), [qca] "v"(qca), [qwa] "v"(qwa),
                       [chan4] "v"(chan4), [heada] "v"(heada), [vzero] "v"(vzero), [nmax] "s"(nmax), [spare] "s"(sparemask),
-                      [o_tail1] "n"(512 + offsetof(Q4Shared, tail1)), [o_prog] "n"(512 + offsetof(Q4Shared, progress)),
-                      [o_rlow] "n"(512 + offsetof(Q4Shared, ring_low)),
-#define Q4_QC(S) (512 + offsetof(Q4Shared, q1c) + (S) * 512)
-#define Q4_QW(S) (512 + offsetof(Q4Shared, q1w) + (S) * 512)
+                      [o_tail0] "n"(512 + offsetof(Q4Shared, tailB)), [o_tail1] "n"(512 + offsetof(Q4Shared, tailB) + 4),
+                      [o_prog] "n"(512 + offsetof(Q4Shared, progress)), [o_rlow] "n"(512 + offsetof(Q4Shared, ring_low)),
+#define Q4_QC(S) (512 + offsetof(Q4Shared, q1c) + (S) * kQ4Cols * 8)
+#define Q4_QW(S) (512 + offsetof(Q4Shared, q1w) + (S) * kQ4Cols * 8)
                       [qc0] "n"(Q4_QC(0)), [qc1] "n"(Q4_QC(1)), [qc2] "n"(Q4_QC(2)), [qc3] "n"(Q4_QC(3)),
                       [qc4] "n"(Q4_QC(4)), [qc5] "n"(Q4_QC(5)), [qc6] "n"(Q4_QC(6)), [qc7] "n"(Q4_QC(7)),
                       [qw0] "n"(Q4_QW(0)), [qw1] "n"(Q4_QW(1)), [qw2] "n"(Q4_QW(2)), [qw3] "n"(Q4_QW(3)),
                       [qw4] "n"(Q4_QW(4)), [qw5] "n"(Q4_QW(5)), [qw6] "n"(Q4_QW(6)), [qw7] "n"(Q4_QW(7))
                     : "memory", "vcc", "scc", "s86",
-                      "v200", "v201", "v202", "v203", "v207", "v209", "v210", "v211", "v212", "v213",
-                      "v215", "v217", "v220", "v221", "v222", "v223", "v224", "v225", "v226",
-                      "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236");
+                      "v100", "v101", "v102", "v103", "v107", "v109", "v110", "v111", "v112", "v113",
+                      "v115", "v117", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
+                      "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136");
 #undef Q4_STEP
 #undef Q4_CHECK
 #undef Q4_RINGCHK
@@ -556,21 +514,16 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #undef Q4_OUTE
 #undef Q4_OUTO
 #undef Q4_RLOW
-#undef Q4_A
-#undef Q4_B
 #undef Q4_QC
 #undef Q4_QW
             }
-#endif
-            // i has moved past the step; chains in smask have not done it yet (their `left` has been counted down: undo)
+            // i has moved past the step; chains in smask have not done it yet
             if (smask) {
                 const bool mine = ((smask >> lane) & 1) != 0;
 #ifdef MZD_Q4_STATS
                 n_general++;
 #endif
-                if (mine) left += 1u;
-                general_step(i - 1, mine);
-                if (mine && live) left -= 1u;
+                general_step(i - 1, mine);  // (`left` is already what the next step's limit needs: the asm exit put it back)
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -585,13 +538,23 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             atomicAdd(&g_q4_stats[5], (unsigned long long)n_general);
         }
 #endif
-        (void)wait_space; (void)polls; (void)q1c_lane; (void)q1w_chain; (void)vzero; (void)qca; (void)qwa; (void)chan4; (void)heada; (void)sparemask;
+        (void)polls;
         if (spare && has && t.n_seq > 0) shs->stA[ch] = status;
-    } else if (wave == 4) {
-        // ================= stage B: field extraction and values, four steps at a time =================
+    } else if (wave == 4 || wave == 5) {
+        // ================= stage B: field extraction and values, four steps at a time.  TWO wavefronts: wave 4 takes the
+        // even batches (queue slots 0..3), wave 5 the odd ones (slots 4..7) -- a wavefront issues an instruction every ~6
+        // cycles, and the ~55 of a stage-B step would otherwise be longer than stage A's step.
+        const uint32_t par = (uint32_t)wave - 4u;
+        const int col = min(lane, kQ4Cols - 1);  // lanes 56..63 have no column: they shadow the last one
         uint32_t head_seen = 0, tail_seen = 0;
-        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+#ifdef MZD_Q4_PROF
+        long long prof_in = 0, prof_out = 0, prof_t0 = clock64();
+#endif
+        for (uint32_t j0 = par * kPipeBatch; j0 < nmax; j0 += 2 * kPipeBatch) {
             const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+#ifdef MZD_Q4_PROF
+            const long long w0 = clock64();
+#endif
             while (head_seen < need) {
                 const uint32_t h0 = __hip_atomic_load(&shs->head1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t h1 = __hip_atomic_load(&shs->head1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -600,15 +563,18 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 head_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(min(h0, h1), min(h2, h3)));
                 if (head_seen < need) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef MZD_Q4_PROF
+            prof_in += clock64() - w0;
+#endif
             asm volatile("" ::: "memory");
             uint64_t T[kPipeBatch], Cq[kPipeBatch];
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
-                T[u] = shs->q1w[(j0 + u) % kPipeDepth][lane];
-                Cq[u] = *(const uint64_t *)&shs->q1c[(j0 + u) % kPipeDepth][lane][0];
+                T[u] = shs->q1w[(j0 + u) % kPipeDepth][col];
+                Cq[u] = *(const uint64_t *)&shs->q1c[(j0 + u) % kPipeDepth][col][0];
             }
             asm volatile("" ::: "memory");
-            __hip_atomic_store(&shs->tail1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&shs->tailB[par], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             uint64_t q[kPipeBatch];
 #ifdef MZD_EXP_FAST_BC  // timing experiment only (wrong results): what stage A can do when nothing holds it up
 #pragma unroll
@@ -634,57 +600,80 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 q[u] = (kk & 0x8000u) ? T[u] : v;
             }
 #endif
+#ifdef MZD_Q4_PROF
+            const long long w1 = clock64();
+#endif
+            // the four slots this wavefront writes were last used by ITS batch before (j0 - 8): free once stage C2 has stored it
             while (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) {
                 tail_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
                     (int)__hip_atomic_load(&shs->tail2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (j0 + (uint32_t)kPipeBatch - tail_seen > (uint32_t)kPipeDepth) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef MZD_Q4_PROF
+            prof_out += clock64() - w1;
+#endif
 #pragma unroll
-            for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][lane] = q[u];
+            for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][col] = q[u];
             asm volatile("" ::: "memory");
-            __hip_atomic_store(&shs->head2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&shs->head2[par], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    } else if (wave == 5) {
-        // ================= stage C: sums, offset history, records (as k_seq_pipe) =================
+#ifdef MZD_Q4_PROF
+        if (blockIdx.x == 0 && lane == 0) printf("B%u: cycles %lld wait_in %lld wait_out %lld (steps %u)\n", par, clock64() - prof_t0, prof_in, prof_out, nmax);
+#endif
+    } else if (wave == 6) {
+        // ================= stage C1: repeat-offset history (sequence_execution.go:65-114), record packing =================
+        // Branch-free per sequence: errors are sticky (a failed block's records, sums and history are never used), the
+        // history update is a chain of selects.  The steps that every chain of the workgroup still has (the first
+        // `ncommon`) skip the "is this chain still active" predicate.  The finished records go back into the queue slot
+        // they came from; stage C2 keeps the running sums and stores them (a wavefront issues an instruction every ~6
+        // cycles: sums, tile bases and the scattered stores on top of the history would make this stage's step longer
+        // than stage A's).
+        const int col = min(lane, kQ4Cols - 1);
         int h0, h1, h2;
         if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
         else { h0 = -1; h1 = -2; h2 = -3; }
-        uint32_t litPos = 0, outPos = 0;
-        uint32_t err_unsup = 0, err_off = 0, err_size = 0;
-        uint64_t *myrec = recs + t.rec_off;
-        TileBase *mytile = tiles + t.tile_off;
+        uint32_t max_ofv = 0, min_off = 0xFFFFFFFFu;
         const uint32_t my_n = has ? t.n_seq : 0u;
-        uint32_t head_seen = 0;
-        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+        const uint32_t ncommon = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(my_n ? my_n : 0xFFFFFFFFu)) & ~3u;
+        uint32_t head_seen0 = 0, head_seen1 = 0;
+#ifdef MZD_Q4_PROF
+        long long prof_in = 0, prof_t0 = clock64();
+#endif
+        auto batch = [&](uint32_t j0, auto checked_tag) {
+            constexpr bool CHECKED = decltype(checked_tag)::value;
             const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+            uint32_t &head_seen = (j0 & kPipeBatch) ? head_seen1 : head_seen0;
+#ifdef MZD_Q4_PROF
+            const long long w0 = clock64();
+#endif
             while (head_seen < need) {
                 head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
-                    (int)__hip_atomic_load(&shs->head2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    (int)__hip_atomic_load(&shs->head2[(j0 >> 2) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (head_seen < need) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef MZD_Q4_PROF
+            prof_in += clock64() - w0;
+#endif
             asm volatile("" ::: "memory");
             uint64_t q[kPipeBatch];
 #pragma unroll
-            for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][lane];
-            asm volatile("" ::: "memory");
-            __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][col];
 #ifdef MZD_EXP_FAST_BC
-            litPos += (uint32_t)(q[0] ^ q[1] ^ q[2] ^ q[3]);
-            continue;
+            max_ofv += (uint32_t)(q[0] ^ q[1] ^ q[2] ^ q[3]);
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->head3, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
 #endif
-            if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
-            uint64_t rr[kPipeBatch];
+            uint32_t rh[kPipeBatch];
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
                 const uint32_t j = j0 + u;
-                const bool act = j < my_n;
+                const bool act = !CHECKED || j < my_n;
                 const uint32_t lo = (uint32_t)q[u], hi = (uint32_t)(q[u] >> 32);
-                const uint32_t LL = lo & kRecLlMask;
-                const uint32_t ML = __builtin_amdgcn_alignbit(hi, lo, kRecMlShift) & kRecMlMask;
                 const uint32_t ofv = hi >> (kRecOffShift - 32);
                 // 0 = not active (history untouched), 1..4 = repeat cases 0..3, 5 = new offset
-                uint32_t idx = ofv > 3 ? 5u : ofv + (LL == 0 ? 1u : 0u);
-                idx = act ? idx : 0u;
+                uint32_t idx = ofv > 3 ? 5u : ofv + ((lo & kRecLlMask) == 0 ? 1u : 0u);
+                if (CHECKED) idx = act ? idx : 0u;
                 int off = (int)(ofv - 3);                 // idx 5
                 off = idx == 4 ? hist_dec(h0) : off;      // sequence_execution.go:65-114
                 off = idx == 3 ? h2 : off;
@@ -693,34 +682,98 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 h2 = idx >= 3 ? h1 : h2;
                 h1 = idx >= 2 ? h0 : h1;
                 h0 = idx >= 2 ? off : h0;
-                err_unsup |= act && ofv >= kRecOffSymbolic;  // offset value >= 2^28
-                err_off |= act && off == 0;
-                litPos += act ? LL : 0u;
-                outPos += act ? LL + ML : 0u;
-                err_size |= outPos > kBlockMax;  // a block regenerates <= 128 KiB
+                // errors, checked at the end: an offset value >= 2^28 (unsupported), a zero offset (ringbuffer.go:189)
+                max_ofv = max(max_ofv, CHECKED ? (act ? ofv : 0u) : ofv);
+                min_off = min(min_off, CHECKED ? (act ? (uint32_t)off : 0xFFFFFFFFu) : (uint32_t)off);
                 const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
-                rr[u] = (uint64_t)lo | ((uint64_t)((hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32))) << 32);
+                rh[u] = (hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32));
             }
+            // only the high dword of a record changes (offset value -> resolved offset)
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) ((uint32_t *)&shs->q2[(j0 + u) % kPipeDepth][col])[1] = rh[u];
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->head3, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        uint32_t j0 = 0;
+        for (; j0 < min(ncommon, nmax); j0 += kPipeBatch) batch(j0, std::false_type{});
+        for (; j0 < nmax; j0 += kPipeBatch) batch(j0, std::true_type{});
+#ifdef MZD_Q4_PROF
+        if (blockIdx.x == 0 && lane == 0) printf("C1: cycles %lld wait_in %lld (common steps %u)\n", clock64() - prof_t0, prof_in, ncommon);
+#endif
+        const int status = max_ofv >= kRecOffSymbolic ? MZD_ERR_UNSUPPORTED : (min_off == 0 ? MZD_ERR_OFFSET : MZD_OK);
+        if (has && t.n_seq > 0) {
+            BlockSum *bs = &sums[t.block];
+            bs->hist[0] = h0;
+            bs->hist[1] = h1;
+            bs->hist[2] = h2;
+        }
+        shs->stC[lane] = status;
+    } else if (wave == 7) {
+        // ================= stage C2: running sums, tile bases, and the finished records leave for HBM =================
+        // two 16-byte stores per lane and batch instead of four 8-byte ones (every store is a scatter over the chains'
+        // record streams)
+        const int col = min(lane, kQ4Cols - 1);
+        uint64_t *myrec = recs + t.rec_off;
+        TileBase *mytile = tiles + t.tile_off;
+        const uint32_t my_n = has ? t.n_seq : 0u;
+        uint32_t litPos = 0, outPos = 0, err_size = 0;
+        uint32_t head_seen = 0;
+#ifdef MZD_Q4_PROF
+        long long prof_in = 0, prof_t0 = clock64();
+#endif
+        for (uint32_t j0 = 0; j0 < nmax; j0 += kPipeBatch) {
+            const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
+#ifdef MZD_Q4_PROF
+            const long long w0 = clock64();
+#endif
+            while (head_seen < need) {
+                head_seen = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&shs->head3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head_seen < need) __builtin_amdgcn_s_sleep(1);
+            }
+#ifdef MZD_Q4_PROF
+            prof_in += clock64() - w0;
+#endif
+            asm volatile("" ::: "memory");
+            uint64_t rr[kPipeBatch];
+#pragma unroll
+            for (int u = 0; u < kPipeBatch; u++) rr[u] = shs->q2[(j0 + u) % kPipeDepth][col];
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef MZD_EXP_FAST_BC
+            if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
             if (j0 + (uint32_t)kPipeBatch <= my_n) {
+#pragma unroll
+                for (int u = 0; u < kPipeBatch; u++) {
+                    const uint32_t LL = (uint32_t)rr[u] & kRecLlMask, ML = (uint32_t)(rr[u] >> kRecMlShift) & kRecMlMask;
+                    litPos += LL;
+                    outPos += LL + ML;
+                }
                 typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8)));
                 *(u64x2 *)(myrec + j0) = u64x2{rr[0], rr[1]};
                 *(u64x2 *)(myrec + j0 + 2) = u64x2{rr[2], rr[3]};
             } else {
 #pragma unroll
                 for (int u = 0; u < kPipeBatch; u++)
-                    if (j0 + u < my_n) myrec[j0 + u] = rr[u];
+                    if (j0 + u < my_n) {
+                        const uint32_t LL = (uint32_t)rr[u] & kRecLlMask, ML = (uint32_t)(rr[u] >> kRecMlShift) & kRecMlMask;
+                        litPos += LL;
+                        outPos += LL + ML;
+                        myrec[j0 + u] = rr[u];
+                    }
             }
+            err_size |= outPos > kBlockMax;  // a block regenerates <= 128 KiB (four steps add < 2^21: no wrap between checks)
+#endif
         }
-        const int status = err_unsup ? MZD_ERR_UNSUPPORTED : (err_off ? MZD_ERR_OFFSET : (err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK));
+#ifdef MZD_Q4_PROF
+        if (blockIdx.x == 0 && lane == 0) printf("C2: cycles %lld wait_in %lld\n", clock64() - prof_t0, prof_in);
+#endif
         if (has && t.n_seq > 0) {
             BlockSum *bs = &sums[t.block];
             bs->lit_total = litPos;
             bs->out_total = outPos;
-            bs->hist[0] = h0;
-            bs->hist[1] = h1;
-            bs->hist[2] = h2;
         }
-        shs->stC[lane] = status;
+        shs->stC2[lane] = err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
     } else {
         // ================= wave P: the chains' bitstreams, ahead of stage A (as k_seq_pipe) =================
         const uint8_t *inb = in - MZD_IN_PAD;
@@ -771,9 +824,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     __syncthreads();
     // decode-stage errors come first, as in the reference, where DecodeSequences runs to its end
     // before ExecuteSequences starts
-    if (wave == 5 && has && t.n_seq > 0) {
+    if (wave == 6 && has && t.n_seq > 0) {
         int st = shs->stA[lane];
         if (st == MZD_OK) st = shs->stC[lane];
+        if (st == MZD_OK) st = shs->stC2[lane];
         if (st != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, st);
     }
 }
