@@ -59,6 +59,59 @@ __device__ __forceinline__ uint32_t dpp_quad(uint32_t v)  // quad_perm, all rows
 }
 constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 
+// What stage B hands stage C1 in a record's offset field: the repeat case already decided from the two things it depends
+// on (offset value, literal length == 0; sequence_execution.go:65-114) -- 1..4 = the history cases of q4_history_step,
+// >= 5 = a new offset of (code - 4).  Stage C1 is ONE wavefront walking every chain's history, an instruction every ~6
+// cycles: whatever does not need the history is computed a stage earlier.
+__device__ __forceinline__ uint32_t q4_offset_code(uint32_t ofv, uint32_t ll) { return ofv + ((ofv > 3 || ll == 0) ? 1u : 0u); }
+constexpr uint32_t kQ4SymBase = (kRecOffSymbolic << 3) - 8u;  // (symbolic | (-off - 1)) << 3 = kQ4SymBase - (off << 3)
+
+// One sequence of the repeat-offset history for every chain of the wavefront (lane = chain).  `hi` = high dword of the
+// record as stage B left it (ML bits 15..17 | offset code << 3); h0..h2 = the history, kept SHIFTED LEFT BY 3 like the
+// record's field (symbolic values of a block whose history is unknown are negative: -8, -16, -24); returns the finished
+// high dword.  maxv / minv collect the two error conditions (code too large; zero offset).  Hand-scheduled: the
+// compiler's version of the same selects puts every compare in an SGPR pair right before its use, and gfx950 wants two
+// wait states between a VALU write of a mask and the VALU read of it (an s_nop per select); here the five compares on
+// the code are issued together and none of the 26 instructions waits.
+__device__ __forceinline__ uint32_t q4_history_step(uint32_t hi, uint32_t &h0, uint32_t &h1, uint32_t &h2, uint32_t &maxv,
+                                                    uint32_t &minv)
+{
+    uint32_t rh, idx, nw, t, off;
+    unsigned long long m0, m1, m2, m3, m4;
+    asm volatile(
+        "v_lshrrev_b32 %[idx], 3, %[hi]\n\t"
+        "v_and_b32 %[nw], -8, %[hi]\n\t"
+        "v_cmp_lt_i32 vcc, 0, %[h0]\n\t"
+        "v_min_u32 %[idx], 5, %[idx]\n\t"              // 1..4: history cases, 5: new offset
+        "v_add_u32 %[nw], -32, %[nw]\n\t"              // new offset = code - 4
+        "v_cndmask_b32_e64 %[t], 32, 8, vcc\n\t"
+        "v_cmp_eq_u32_e64 %[m0], 4, %[idx]\n\t"
+        "v_cmp_eq_u32_e64 %[m1], 3, %[idx]\n\t"
+        "v_cmp_eq_u32_e64 %[m2], 2, %[idx]\n\t"
+        "v_cmp_gt_u32_e64 %[m3], 2, %[idx]\n\t"
+        "v_cmp_le_u32_e64 %[m4], 3, %[idx]\n\t"
+        "v_sub_u32 %[t], %[h0], %[t]\n\t"              // hist_dec(h0): h0 - 1, or h0 - 4 when symbolic
+        "v_cndmask_b32_e64 %[off], %[nw], %[t], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[off], %[off], %[h2], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[off], %[off], %[h1], %[m2]\n\t"
+        "v_cndmask_b32_e64 %[off], %[off], %[h0], %[m3]\n\t"
+        "v_cmp_lt_i32 vcc, 0, %[off]\n\t"
+        "v_sub_u32 %[t], %[symbase], %[off]\n\t"
+        "v_cndmask_b32_e64 %[h2], %[h2], %[h1], %[m4]\n\t"
+        "v_cndmask_b32_e64 %[h1], %[h0], %[h1], %[m3]\n\t"
+        "v_cndmask_b32_e64 %[h0], %[off], %[h0], %[m3]\n\t"
+        "v_cndmask_b32_e32 %[t], %[t], %[off], vcc\n\t"
+        "v_max_u32 %[maxv], %[maxv], %[hi]\n\t"
+        "v_min_u32 %[minv], %[minv], %[off]\n\t"
+        "v_bfi_b32 %[rh], 7, %[hi], %[t]"
+        : [rh] "=&v"(rh), [idx] "=&v"(idx), [nw] "=&v"(nw), [t] "=&v"(t), [off] "=&v"(off), [m0] "=&s"(m0), [m1] "=&s"(m1),
+          [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [maxv] "+v"(maxv),
+          [minv] "+v"(minv)
+        : [hi] "v"(hi), [symbase] "s"(kQ4SymBase)
+        : "vcc");
+    return rh;
+}
+
 __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                                        uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                                        uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
@@ -277,9 +330,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     remi -= total;
                     gL = (nl << nbL) + aL; gM = (nm << nbM) + aM; gO = (no << nbO) + aO;  // fse.go:282-290
                     const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
-                    shs->q1w[idx % kPipeDepth][ch] = (uint64_t)((cl & 0xFFFFFF) + llx) |
-                                                     ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
-                                                     ((uint64_t)ofv << kRecOffShift);
+                    const uint32_t llv = (cl & 0xFFFFFF) + llx;
+                    shs->q1w[idx % kPipeDepth][ch] = (uint64_t)llv | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                                     ((uint64_t)q4_offset_code(ofv, llv) << kRecOffShift);
                     shs->q1c[idx % kPipeDepth][ch][3] = 0x8000u;
                     woff = off + 8u;
                     wk = (uint32_t)k;
@@ -595,8 +648,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 const uint32_t mlx = __builtin_amdgcn_ubfe(Y, 32u - exM, exM);
                 const uint32_t llx = __builtin_amdgcn_ubfe(Y, 32u - exM - exL, exL);
                 const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
-                const uint64_t v = (uint64_t)((cl & 0xFFFFFF) + llx) | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
-                                   ((uint64_t)ofv << kRecOffShift);
+                const uint32_t llv = (cl & 0xFFFFFF) + llx;
+                const uint64_t v = (uint64_t)llv | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                   ((uint64_t)q4_offset_code(ofv, llv) << kRecOffShift);
                 q[u] = (kk & 0x8000u) ? T[u] : v;
             }
 #endif
@@ -629,10 +683,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         // cycles: sums, tile bases and the scattered stores on top of the history would make this stage's step longer
         // than stage A's).
         const int col = min(lane, kQ4Cols - 1);
-        int h0, h1, h2;
-        if (t.hist_known) { h0 = 1; h1 = 4; h2 = 8; }  // framedecompressor.go:48,59
-        else { h0 = -1; h1 = -2; h2 = -3; }
-        uint32_t max_ofv = 0, min_off = 0xFFFFFFFFu;
+        uint32_t h0, h1, h2;  // shifted left by 3, as the offset field sits in a record's high dword
+        if (t.hist_known) { h0 = 1u << 3; h1 = 4u << 3; h2 = 8u << 3; }  // framedecompressor.go:48,59
+        else { h0 = (uint32_t)-1 << 3; h1 = (uint32_t)-2 << 3; h2 = (uint32_t)-3 << 3; }
+        uint32_t maxv = 0, minv = 0xFFFFFFFFu;
         const uint32_t my_n = has ? t.n_seq : 0u;
         const uint32_t ncommon = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(my_n ? my_n : 0xFFFFFFFFu)) & ~3u;
         uint32_t head_seen0 = 0, head_seen1 = 0;
@@ -655,11 +709,11 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             prof_in += clock64() - w0;
 #endif
             asm volatile("" ::: "memory");
-            uint64_t q[kPipeBatch];
+            uint32_t qh[kPipeBatch];  // only the high dword of a record changes (offset code -> resolved offset)
 #pragma unroll
-            for (int u = 0; u < kPipeBatch; u++) q[u] = shs->q2[(j0 + u) % kPipeDepth][col];
+            for (int u = 0; u < kPipeBatch; u++) qh[u] = ((const uint32_t *)&shs->q2[(j0 + u) % kPipeDepth][col])[1];
 #ifdef MZD_EXP_FAST_BC
-            max_ofv += (uint32_t)(q[0] ^ q[1] ^ q[2] ^ q[3]);
+            maxv += qh[0] ^ qh[1] ^ qh[2] ^ qh[3];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->head3, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return;
@@ -667,28 +721,26 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             uint32_t rh[kPipeBatch];
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) {
-                const uint32_t j = j0 + u;
-                const bool act = !CHECKED || j < my_n;
-                const uint32_t lo = (uint32_t)q[u], hi = (uint32_t)(q[u] >> 32);
-                const uint32_t ofv = hi >> (kRecOffShift - 32);
-                // 0 = not active (history untouched), 1..4 = repeat cases 0..3, 5 = new offset
-                uint32_t idx = ofv > 3 ? 5u : ofv + ((lo & kRecLlMask) == 0 ? 1u : 0u);
-                if (CHECKED) idx = act ? idx : 0u;
-                int off = (int)(ofv - 3);                 // idx 5
-                off = idx == 4 ? hist_dec(h0) : off;      // sequence_execution.go:65-114
-                off = idx == 3 ? h2 : off;
-                off = idx == 2 ? h1 : off;
-                off = idx <= 1 ? h0 : off;
-                h2 = idx >= 3 ? h1 : h2;
-                h1 = idx >= 2 ? h0 : h1;
-                h0 = idx >= 2 ? off : h0;
-                // errors, checked at the end: an offset value >= 2^28 (unsupported), a zero offset (ringbuffer.go:189)
-                max_ofv = max(max_ofv, CHECKED ? (act ? ofv : 0u) : ofv);
-                min_off = min(min_off, CHECKED ? (act ? (uint32_t)off : 0xFFFFFFFFu) : (uint32_t)off);
-                const uint32_t offfield = off > 0 ? (uint32_t)off : (kRecOffSymbolic | (uint32_t)(-off - 1));
-                rh[u] = (hi & ((1u << (kRecOffShift - 32)) - 1)) | (offfield << (kRecOffShift - 32));
+                if (!CHECKED) {
+                    rh[u] = q4_history_step(qh[u], h0, h1, h2, maxv, minv);
+                } else {
+                    // the same step for the chains that still have a sequence j0 + u; the others keep their history
+                    const bool act = j0 + u < my_n;
+                    const uint32_t hi = qh[u];
+                    const uint32_t idx = act ? min(hi >> 3, 5u) : 0u;
+                    uint32_t off = (hi & ~7u) - 32u;                                       // new offset
+                    off = idx == 4 ? ((int)h0 > 0 ? h0 - 8u : h0 - 32u) : off;             // sequence_execution.go:65-114
+                    off = idx == 3 ? h2 : off;
+                    off = idx == 2 ? h1 : off;
+                    off = idx <= 1 ? h0 : off;
+                    h2 = idx >= 3 ? h1 : h2;
+                    h1 = idx >= 2 ? h0 : h1;
+                    h0 = idx >= 2 ? off : h0;
+                    maxv = max(maxv, act ? hi : 0u);
+                    minv = min(minv, act ? off : 0xFFFFFFFFu);
+                    rh[u] = (hi & 7u) | ((int)off > 0 ? off : kQ4SymBase - off);
+                }
             }
-            // only the high dword of a record changes (offset value -> resolved offset)
 #pragma unroll
             for (int u = 0; u < kPipeBatch; u++) ((uint32_t *)&shs->q2[(j0 + u) % kPipeDepth][col])[1] = rh[u];
             asm volatile("" ::: "memory");
@@ -700,12 +752,13 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_Q4_PROF
         if (blockIdx.x == 0 && lane == 0) printf("C1: cycles %lld wait_in %lld (common steps %u)\n", clock64() - prof_t0, prof_in, ncommon);
 #endif
-        const int status = max_ofv >= kRecOffSymbolic ? MZD_ERR_UNSUPPORTED : (min_off == 0 ? MZD_ERR_OFFSET : MZD_OK);
+        // errors: an offset value >= 2^28 (unsupported; its code is one more), a zero offset (ringbuffer.go:189)
+        const int status = (maxv >> 3) > kRecOffSymbolic ? MZD_ERR_UNSUPPORTED : (minv == 0 ? MZD_ERR_OFFSET : MZD_OK);
         if (has && t.n_seq > 0) {
             BlockSum *bs = &sums[t.block];
-            bs->hist[0] = h0;
-            bs->hist[1] = h1;
-            bs->hist[2] = h2;
+            bs->hist[0] = (int)h0 >> 3;
+            bs->hist[1] = (int)h1 >> 3;
+            bs->hist[2] = (int)h2 >> 3;
         }
         shs->stC[lane] = status;
     } else if (wave == 7) {
