@@ -375,18 +375,26 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         const long long stats_t0 = clock64();
         uint32_t n_general = 0;
 #endif
+        // Steps [0, ncom) are more than 64 steps away from every chain's last sequence: "steps before the last" cannot be the
+        // smallest term of a step's limit (64 - k is at most 64) and the loop variant that runs them leaves it out.
+        const uint32_t min_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(live ? last_i : 0xFFFFFFFFu));
+        const uint32_t ncom = min_last >= 64u ? min((min_last - 64u) & ~3u, nmax & ~3u) : 0u;
         while (i < nmax) {
             uint64_t smask = 0;
             {
-                // The step, hand-scheduled (~44 instructions; k_seq_pipe's: ~66; a lone wavefront issues one instruction
+                // The step, hand-scheduled (~41 instructions; k_seq_pipe's: ~66; a lone wavefront issues one instruction
                 // per ~6 cycles whatever its kind, so the count IS the step).  The loop body is the step EIGHT times, one
                 // instance per queue slot, as in k_seq_pipe: slot addresses are immediates, queue space / the ring / the
-                // cursor for wave P are dealt with once per batch of four steps, head1 is published and nmax checked at the
-                // end of a batch.  A step requests the NEXT step's cell as soon as it has the new state (speculatively: a
+                // cursor for wave P are dealt with once per batch of four steps, the step counter moves, head1 is
+                // published and the end checked at the end of a batch (a step that leaves the loop adds its own position
+                // in the batch).  A step requests the NEXT step's cell as soon as it has the new state (speculatively: a
                 // chain that does not "go" reads with a meaningless state; LDS reads outside the allocation return zero)
-                // and does its bookkeeping behind that read.  DPP reads of a VGPR keep two instructions' distance from
-                // the VALU write of it (the hardware does not interlock that; nothing inside an asm statement is padded
-                // by the compiler).  Temporaries are fixed registers v100..v136 / s86.
+                // and does its bookkeeping behind that read.  The window is read and handed to stage B by the fourth lanes only
+                // (exec switched twice per step: letting all four lanes of a chain do it -- same data, same queue address,
+                // the other three reading an aligned address -- saves two instructions and was 40 % SLOWER: the LDS pipe
+                // is too full for 64-lane 8-byte accesses).  DPP reads of a VGPR keep
+                // two instructions' distance from the VALU write of it (the hardware does not interlock that; nothing
+                // inside an asm statement is padded by the compiler).  Temporaries are fixed registers v100..v136 / s86.
                 static_assert(kPipeDepth == 8 && kPipeBatch == 4 && kPipeRing == 128, "the unrolled loop assumes 2 batches of 4 slots, a 128-byte ring");
                 uint32_t stb = st;  // the states alternate between two register sets
                 // (wave-uniform by construction; said explicitly, or the "s" operands below are refused)
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 tail0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail0);
                 tail1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail1);
                 polls = (uint32_t)__builtin_amdgcn_readfirstlane((int)polls);
+                if (live) left = last_i - i;
 #define Q4_RINGCHK(TAG)                                                                                     \
     "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n"                                                      \
     "L_q4_ring" TAG "_%=:\n\t"                                                                              \
@@ -430,9 +439,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     Q4_RINGCHK(TAG)
 // On entry: this step's cell is on its way into v103 (requested by the step before, or the prologue), DMl/DMh get the
-// 8 bytes at the cursor (read by the fourth lane at the end of the step before), v128 holds the limit.  DL: where the
-// next step's window goes.
-#define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW)                                               \
+// 8 bytes at the cursor (read at the end of the step before), v128 holds the limit.  DL: where the next step's window
+// goes.  LIMIT: the instruction(s) that finish the next step's limit in v128 (from 64 - k).
+#define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                        \
     "L_q4_go" TAG "_%=:\n\t"                                                                                \
     "s_waitcnt lgkmcnt(3)\n\t"                      /* the cell (behind it: two queue writes, the ring read) */ \
     "v_lshrrev_b32 v115, %[shr], v103\n\t"          /* code field */                                        \
@@ -440,9 +449,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "v_cndmask_b32_e64 v131, v103, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
     "v_ffbh_u32 v120, v117\n\t"                                                                             \
     "v_sub_u32_e64 v115, v115, %[Kc] clamp\n\t"     /* ex */                                                \
-    "v_sub_u32 v129, 0, %[k]\n\t"                   /* -k */                                                \
     "v_min_u32 v120, 0x4000000, v120\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
-    "s_add_u32 %[i], %[i], 1\n\t"                                                                           \
     "v_sub_u32 v120, v120, %[nbK]\n\t"              /* nb */                                                \
     "v_add_u32_dpp v121, v115, v115 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
     "s_waitcnt lgkmcnt(0)\n\t"                      /* the window */                                        \
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "v_add_u32_dpp v123, v121, v121 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
     "v_mov_b32_dpp v111, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
     "v_add_u32_dpp v124, v120, v122 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
-    "v_sub_u32 v129, v123, v129\n\t"                /* k + o3 */                                            \
+    "v_add_u32 v129, v123, %[k]\n\t"                /* k + o3 */                                            \
     "v_sub_u32 v125, 0, v124\n\t"                   /* -P */                                                \
     "v_lshlrev_b64 v[112:113], v129, v[110:111]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
     "v_add_u32_dpp v130, v124, v123 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
@@ -468,10 +475,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
     "v_sub_u32 %[off], %[off], v107\n\t"                                                                    \
     "v_sub_u32 v128, 64, %[k]\n\t"                                                                          \
-    "v_and_b32 v109, 127, %[off]\n\t"                                                                       \
-    "v_min3_u32 v128, v128, %[rem1], %[left]\n\t"   /* the next limit = min(64 - k, rem + 1, steps before the last) */ \
+    "v_and_b32 v109, 127, %[off]\n\t"                                                                   \
+    LIMIT                                           /* the next limit = min(64 - k, rem + 1[, steps before the last]) */ \
     "v_add_u32 v109, v109, %[ringl]\n\t"                                                                    \
-    "v_add_u32 %[left], -1, %[left]\n\t"                                                                    \
     "s_andn2_b64 %[smask], exec, vcc\n\t"           /* chains that need the general step; SCC = any */      \
     "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
     "ds_write_b64 %[qwa], v[110:111] offset:" QW "\n\t" /* this step's window for stage B */                \
@@ -480,91 +486,116 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     RLOW                                                                                                    \
     "s_cbranch_scc1 " OUT "\n\t"
 #define Q4_PUBLISH(OUT)                                                                                     \
+    "s_add_u32 %[i], %[i], 4\n\t"                                                                           \
     "v_mov_b32 v102, %[i]\n\t"                                                                              \
     "ds_write_b32 %[heada], v102\n\t"                                                                       \
     "s_cmp_lt_u32 %[i], %[nmax]\n\t"                                                                        \
     "s_cbranch_scc0 " OUT "\n\t"
-#define Q4_OUTE "L_q4_oute_%="
+#define Q4_X1 "L_q4_x1_%="
+#define Q4_X2 "L_q4_x2_%="
+#define Q4_X3 "L_q4_x3_%="
+#define Q4_X4 "L_q4_x4_%="
 #define Q4_OUTO "L_q4_outo_%="
 #define Q4_RLOW "ds_read_b32 v136, %[chan4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
-                asm volatile(
-                    // prologue = what the tail of a step before would have done.  The ring must hold the bytes at the
-                    // cursor BEFORE they are read (the very first entry: wave P may not have filled anything yet; after a
-                    // general step: the cursor has moved by more than a hot step).
-                    "v_mov_b32 v136, -1\n\t"  // no ring_low read ahead yet: the first batch check takes the slow path
-                    Q4_RINGCHK("e")
-                    "L_q4_goe_%=:\n\t"
-                    "v_and_b32 v109, 127, %[off]\n\t"
-                    "v_sub_u32 v128, 64, %[k]\n\t"
-                    "v_add_u32 v109, v109, %[ringl]\n\t"
-                    "v_min3_u32 v128, v128, %[rem1], %[left]\n\t"
-                    "v_lshl_add_u32 v100, %[sa], 1, %[cb]\n\t"
-                    "v_add_u32 %[left], -1, %[left]\n\t"
-                    "ds_read_u16 v103, v100\n\t"
-                    "s_mov_b64 exec, %[spare]\n\t"
-                    "ds_read_b64 v[132:133], v109\n\t"
-                    "ds_read_b64 v[134:135], v109\n\t"
-                    "s_mov_b64 exec, -1\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "s_and_b32 s86, %[i], 7\n\t"
-                    "s_cmp_eq_u32 s86, 0\n\t"
-                    "s_cbranch_scc1 L_q4_top0_%=\n\t"
-                    "s_cmp_eq_u32 s86, 1\n\t"
-                    "s_cbranch_scc1 L_q4_go1_%=\n\t"
-                    "s_cmp_eq_u32 s86, 2\n\t"
-                    "s_cbranch_scc1 L_q4_go2_%=\n\t"
-                    "s_cmp_eq_u32 s86, 3\n\t"
-                    "s_cbranch_scc1 L_q4_go3_%=\n\t"
-                    "s_cmp_eq_u32 s86, 4\n\t"
-                    "s_cbranch_scc1 L_q4_top4_%=\n\t"
-                    "s_cmp_eq_u32 s86, 5\n\t"
-                    "s_cbranch_scc1 L_q4_go5_%=\n\t"
-                    "s_cmp_eq_u32 s86, 6\n\t"
-                    "s_cbranch_scc1 L_q4_go6_%=\n\t"
-                    "s_branch L_q4_go7_%=\n"
-                    Q4_CHECK("0", "%[tail0]", "%[o_tail0]")
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_OUTE, "")
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_OUTO, "")
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_OUTE, "")
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_OUTO, Q4_RLOW)
-                    Q4_PUBLISH(Q4_OUTO)
-                    Q4_CHECK("4", "%[tail1]", "%[o_tail1]")
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_OUTE, "")
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_OUTO, "")
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_OUTE, "")
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_OUTO, Q4_RLOW)
-                    Q4_PUBLISH(Q4_OUTO)
-                    "s_branch L_q4_top0_%=\n"
-                    "L_q4_oute_%=:\n\t"  // left after an even slot: the new states are in set b
-                    "v_cndmask_b32 %[sa], %[sa], %[sb], vcc\n\t"  // vcc is still the last step's "go"
-                    "s_branch L_q4_done_%=\n"
-                    "L_q4_outo_%=:\n\t"  // after an odd slot: old states in set b, new ones in set a
-                    "v_cndmask_b32 %[sa], %[sb], %[sa], vcc\n"
-                    "L_q4_done_%=:\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"  // the speculative cell read and the ring read are still on their way
-                    // the limit computation of the last step counted `left` down for a step that was not done
-                    "v_add_u32 %[left], 1, %[left]\n\t"
-                    : [sa] "+v"(st), [sb] "+v"(stb), [k] "+v"(wk), [rem1] "+v"(rem1), [left] "+v"(left), [off] "+v"(woff), [i] "+s"(i),
-                      [tail0] "+s"(tail0), [tail1] "+s"(tail1), [polls] "+s"(polls), [smask] "=&s"(smask)
-                    : [cb] "v"(cb), [shr] "v"(shr), [Kc] "v"(Kc), [nbK] "v"(nbK), [ringl] "v"(ringl), [qca] "v"(qca), [qwa] "v"(qwa),
-                      [chan4] "v"(chan4), [heada] "v"(heada), [vzero] "v"(vzero), [nmax] "s"(nmax), [spare] "s"(sparemask),
-                      [o_tail0] "n"(512 + offsetof(Q4Shared, tailB)), [o_tail1] "n"(512 + offsetof(Q4Shared, tailB) + 4),
-                      [o_prog] "n"(512 + offsetof(Q4Shared, progress)), [o_rlow] "n"(512 + offsetof(Q4Shared, ring_low)),
 #define Q4_QC(S) (512 + offsetof(Q4Shared, q1c) + (S) * kQ4Cols * 8)
 #define Q4_QW(S) (512 + offsetof(Q4Shared, q1w) + (S) * kQ4Cols * 8)
-                      [qc0] "n"(Q4_QC(0)), [qc1] "n"(Q4_QC(1)), [qc2] "n"(Q4_QC(2)), [qc3] "n"(Q4_QC(3)),
-                      [qc4] "n"(Q4_QC(4)), [qc5] "n"(Q4_QC(5)), [qc6] "n"(Q4_QC(6)), [qc7] "n"(Q4_QC(7)),
-                      [qw0] "n"(Q4_QW(0)), [qw1] "n"(Q4_QW(1)), [qw2] "n"(Q4_QW(2)), [qw3] "n"(Q4_QW(3)),
-                      [qw4] "n"(Q4_QW(4)), [qw5] "n"(Q4_QW(5)), [qw6] "n"(Q4_QW(6)), [qw7] "n"(Q4_QW(7))
-                    : "memory", "vcc", "scc", "s86",
-                      "v100", "v101", "v102", "v103", "v107", "v109", "v110", "v111", "v112", "v113",
-                      "v115", "v117", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
-                      "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136");
+#define Q4_HOT_LOOP(LIMIT, BOUND)                                                                                       \
+                asm volatile(                                                                                           \
+                    /* prologue = what the tail of a step before would have done.  The ring must hold the bytes at the  \
+                       cursor BEFORE they are read (the very first entry: wave P may not have filled anything yet;      \
+                       after a general step: the cursor has moved by more than a hot step). */                          \
+                    "v_mov_b32 v136, -1\n\t"  /* no ring_low read ahead yet: the first batch check takes the slow path */ \
+                    Q4_RINGCHK("e")                                                                                     \
+                    "L_q4_goe_%=:\n\t"                                                                                  \
+                    "v_and_b32 v109, 127, %[off]\n\t"                                                               \
+                    "v_sub_u32 v128, 64, %[k]\n\t"                                                                      \
+                    "v_add_u32 v109, v109, %[ringl]\n\t"                                                                \
+                    LIMIT                                                                                               \
+                    "v_lshl_add_u32 v100, %[sa], 1, %[cb]\n\t"                                                          \
+                    "ds_read_u16 v103, v100\n\t"                                                                        \
+                    "s_mov_b64 exec, %[spare]\n\t"                                                                      \
+                    "ds_read_b64 v[132:133], v109\n\t"                                                                  \
+                    "ds_read_b64 v[134:135], v109\n\t"                                                                  \
+                    "s_mov_b64 exec, -1\n\t"                                                                            \
+                    "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                    "s_and_b32 s86, %[i], 7\n\t"                                                                        \
+                    "s_and_b32 %[i], %[i], -4\n\t" /* inside the loop the counter stands at the start of the batch */   \
+                    "s_cmp_eq_u32 s86, 0\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_top0_%=\n\t"                                                                   \
+                    "s_cmp_eq_u32 s86, 1\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_go1_%=\n\t"                                                                    \
+                    "s_cmp_eq_u32 s86, 2\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_go2_%=\n\t"                                                                    \
+                    "s_cmp_eq_u32 s86, 3\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_go3_%=\n\t"                                                                    \
+                    "s_cmp_eq_u32 s86, 4\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_top4_%=\n\t"                                                                   \
+                    "s_cmp_eq_u32 s86, 5\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_go5_%=\n\t"                                                                    \
+                    "s_cmp_eq_u32 s86, 6\n\t"                                                                           \
+                    "s_cbranch_scc1 L_q4_go6_%=\n\t"                                                                    \
+                    "s_branch L_q4_go7_%=\n"                                                                            \
+                    Q4_CHECK("0", "%[tail0]", "%[o_tail0]")                                                             \
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_PUBLISH(Q4_OUTO)                                                                                 \
+                    Q4_CHECK("4", "%[tail1]", "%[o_tail1]")                                                             \
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_PUBLISH(Q4_OUTO)                                                                                 \
+                    "s_branch L_q4_top0_%=\n"                                                                           \
+                    /* a step that leaves: the counter moves past it; after the first / third step of a batch the new   \
+                       states are in set b, after the second / fourth in set a (vcc is still the step's "go") */         \
+                    "L_q4_x1_%=:\n\t"                                                                                   \
+                    "s_add_u32 %[i], %[i], 1\n\t"                                                                       \
+                    "s_branch L_q4_oute_%=\n"                                                                           \
+                    "L_q4_x3_%=:\n\t"                                                                                   \
+                    "s_add_u32 %[i], %[i], 3\n"                                                                         \
+                    "L_q4_oute_%=:\n\t"                                                                                 \
+                    "v_cndmask_b32 %[sa], %[sa], %[sb], vcc\n\t"                                                        \
+                    "s_branch L_q4_done_%=\n"                                                                           \
+                    "L_q4_x2_%=:\n\t"                                                                                   \
+                    "s_add_u32 %[i], %[i], 2\n\t"                                                                       \
+                    "s_branch L_q4_outo_%=\n"                                                                           \
+                    "L_q4_x4_%=:\n\t"                                                                                   \
+                    "s_add_u32 %[i], %[i], 4\n"                                                                         \
+                    "L_q4_outo_%=:\n\t"                                                                                 \
+                    "v_cndmask_b32 %[sa], %[sb], %[sa], vcc\n"                                                          \
+                    "L_q4_done_%=:\n\t"                                                                                 \
+                    "s_waitcnt lgkmcnt(0)\n\t"  /* the speculative cell read and the ring read are still on their way */ \
+                    : [sa] "+v"(st), [sb] "+v"(stb), [k] "+v"(wk), [rem1] "+v"(rem1), [off] "+v"(woff), [i] "+s"(i),    \
+                      [left] "+v"(left), [tail0] "+s"(tail0), [tail1] "+s"(tail1), [polls] "+s"(polls), [smask] "=&s"(smask)               \
+                    : [cb] "v"(cb), [shr] "v"(shr), [Kc] "v"(Kc), [nbK] "v"(nbK), [ringl] "v"(ringl), [qca] "v"(qca), [qwa] "v"(qwa), \
+                      [chan4] "v"(chan4), [heada] "v"(heada), [vzero] "v"(vzero),                                       \
+                      [nmax] "s"(BOUND), [spare] "s"(sparemask),                                                       \
+                      [o_tail0] "n"(512 + offsetof(Q4Shared, tailB)), [o_tail1] "n"(512 + offsetof(Q4Shared, tailB) + 4), \
+                      [o_prog] "n"(512 + offsetof(Q4Shared, progress)), [o_rlow] "n"(512 + offsetof(Q4Shared, ring_low)), \
+                      [qc0] "n"(Q4_QC(0)), [qc1] "n"(Q4_QC(1)), [qc2] "n"(Q4_QC(2)), [qc3] "n"(Q4_QC(3)),               \
+                      [qc4] "n"(Q4_QC(4)), [qc5] "n"(Q4_QC(5)), [qc6] "n"(Q4_QC(6)), [qc7] "n"(Q4_QC(7)),               \
+                      [qw0] "n"(Q4_QW(0)), [qw1] "n"(Q4_QW(1)), [qw2] "n"(Q4_QW(2)), [qw3] "n"(Q4_QW(3)),               \
+                      [qw4] "n"(Q4_QW(4)), [qw5] "n"(Q4_QW(5)), [qw6] "n"(Q4_QW(6)), [qw7] "n"(Q4_QW(7))                \
+                    : "memory", "vcc", "scc", "s86",                                                                    \
+                      "v100", "v101", "v102", "v103", "v107", "v109", "v110", "v111", "v112", "v113",                   \
+                      "v115", "v117", "v120", "v121", "v122", "v123", "v124", "v125", "v126",                           \
+                      "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136")
+                if (i < ncom) {
+                    Q4_HOT_LOOP("v_min_u32 v128, v128, %[rem1]\n\t", ncom);
+                } else {
+                    Q4_HOT_LOOP("v_min3_u32 v128, v128, %[rem1], %[left]\n\tv_add_u32 %[left], -1, %[left]\n\t", nmax);
+                }
+#undef Q4_HOT_LOOP
 #undef Q4_STEP
 #undef Q4_CHECK
 #undef Q4_RINGCHK
 #undef Q4_PUBLISH
-#undef Q4_OUTE
+#undef Q4_X1
+#undef Q4_X2
+#undef Q4_X3
+#undef Q4_X4
 #undef Q4_OUTO
 #undef Q4_RLOW
 #undef Q4_QC
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_Q4_STATS
                 n_general++;
 #endif
-                general_step(i - 1, mine);  // (`left` is already what the next step's limit needs: the asm exit put it back)
+                general_step(i - 1, mine);
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
