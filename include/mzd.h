@@ -201,7 +201,9 @@ int mzd_device_count(void);
 
 /* Tuning knobs (0 == default). */
 typedef struct mzd_options {
-    uint32_t seq_variant;     /* 0: k_seq_pipe (three-stage pipeline, default); 1: k_seq (two wavefronts); see DESIGN.md */
+    uint32_t seq_variant;     /* sequence decoder: 0 default (= 2); 1: k_seq (two wavefronts per 16 chains); 2: k_seq_q4
+                                 (four lanes per chain, five-stage pipeline); 3: k_seq_pipe (one lane per chain, three
+                                 stages); see DESIGN.md */
     uint32_t exec_threads;    /* threads per frame in the execution kernel (multiple of 64) */
     uint32_t exec_chunk;      /* LDS window chunk of the execution kernel in bytes (multiple of 1024) */
     uint32_t huf_min_lds;     /* minimum LDS bytes requested per Huffman workgroup (residency cap) */

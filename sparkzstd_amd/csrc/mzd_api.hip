@@ -1121,11 +1121,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // the last, partial round leaves most CUs idle.  The batch is cut at the frame where the full rounds
     // end: k_seq(tail) then runs on the caller's stream while k_exec(head) fills the idle CUs from a
     // second stream (frames are independent, so the two never touch the same data).
-    // seq_variant 0 (default): k_seq_pipe; 1: k_seq, the two-wavefront kernel.  k_seq_pipe addresses the
-    // bitstreams with 32-bit offsets from the blob's front slack, so larger blobs take k_seq as well.
-    if (ctx->opt.seq_variant > 2 || ctx->opt.huf_variant > 2) return MZD_ERR_INVALID_ARG;
-    const bool pipe = ctx->opt.seq_variant != 1;  // 0: k_seq_pipe, 2: k_seq_q4 (both address a window of the blob); 1: k_seq
-    const bool q4 = ctx->opt.seq_variant == 2;
+    // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
+    // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 2) return MZD_ERR_INVALID_ARG;
+    const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
+    const bool pipe = sv != 1;  // the kernels that address a window of the blob
+    const bool q4 = sv == 2;
     // k_seq_pipe: two chains fewer than fit, so that ~6 KiB of every CU's LDS stay free and the small
     // k_huf workgroups run in k_seq's shadow instead of queueing for whole CUs (measured with 54 chains of 56:
     // 28.6 ms per step; 55: 29.5; 56: 32.2; 53: 29.2; 51: 30.9)

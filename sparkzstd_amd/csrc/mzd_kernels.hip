@@ -2316,9 +2316,13 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         const bool two = __any(sLL > 16);  // wave-uniform: a second 16-byte half exists somewhere
                         if (sLL) {
                             if (!litRle) {
+#ifndef MZD_ABL_EXEC_NOLIT  /* ablations: timing experiments only, wrong results */
                                 a = *(const U128U *)(lits + srcL);
                                 if (two) c = *(const U128U *)(lits + srcL + (sLL > 16 ? 16 : 0));
+#endif
+#if !defined(MZD_ABL_EXEC_NOLIT) && !defined(MZD_ABL_EXEC_NOWT)
                                 wt = ld32u_g(lits + srcL + (sLL >= 4 ? sLL - 4 : 0));
+#endif
                             }
                             uint8_t *d = lbuf + dstL;
                             lds_store_upto16(d, min(sLL, 16u), a.x, a.y, a.z, a.w, wt);
@@ -2356,9 +2360,13 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         uint32_t wt = 0;
                         const bool two = __any(g && ML > 16);
                         if (g) {
+#ifndef MZD_ABL_EXEC_NOFAR
                             a = *(const U128U *)sp;
                             if (two) c = *(const U128U *)(sp + (ML > 16 ? 16 : 0));
+#endif
+#if !defined(MZD_ABL_EXEC_NOFAR) && !defined(MZD_ABL_EXEC_NOWT)
                             wt = ld32u_g(sp + (ML >= 4 ? ML - 4 : 0));
+#endif
                             uint8_t *d = lbuf + dstM;
                             lds_store_upto16(d, min(ML, 16u), a.x, a.y, a.z, a.w, wt);
                             if (two) lds_store_upto16(d + 16, ML > 16 ? ML - 16 : 0, c.x, c.y, c.z, c.w, wt);

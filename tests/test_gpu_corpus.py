@@ -22,7 +22,7 @@ def _decode(frames, ctx):
     return outs, sts
 
 
-@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (0, 128), (1, 128), (0, 64), (1, 64), (2, 128), (2, 256)])
+@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (3, 256), (0, 128), (1, 128), (3, 128), (0, 64), (1, 64), (3, 64)])
 def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
@@ -205,7 +205,7 @@ def test_corrupt_input_reports_status_not_fault(corpus, ctx):
     check_expected(name, outs2[0], length, sha, exp)
 
 
-@pytest.mark.parametrize("seq_variant", [0, 1, 2])
+@pytest.mark.parametrize("seq_variant", [0, 1, 3])
 def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant):
     """Every corpus frame, mutated 6 times (random byte flips past the frame header, seeded), all
     in ONE device batch.  The device must not fault; a frame it reports as decoded must be one
@@ -326,7 +326,7 @@ def test_content_checksum_verification_on_device(corpus):
     assert sts2 == [0] * 4
 
 
-@pytest.mark.parametrize("seq_variant", [0, 1, 2])
+@pytest.mark.parametrize("seq_variant", [0, 1, 3])
 def test_escape_codes_long_literal_runs_and_long_matches(oracle, seq_variant):
     """k_seq_pipe keeps literal-length codes >= 32 (runs >= 8192 bytes) and match-length codes >= 45
     (>= 1027 bytes) out of its 2-byte LDS cell ("escape": next = 0) and serves them in the general

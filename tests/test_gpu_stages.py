@@ -99,7 +99,7 @@ def _next_offset(hist, value, ll):
     return off
 
 
-@pytest.mark.parametrize("seq_variant,huf_variant", [(0, 1), (1, 1), (0, 2), (2, 1)])
+@pytest.mark.parametrize("seq_variant,huf_variant", [(0, 1), (1, 1), (0, 2), (3, 1)])
 def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle, seq_variant, huf_variant):
     """After one pass over the whole corpus: for every compressed block, the literal bytes the Huffman stage
     regenerated (literals.go:283-361 LiteralSection.Data) and every sequence's (LiteralLength, MatchLength,

@@ -9,7 +9,7 @@ from tools import synth_binding as sb
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 blob, off, ln, ck, ns = sb.make_batch(4, 0, n, threads=8)
 frames = [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
-ctx = z.Context(0, seq_variant=0, exec_threads=int(os.environ.get("EXEC_THREADS", "0")), exec_chunk=int(os.environ.get("EXEC_CHUNK", "0")))
+ctx = z.Context(0, seq_variant=int(os.environ.get("SEQ_VARIANT", "0")), exec_threads=int(os.environ.get("EXEC_THREADS", "0")), exec_chunk=int(os.environ.get("EXEC_CHUNK", "0")))
 L = _lib.load()
 buf = (ctypes.c_ulonglong * 32)()
 L.mzd_debug_exec_stats(buf, 1)
