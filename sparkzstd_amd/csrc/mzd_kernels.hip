@@ -2146,6 +2146,9 @@ __device__ void exec_tile_in_hbm(uint8_t *out, uint64_t outPos, const uint8_t *l
 #ifndef MZD_EXEC_WAVES_PER_SIMD
 #define MZD_EXEC_WAVES_PER_SIMD 8
 #endif
+#ifndef MZD_EXEC_IDLE_SLEEP
+#define MZD_EXEC_IDLE_SLEEP 1  // units of 64 cycles between two polls of a wavefront that found nothing to do
+#endif
 __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
@@ -2503,7 +2506,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         if ((++spins & 15) == 0 &&
                             __hip_atomic_load(&sh->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != MZD_OK)
                             break;  // corrupt input: a skipped match would never validate its bytes
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(MZD_EXEC_IDLE_SLEEP);
                     }
                 }
             }
