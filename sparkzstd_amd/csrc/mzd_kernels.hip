@@ -2385,6 +2385,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                 const uint64_t needm = (isShort && s1 > s0) ? span_mask((uint32_t)s0 & 31, (uint32_t)(s1 - s0)) : 0ull;
                 const uint32_t needw = (uint32_t)s0 >> 5;
                 const bool fastKind = isShort && !overlap && srcM >= 0;
+#if defined(MZD_EXEC_CXX_LOOP) || defined(MZD_EXEC_STATS)
                 uint32_t spins = 0;
                 while (__any(pending)) {
                     EXEC_STAT(3, 1);
@@ -2509,6 +2510,177 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         __builtin_amdgcn_s_sleep(MZD_EXEC_IDLE_SLEEP);
                     }
                 }
+#else
+                // The same loop with its common iteration -- readiness test of the short matches, the copy of the ready
+                // non-overlapping ones, publication -- as ONE hand-written statement.  k_exec is bound by the CU's scalar
+                // unit, and what the compiler's version (above, kept for the statistics build and as the reference) spends
+                // there is exec-mask bookkeeping: every wave-uniform `if (__any(..))` is a v_cndmask / v_cmp / s_cbranch
+                // triple, every divergent `if` an s_and_saveexec / s_or pair (58 scalar + branch instructions per fast
+                // iteration).  Here the pending lanes are MASKS in scalar registers (F: short, non-overlapping, sourced
+                // inside the chunk; S: the other short ones; L: long ones), an iteration narrows exec step by step and
+                // restores it once (~20).  The rare kinds (S: 0.08 passes per tile on the bench workload, L: 0.0002) stay
+                // in C++.  Same stores in the same order as the C++ fast pass; DS operations of a wavefront execute in
+                // order, so the bytes are in LDS before their validity bits.
+                const bool fastK = fastKind && ML >= 3;  // (a match is >= 3 bytes by the format; the hand-written copy relies on it)
+                uint64_t F = __ballot(pending && fastK);
+                uint64_t S = __ballot(pending && isShort && !fastK);
+                uint64_t L = __ballot(pending && !isShort);
+                const uint32_t na = (uint32_t)(uintptr_t)(vmap + needw);
+                const uint32_t nlo = (uint32_t)needm, nhi = (uint32_t)(needm >> 32);
+                const uint32_t srcA = (uint32_t)(uintptr_t)lbuf + (uint32_t)srcM, dstA = (uint32_t)(uintptr_t)lbuf + dstM;
+                const uint64_t pm = span_mask(dstM & 31, ML);
+                const uint32_t pa = (uint32_t)(uintptr_t)(vmap + (dstM >> 5)), plo = (uint32_t)pm, phi = (uint32_t)(pm >> 32);
+                uint32_t spins = 0;
+                while (F | S | L) {
+                    uint64_t RF, RS, T;
+#define MZD_EXEC_BLOCK(O0, O4)                                                                                          \
+    "ds_read_b64 v[56:57], %[src] offset:" #O0 "\n\t"   /* past the source: unused (and inside the buffer's slack) */    \
+    "v_cmp_le_u32 vcc, " #O0 ", v58\n\t"                                                                                \
+    "v_min_u32 v60, " #O0 ", v58\n\t"                                                                                   \
+    "v_add_u32 v60, %[dst], v60\n\t"                                                                                    \
+    "v_min_u32 v62, " #O4 ", v58\n\t"                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
+    "v_cndmask_b32 v61, v59, v56, vcc\n\t"                                                                              \
+    "v_cmp_le_u32 vcc, " #O4 ", v58\n\t"                                                                                \
+    "v_add_u32 v62, %[dst], v62\n\t"                                                                                    \
+    "ds_write_b32 v60, v61\n\t"                                                                                         \
+    "v_cndmask_b32 v63, v59, v57, vcc\n\t"                                                                              \
+    "ds_write_b32 v62, v63\n\t"
+                    asm volatile(
+                        "s_or_b64 exec, %[F], %[S]\n\t"            // the short matches still pending
+                        "ds_read2_b32 v[56:57], %[na] offset1:1\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_bfi_b32 v56, v56, 0, %[nlo]\n\t"        // needed and not valid
+                        "v_bfi_b32 v57, v57, 0, %[nhi]\n\t"
+                        "v_or_b32 v56, v56, v57\n\t"
+                        "v_cmp_eq_u32 vcc, 0, v56\n\t"             // ready
+                        "s_and_b64 %[RS], vcc, %[S]\n\t"
+                        "s_and_b64 %[RF], vcc, %[F]\n\t"
+                        "s_cbranch_scc0 L_ex_done_%=\n\t"
+                        "s_andn2_b64 %[F], %[F], %[RF]\n\t"
+                        "s_mov_b64 exec, %[RF]\n\t"
+                        "v_cmp_gt_u32 vcc, 4, %[ml]\n\t"
+                        "v_add_u32 v58, -4, %[ml]\n\t"             // last = ML - 4
+                        "s_and_saveexec_b64 %[T], vcc\n\t"         // T = the ready lanes
+                        "s_cbranch_execz L_ex_no3_%=\n\t"
+                        // three bytes
+                        "ds_read_b32 v56, %[src]\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_lshrrev_b32 v57, 8, v56\n\t"
+                        "ds_write_b8 %[dst], v56\n\t"
+                        "ds_write_b8 %[dst], v57 offset:1\n\t"
+                        "ds_write_b8_d16_hi %[dst], v56 offset:2\n"
+                        "L_ex_no3_%=:\n\t"
+                        "s_andn2_b64 exec, %[T], vcc\n\t"          // four bytes and more: dword stores, the last one collapsing onto the tail
+                        "s_cbranch_execz L_ex_pub_%=\n\t"
+                        "ds_read_b64 v[56:57], %[src]\n\t"
+                        "v_add_u32 v59, %[src], v58\n\t"
+                        "ds_read_b32 v59, v59\n\t"                 // source bytes [ML - 4, ML)
+                        "v_cmp_le_u32 vcc, 4, v58\n\t"
+                        "v_min_u32 v60, 4, v58\n\t"
+                        "v_add_u32 v60, %[dst], v60\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_cndmask_b32 v61, v59, v57, vcc\n\t"
+                        "ds_write_b32 %[dst], v56\n\t"
+                        "ds_write_b32 v60, v61\n\t"
+                        "v_cmp_lt_u32 vcc, 8, %[ml]\n\t"           // lanes whose copy is complete drop out (LDS time is per active lane)
+                        "s_and_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execz L_ex_pub_%=\n\t"
+                        MZD_EXEC_BLOCK(8, 12)
+                        "v_cmp_lt_u32 vcc, 16, %[ml]\n\t"
+                        "s_and_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execz L_ex_pub_%=\n\t"
+                        MZD_EXEC_BLOCK(16, 20)
+                        "v_cmp_lt_u32 vcc, 24, %[ml]\n\t"
+                        "s_and_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execz L_ex_pub_%=\n\t"
+                        MZD_EXEC_BLOCK(24, 28)
+                        "L_ex_pub_%=:\n\t"
+                        "s_mov_b64 exec, %[T]\n\t"
+                        "ds_or_b32 %[pa], %[plo]\n\t"
+                        "v_cmp_ne_u32 vcc, 0, %[phi]\n\t"
+                        "s_and_b64 exec, exec, vcc\n\t"
+                        "ds_or_b32 %[pa], %[phi] offset:4\n"
+                        "L_ex_done_%=:\n\t"
+                        "s_mov_b64 exec, -1\n\t"
+                        : [F] "+s"(F), [RF] "=&s"(RF), [RS] "=&s"(RS), [T] "=&s"(T)
+                        : [S] "s"(S), [na] "v"(na), [nlo] "v"(nlo), [nhi] "v"(nhi), [src] "v"(srcA), [dst] "v"(dstA), [ml] "v"(ML),
+                          [pa] "v"(pa), [plo] "v"(plo), [phi] "v"(phi)
+                        : "memory", "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+#undef MZD_EXEC_BLOCK
+                    bool progressed = RF != 0;
+                    // short matches that overlap themselves or straddle the chunk start: byte loop
+                    if (RS) {
+                        progressed = true;
+                        const bool slowb = (RS >> lane) & 1;
+                        const uint32_t n = slowb ? ML : 0;
+                        const uint32_t nmax = wave_max_u32(n);
+                        const uint8_t *gsrc = bout + (int)chunkStart;  // HBM address of chunk-relative position 0
+                        for (uint32_t j = 0; j < nmax; j++) {
+                            if (j < n) {
+                                const int q = srcM + (int)j;
+                                const uint8_t v = q >= 0 ? lbuf[q] : gsrc[q];
+                                lbuf[dstM + j] = v;
+                            }
+                        }
+                        if (slowb) publish(vmap, dstM, ML);
+                        S &= ~RS;
+                    }
+                    // at most one long match per iteration, whole wavefront, non-blocking readiness test
+                    if (L) {
+                        const int src = __builtin_ctzll(L);
+                        const uint32_t n = (uint32_t)__shfl((int)ML, src, 64);
+                        const uint32_t d = (uint32_t)__shfl((int)dstM, src, 64);
+                        const int s = __shfl(srcM, src, 64);
+                        const uint32_t o = (uint32_t)__shfl(off, src, 64);
+                        const uint32_t sp2 = (uint32_t)__shfl((int)span, src, 64);
+                        bool ok = true;
+                        const int q0 = max(s, 0), q1 = s + (int)sp2;
+                        if (q1 > q0) {
+                            const uint32_t wf = (uint32_t)q0 >> 5, wl = (uint32_t)(q1 - 1) >> 5;
+                            for (uint32_t wi = wf + lane; wi <= wl; wi += 64) {
+                                uint32_t need = 0xFFFFFFFFu;
+                                if (wi == wf) need &= 0xFFFFFFFFu << ((uint32_t)q0 & 31);
+                                if (wi == wl) need &= 0xFFFFFFFFu >> (31 - ((uint32_t)(q1 - 1) & 31));
+                                const uint32_t v = __hip_atomic_load(&vmap[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                ok = ok && ((v & need) == need);
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) {
+                            progressed = true;
+                            const uint8_t *gsrc = bout + (int)chunkStart;
+                            if (o >= 64) {
+                                // each 64-byte step only reads bytes written by earlier steps (in-order LDS)
+                                for (uint32_t j = lane; j < n; j += 64) {
+                                    const int q = s + (int)j;
+                                    const uint8_t v = q >= 0 ? lbuf[q] : gsrc[q];
+                                    lbuf[d + j] = v;
+                                }
+                            } else {
+                                // overlapping: periodic fill from the (final) pattern [s, s+o)
+                                uint32_t r = (uint32_t)lane % o;
+                                const uint32_t stepr = 64 % o;
+                                for (uint32_t j = lane; j < n; j += 64) {
+                                    const int q = s + (int)r;
+                                    const uint8_t v = q >= 0 ? lbuf[q] : gsrc[q];
+                                    lbuf[d + j] = v;
+                                    r += stepr;
+                                    if (r >= o) r -= o;
+                                }
+                            }
+                            for (uint32_t j = lane * 32; j < n; j += 64 * 32) publish(vmap, d + j, min(32u, n - j));
+                            L &= L - 1;
+                        }
+                    }
+                    if (!progressed) {
+                        if ((++spins & 15) == 0 &&
+                            __hip_atomic_load(&sh->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != MZD_OK)
+                            break;  // corrupt input: a skipped match would never validate its bytes
+                        __builtin_amdgcn_s_sleep(MZD_EXEC_IDLE_SLEEP);
+                    }
+                }
+#endif
             }
             __syncthreads();
             // ---- the chunk leaves for HBM: head bytes, aligned 16-byte body, tail bytes
