@@ -2566,26 +2566,27 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         // three bytes
                         "ds_read_b32 v56, %[src]\n\t"
                         "s_waitcnt lgkmcnt(0)\n\t"
-                        "v_lshrrev_b32 v57, 8, v56\n\t"
-                        "ds_write_b8 %[dst], v56\n\t"
-                        "ds_write_b8 %[dst], v57 offset:1\n\t"
+                        "ds_write_b16 %[dst], v56\n\t"
                         "ds_write_b8_d16_hi %[dst], v56 offset:2\n"
                         "L_ex_no3_%=:\n\t"
-                        "s_andn2_b64 exec, %[T], vcc\n\t"          // four bytes and more: dword stores, the last one collapsing onto the tail
+                        "s_andn2_b64 exec, %[T], vcc\n\t"          // four bytes and more
                         "s_cbranch_execz L_ex_pub_%=\n\t"
+                        // 4..8 bytes: two dword stores, the second at min(4, ML - 4) with the source bytes from there on
+                        // (one 8-byte read, byte-misaligned: a cycle per active lane in the LDS pipe; no separate tail read)
                         "ds_read_b64 v[56:57], %[src]\n\t"
-                        "v_add_u32 v59, %[src], v58\n\t"
-                        "ds_read_b32 v59, v59\n\t"                 // source bytes [ML - 4, ML)
-                        "v_cmp_le_u32 vcc, 4, v58\n\t"
                         "v_min_u32 v60, 4, v58\n\t"
+                        "v_lshlrev_b32 v61, 3, v60\n\t"
                         "v_add_u32 v60, %[dst], v60\n\t"
                         "s_waitcnt lgkmcnt(0)\n\t"
-                        "v_cndmask_b32 v61, v59, v57, vcc\n\t"
                         "ds_write_b32 %[dst], v56\n\t"
-                        "ds_write_b32 v60, v61\n\t"
+                        "v_lshrrev_b64 v[62:63], v61, v[56:57]\n\t"
+                        "ds_write_b32 v60, v62\n\t"
                         "v_cmp_lt_u32 vcc, 8, %[ml]\n\t"           // lanes whose copy is complete drop out (LDS time is per active lane)
                         "s_and_b64 exec, exec, vcc\n\t"
                         "s_cbranch_execz L_ex_pub_%=\n\t"
+                        // longer: dword stores at min(4k, ML - 4), the ones past the end collapsing onto the tail dword
+                        "v_add_u32 v59, %[src], v58\n\t"
+                        "ds_read_b32 v59, v59\n\t"                 // source bytes [ML - 4, ML)
                         MZD_EXEC_BLOCK(8, 12)
                         "v_cmp_lt_u32 vcc, 16, %[ml]\n\t"
                         "s_and_b64 exec, exec, vcc\n\t"
