@@ -1272,13 +1272,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_init_done, s));
-    // k_seq(head) is submitted FIRST so that its workgroups (nearly all of a CU's LDS each) claim the
-    // CUs; k_huf's small workgroups then fill what is left instead of delaying them
-    launch_seq(0, fA);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
-    HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
-    if (db->n_huf_tasks) {
+    auto launch_huf = [&]() {
+        if (!db->n_huf_tasks) return;
         // Which Huffman kernel: a lane per stream (k_huf) needs >= 64 streams per wavefront and many wavefronts per CU
         // to hide its ~190-cycle step; when the batch has few, long streams, a wavefront per stream decoding its
         // segments in parallel (k_huf_seg) is the one that fills the chip.
@@ -1295,7 +1290,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         else
             k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                   db->d_litbuf, db->d_sums, db->huf_slot_cells);
-    }
+    };
+    // k_seq(head) is submitted FIRST so that its workgroups (nearly all of a CU's LDS each) claim the
+    // CUs; k_huf's small workgroups then fill what is left instead of delaying them.  (Tried: k_huf beside the LAST,
+    // partial round of the sequence stage instead of the first, k_exec in one launch after both: 22.3-22.5 ms against
+    // 21.2-21.8 ms per pass.)
+    launch_seq(0, fA);
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
+    HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
+    launch_huf();
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
     if (split) {

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                                                        BlockSum *sums, uint32_t nch, uint64_t in_base)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef MZD_Q4_PROF
+    const long long prof_w0 = wall_clock64(), prof_c0 = clock64();  // 100 MHz / shader clock
+#endif
     uint32_t *CTc = (uint32_t *)smem;  // [2][64] by c6: base(24) | extra(8)   (predefined.go:5-20,36-50)
     Q4Shared *shs = (Q4Shared *)(smem + 512);
     uint16_t *cells = (uint16_t *)(smem + kQ4FixedLds);
@@ -194,6 +197,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     }
     __syncthreads();
 
+#ifdef MZD_Q4_PROF
+    const long long prof_w1 = wall_clock64();
+#endif
     // trip count of every stage: the longest chain of the workgroup (the q2 descriptors are gone: ask every lane of B)
     uint32_t nmax;
     {
@@ -906,6 +912,13 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         }
     }
     __syncthreads();
+#ifdef MZD_Q4_PROF
+    if ((blockIdx.x == 0 || blockIdx.x == 700) && threadIdx.x == 0) {
+        const long long w2 = wall_clock64(), c2 = clock64();
+        printf("workgroup %u: staging %.1f us, whole %.1f us, shader clock %.0f MHz\n", blockIdx.x, (prof_w1 - prof_w0) / 100.0,
+               (w2 - prof_w0) / 100.0, (double)(c2 - prof_c0) / ((w2 - prof_w0) / 100.0));
+    }
+#endif
     // decode-stage errors come first, as in the reference, where DecodeSequences runs to its end
     // before ExecuteSequences starts
     if (wave == 6 && has && t.n_seq > 0) {
