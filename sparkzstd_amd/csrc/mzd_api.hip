@@ -96,6 +96,7 @@ struct mzd_dbatch {
     // geometry
     uint32_t n_frames = 0, n_blocks = 0, n_huf_tasks = 0, n_seq_tasks = 0;
     uint32_t huf_slot_cells = 2;
+    uint32_t seq_cells[3] = {512, 512, 256};  // largest LL / ML / OF table of the batch's sequence tasks (cells)
     std::vector<uint32_t> frame_seq_task;  // host: index of the first SeqTask of every frame (+ total)
     std::vector<uint64_t> frame_out_off, frame_out_cap;  // host: output slab of every frame
     std::vector<uint64_t> frame_in_lo, frame_in_hi;      // host: extent of the frame's sequence bitstreams in the blob (lo > hi: none)
@@ -310,6 +311,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         }
     }
     uint32_t max_huf_bits = 1;
+    uint32_t seq_logs[3] = {0, 0, 0};  // largest LL / ML / OF accuracy log among the sequence tasks
     // device layout of the Huffman decode tables: 1 << max_bits cells each, whatever form they arrived in
     std::vector<uint32_t> huf_dev_off(b->n_huf_tables + 1, 0);
     std::vector<uint8_t> huf_bits(b->n_huf_tables, 1);
@@ -489,6 +491,9 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                 t.ll_log = b->fse_tables[bd.ll_table].acc_log;
                 t.of_log = b->fse_tables[bd.of_table].acc_log;
                 t.ml_log = b->fse_tables[bd.ml_table].acc_log;
+                seq_logs[0] = std::max<uint32_t>(seq_logs[0], t.ll_log);
+                seq_logs[1] = std::max<uint32_t>(seq_logs[1], t.ml_log);
+                seq_logs[2] = std::max<uint32_t>(seq_logs[2], t.of_log);
                 t.hist_known = seen_seq ? 0 : 1;
                 seen_seq = true;
                 in_lo = std::min<uint64_t>(in_lo, bd.seq_off);
@@ -517,6 +522,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->n_blocks = b->n_blocks;
     db->n_huf_tasks = (uint32_t)huf_tasks.size();
     db->n_seq_tasks = (uint32_t)seq_tasks.size();
+    for (int k = 0; k < 3; k++) db->seq_cells[k] = 1u << std::min<uint32_t>(seq_logs[k], k == 2 ? 8u : 9u);
     db->huf_slot_cells = 1u << max_huf_bits;
     db->frame_seq_task = std::move(frame_seq_task);
     db->frame_in_lo = std::move(frame_in_lo);
@@ -773,6 +779,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         n_fse_src += (uint32_t)(kDefN[k] + 1) / 2;
     }
     uint32_t max_huf_bits = 1;
+    uint32_t seq_logs[3] = {0, 0, 0};  // largest LL / ML / OF accuracy log among the sequence tasks
     mzd_batch_stats st{};
     for (uint32_t f = 0; f < n_frames; f++) {
         const FrameCount &c = counts[f];
@@ -812,6 +819,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         n_rec += c.n_rec;
         lit_total += c.lit_bytes;
         max_huf_bits = std::max(max_huf_bits, c.max_huf_bits);
+        for (int k = 0; k < 3; k++) seq_logs[k] = std::max<uint32_t>(seq_logs[k], (c.max_seq_logs >> (8 * k)) & 0xFF);
         st.compressed_bytes += c.comp_bytes;
         st.out_capacity_bytes += fb.out_cap;
         st.n_sequences += c.n_rec;
@@ -832,6 +840,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     db->n_blocks = (uint32_t)n_blocks;
     db->n_huf_tasks = (uint32_t)(4 * n_hufb);
     db->n_seq_tasks = (uint32_t)n_seq;
+    for (int k = 0; k < 3; k++) db->seq_cells[k] = 1u << std::min<uint32_t>(seq_logs[k], k == 2 ? 8u : 9u);
     db->huf_slot_cells = 1u << max_huf_bits;
     db->frame_seq_task = std::move(frame_seq_task);
     db->out_size = out_at;
@@ -1132,7 +1141,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // 28.6 ms per step; 55: 29.5; 56: 32.2; 53: 29.2; 51: 30.9)
     uint32_t nch = q4 ? (uint32_t)kQ4Chains : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
     if (const char *e = getenv("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
-    const uint64_t per_round = (uint64_t)nch * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
+    // k_seq_q4 sizes a chain's LDS slot to the batch's largest tables (less to stage, more LDS left for the Huffman
+    // workgroups beside it).  With small tables TWO workgroups share a CU: the kernel holds 94 VGPRs (five wavefronts per
+    // SIMD, a workgroup is nine wavefronts), so LDS decides -- 54 chains of up to ~580 cells each.
+    const uint32_t q4_slot_cells = db->seq_cells[0] + db->seq_cells[1] + db->seq_cells[2];
+    auto q4_lds = [&](uint32_t per_wg) { return (size_t)kQ4FixedLds + (size_t)per_wg * q4_slot_cells * 2; };
+    const uint32_t wg_per_cu = q4 && 2 * q4_lds(nch) <= (size_t)160 * 1024 ? 2u : 1u;
+    const uint64_t per_round = (uint64_t)nch * wg_per_cu * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames;
     if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
         const uint64_t lim = (db->n_seq_tasks / per_round) * per_round;
@@ -1166,12 +1181,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (use_pipe) {
             // chains per workgroup: as few as fill the same number of rounds (a lone chain per CU when
             // the batch is small -- the step latency does not depend on the number of lanes)
-            const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1);
+            const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1) * wg_per_cu;  // workgroups resident at a time
             const uint64_t rounds = (count + cus * nch - 1) / (cus * nch);
             const uint32_t per_wg = (uint32_t)std::min<uint64_t>(nch, (count + rounds * cus - 1) / (rounds * cus));
             if (q4)
-                k_seq_q4<<<(count + per_wg - 1) / per_wg, kQ4Threads, kQ4FixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
-                    db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base);
+                k_seq_q4<<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
+                    db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,
+                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2]);
             else
                 k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base);
@@ -1216,7 +1232,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         uint32_t limit = 0xFFFFFFFFu;
         if (n_launch > 1) {
             const uint64_t total = db->frame_seq_task[f1] - db->frame_seq_task[f0];
-            const uint64_t round = (uint64_t)nch * (uint64_t)std::max(ctx->num_cus, 1);
+            const uint64_t round = (uint64_t)nch * wg_per_cu * (uint64_t)std::max(ctx->num_cus, 1);
             limit = (uint32_t)std::min<uint64_t>(((total + n_launch - 1) / n_launch + round - 1) / round * round, 0xFFFFFFFFu);
         }
         uint32_t g = f0;

@@ -30,6 +30,7 @@ struct FrameCount {
     int32_t status;
     uint32_t n_blocks, n_seq, n_hufb, n_fse_tab, n_fse_src, n_fse_dev, n_huf_tab, n_huf_src, n_huf_dev, n_tile;
     uint32_t max_huf_bits, checksum, flags;
+    uint32_t max_seq_logs;  // largest accuracy logs of the frame's sequence tables: LL | ML << 8 | OF << 16
     uint32_t n_raw, n_rle, n_comp, n_huf_streams;
     uint64_t n_rec, lit_bytes, out_bound, content_size, comp_bytes;
 };
@@ -513,6 +514,9 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                     po.seq_tasks[fb.seq0 + c.n_seq] = t;
                 }
                 seen_seq = true;
+                c.max_seq_logs = max(c.max_seq_logs & 0xFFu, (uint32_t)use[MZD_FSE_LL].log) |
+                                 (max((c.max_seq_logs >> 8) & 0xFFu, (uint32_t)use[MZD_FSE_ML].log) << 8) |
+                                 (max((c.max_seq_logs >> 16) & 0xFFu, (uint32_t)use[MZD_FSE_OF].log) << 16);
                 c.n_seq++;
                 c.n_rec += nseq;
                 c.n_tile += (nseq + 63) / 64;

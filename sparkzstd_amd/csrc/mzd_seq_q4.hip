@@ -115,8 +115,13 @@ __device__ __forceinline__ uint32_t q4_history_step(uint32_t hi, uint32_t &h0, u
 __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                                        uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                                        uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
-                                                       BlockSum *sums, uint32_t nch, uint64_t in_base)
+                                                       BlockSum *sums, uint32_t nch, uint64_t in_base, uint32_t cells_ll,
+                                                       uint32_t cells_ml, uint32_t cells_of)
 {
+    // cells_ll / cells_ml / cells_of: the largest LL / ML / OF table of the batch (powers of two).  A chain's slot in LDS is
+    // exactly that wide -- 1280 cells when the tables have the format's largest accuracy logs (9 / 9 / 8), 160 when they
+    // are the predefined ones -- so batches of small tables leave room for two or three workgroups per CU.
+    const uint32_t off_ml = cells_ll, off_of = cells_ll + cells_ml, slot_cells = cells_ll + cells_ml + cells_of;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef MZD_Q4_PROF
     const long long prof_w0 = wall_clock64(), prof_c0 = clock64();  // 100 MHz / shader clock
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             desc[4 * lane + 3] = has ? ((uint32_t)t.ll_log | ((uint32_t)t.ml_log << 8) | ((uint32_t)t.of_log << 16)) : 0x00FFFFFFu;
         }
         __syncthreads();
-        const uint32_t ncell = min(nch, n_tasks - blockIdx.x * nch) * kSeqCellsPerChain;
+        const uint32_t ncell = min(nch, n_tasks - blockIdx.x * nch) * slot_cells;
         constexpr int UNR = 8;
         for (uint32_t idx0 = threadIdx.x; idx0 < ncell; idx0 += kQ4Threads * UNR) {
             uint32_t e[UNR], n[UNR], c6k[UNR];
@@ -177,9 +182,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const uint32_t idx = idx0 + kQ4Threads * u;
-                const uint32_t c = idx / kSeqCellsPerChain, r = idx - c * kSeqCellsPerChain;
-                const uint32_t kind = r >= 1024 ? 2u : (r >> 9);
-                const uint32_t i = r - (kind << 9);
+                const uint32_t c = idx / slot_cells, r = idx - c * slot_cells;
+                const uint32_t kind = r >= off_of ? 2u : (r >= off_ml ? 1u : 0u);
+                const uint32_t i = r - (kind == 2 ? off_of : (kind == 1 ? off_ml : 0u));
                 const uint32_t lg = (desc[4 * min(c, 63u) + 3] >> (8 * kind)) & 0xFF;
                 n[u] = 1u << (lg & 31);
                 ok[u] = idx < ncell && lg <= 9 && i < n[u];
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         const uint8_t *inb = in - MZD_IN_PAD;
         const int alL = t.ll_log, alM = t.ml_log, alO = t.of_log;
         const uint32_t sizeL = 1u << alL, sizeM = 1u << alM, sizeO = 1u << alO;
-        const uint32_t slot = ch * kSeqCellsPerChain;
+        const uint32_t slot = ch * slot_cells;
         const bool spare = role == 3;
         const uint32_t dummy_addr = 512u + (uint32_t)offsetof(Q4Shared, dummy);  // byte address of dummy[0]; dummy[1] is the cell
         // ---- per chain (its fourth lane): padding, initial states in the order LL, OF, ML (sequences.go:133-159)
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             st = role == 0 ? l : (role == 1 ? m : (role == 2 ? o : 1u));
             const uint32_t base = (uint32_t)kQ4FixedLds;
             cb = role == 0 ? base + 2u * (slot - sizeL)
-                           : (role == 1 ? base + 2u * (slot + 512 - sizeM) : (role == 2 ? base + 2u * (slot + 1024 - sizeO) : dummy_addr));
+                           : (role == 1 ? base + 2u * (slot + off_ml - sizeM) : (role == 2 ? base + 2u * (slot + off_of - sizeO) : dummy_addr));
             shr = role == 2 ? 10u : 12u;
             Kc = role == 0 ? 3u : (role == 1 ? 7u : 0u);
             nbK = role == 0 ? 31u - (uint32_t)alL : (role == 1 ? 31u - (uint32_t)alM : (role == 2 ? 31u - (uint32_t)alO : 31u));
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             }
         };
         const uint16_t *cL = cells + slot - sizeL;
-        const uint16_t *cM = cells + slot + 512 - sizeM;
-        const uint16_t *cO = cells + slot + 1024 - sizeO;
+        const uint16_t *cM = cells + slot + off_ml - sizeM;
+        const uint16_t *cO = cells + slot + off_of - sizeO;
         // General step of sequence `idx` for the chains in `mine` (their queue entries of this step are rewritten as
         // mode 1), run by the chain's fourth lane on the chain's three states, as k_seq_pipe's.
         auto general_step = [&](uint32_t idx, bool mine) {
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 // the other three reading an aligned address -- saves two instructions and was 40 % SLOWER: the LDS pipe
                 // is too full for 64-lane 8-byte accesses).  DPP reads of a VGPR keep
                 // two instructions' distance from the VALU write of it (the hardware does not interlock that; nothing
-                // inside an asm statement is padded by the compiler).  Temporaries are fixed registers v100..v136 / s86.
+                // inside an asm statement is padded by the compiler).  Temporaries are fixed registers v66..v89 / s86.
                 static_assert(kPipeDepth == 8 && kPipeBatch == 4 && kPipeRing == 128, "the unrolled loop assumes 2 batches of 4 slots, a 128-byte ring");
                 uint32_t stb = st;  // the states alternate between two register sets
                 // (wave-uniform by construction; said explicitly, or the "s" operands below are refused)
@@ -412,10 +417,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #define Q4_RINGCHK(TAG)                                                                                     \
     "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n"                                                      \
     "L_q4_ring" TAG "_%=:\n\t"                                                                              \
-    "ds_read_b32 v100, %[chan4] offset:%[o_rlow]\n\t"                                                       \
-    "v_add_u32 v101, -40, %[off]\n\t"                                                                       \
+    "ds_read_b32 v66, %[chan4] offset:%[o_rlow]\n\t"                                                       \
+    "v_add_u32 v67, -40, %[off]\n\t"                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_cmp_gt_u32 vcc, v100, v101\n\t"                                                                      \
+    "v_cmp_gt_u32 vcc, v66, v67\n\t"                                                                      \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     "s_add_u32 %[polls], %[polls], 0x10000\n\t"                                                             \
     "s_sleep 1\n\t"                                                                                         \
@@ -427,9 +432,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "s_cmp_lt_u32 s86, 5\n\t" /* the batch that used these slots before (i - 8) has been consumed */        \
     "s_cbranch_scc1 L_q4_spc" TAG "_%=\n"                                                                   \
     "L_q4_poll" TAG "_%=:\n\t"                                                                              \
-    "ds_read_b32 v100, %[vzero] offset:" OTL "\n\t"                                                         \
+    "ds_read_b32 v66, %[vzero] offset:" OTL "\n\t"                                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_readfirstlane_b32 " TL ", v100\n\t"                                                                  \
+    "v_readfirstlane_b32 " TL ", v66\n\t"                                                                  \
     "s_sub_u32 s86, %[i], " TL "\n\t"                                                                       \
     "s_cmp_lt_u32 s86, 5\n\t"                                                                               \
     "s_cbranch_scc1 L_q4_spc" TAG "_%=\n\t"                                                                 \
@@ -437,64 +442,64 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "s_sleep 1\n\t"                                                                                         \
     "s_branch L_q4_poll" TAG "_%=\n"                                                                        \
     "L_q4_spc" TAG "_%=:\n\t"                                                                               \
-    /* fast path: ring_low as read during the previous step (v136; it only ever decreases) */               \
-    "v_add_u32 v101, -40, %[off]\n\t"                                                                       \
+    /* fast path: ring_low as read during the previous step (v89; it only ever decreases) */               \
+    "v_add_u32 v67, -40, %[off]\n\t"                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-    "v_cmp_gt_u32 vcc, v136, v101\n\t"                                                                      \
+    "v_cmp_gt_u32 vcc, v89, v67\n\t"                                                                      \
     "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n\t"                                                    \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     Q4_RINGCHK(TAG)
-// On entry: this step's cell is on its way into v103 (requested by the step before, or the prologue), DMl/DMh get the
-// 8 bytes at the cursor (read at the end of the step before), v128 holds the limit.  DL: where the next step's window
-// goes.  LIMIT: the instruction(s) that finish the next step's limit in v128 (from 64 - k).
+// On entry: this step's cell is on its way into v69 (requested by the step before, or the prologue), DMl/DMh get the
+// 8 bytes at the cursor (read at the end of the step before), v85 holds the limit.  DL: where the next step's window
+// goes.  LIMIT: the instruction(s) that finish the next step's limit in v85 (from 64 - k).
 #define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                        \
     "L_q4_go" TAG "_%=:\n\t"                                                                                \
     "s_waitcnt lgkmcnt(3)\n\t"                      /* the cell (behind it: two queue writes, the ring read) */ \
-    "v_lshrrev_b32 v115, %[shr], v103\n\t"          /* code field */                                        \
-    "v_and_b32 v117, 0x3ff, v103\n\t"               /* next */                                              \
-    "v_cndmask_b32_e64 v131, v103, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
-    "v_ffbh_u32 v120, v117\n\t"                                                                             \
-    "v_sub_u32_e64 v115, v115, %[Kc] clamp\n\t"     /* ex */                                                \
-    "v_min_u32 v120, 0x4000000, v120\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
-    "v_sub_u32 v120, v120, %[nbK]\n\t"              /* nb */                                                \
-    "v_add_u32_dpp v121, v115, v115 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+    "v_lshrrev_b32 v76, %[shr], v69\n\t"          /* code field */                                        \
+    "v_and_b32 v77, 0x3ff, v69\n\t"               /* next */                                              \
+    "v_cndmask_b32_e64 v88, v69, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
+    "v_ffbh_u32 v78, v77\n\t"                                                                             \
+    "v_sub_u32_e64 v76, v76, %[Kc] clamp\n\t"     /* ex */                                                \
+    "v_min_u32 v78, 0x4000000, v78\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
+    "v_sub_u32 v78, v78, %[nbK]\n\t"              /* nb */                                                \
+    "v_add_u32_dpp v79, v76, v76 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
     "s_waitcnt lgkmcnt(0)\n\t"                      /* the window */                                        \
-    "v_mov_b32_dpp v110, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
-    "v_add_u32_dpp v122, v120, v120 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
-    "v_add_u32_dpp v123, v121, v121 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
-    "v_mov_b32_dpp v111, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
-    "v_add_u32_dpp v124, v120, v122 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
-    "v_add_u32 v129, v123, %[k]\n\t"                /* k + o3 */                                            \
-    "v_sub_u32 v125, 0, v124\n\t"                   /* -P */                                                \
-    "v_lshlrev_b64 v[112:113], v129, v[110:111]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
-    "v_add_u32_dpp v130, v124, v123 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
-    "v_bfe_u32 v126, v113, v125, v120\n\t"          /* the lane's state field */                            \
-    "v_lshl_add_u32 %[s" SB "], v117, v120, v126\n\t" /* new state, in the OTHER register set */            \
-    "v_cmp_lt_u32 vcc, v130, v128\n\t"              /* go (the same in the four lanes of a chain) */        \
-    "v_lshl_add_u32 v100, %[s" SB "], 1, %[cb]\n\t"                                                         \
-    "ds_read_u16 v103, v100\n\t"                    /* the NEXT step's cell; the rest of the step runs behind it */ \
-    "ds_write_b16 %[qca], v131 offset:" QC "\n\t"                                                           \
-    "v_cndmask_b32 v130, 0, v130, vcc\n\t"                                                                  \
-    "v_sub_u32 %[rem1], %[rem1], v130\n\t"                                                                  \
-    "v_add_u32 %[k], %[k], v130\n\t"                                                                        \
-    "v_lshrrev_b32 v107, 3, %[k]\n\t"               /* normalise the cursor for the next step */            \
+    "v_mov_b32_dpp v72, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_add_u32_dpp v80, v78, v78 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
+    "v_add_u32_dpp v81, v79, v79 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
+    "v_mov_b32_dpp v73, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_add_u32_dpp v82, v78, v80 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
+    "v_add_u32 v86, v81, %[k]\n\t"                /* k + o3 */                                            \
+    "v_sub_u32 v83, 0, v82\n\t"                   /* -P */                                                \
+    "v_lshlrev_b64 v[74:75], v86, v[72:73]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
+    "v_add_u32_dpp v87, v82, v81 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
+    "v_bfe_u32 v84, v75, v83, v78\n\t"          /* the lane's state field */                            \
+    "v_lshl_add_u32 %[s" SB "], v77, v78, v84\n\t" /* new state, in the OTHER register set */            \
+    "v_cmp_lt_u32 vcc, v87, v85\n\t"              /* go (the same in the four lanes of a chain) */        \
+    "v_lshl_add_u32 v66, %[s" SB "], 1, %[cb]\n\t"                                                         \
+    "ds_read_u16 v69, v66\n\t"                    /* the NEXT step's cell; the rest of the step runs behind it */ \
+    "ds_write_b16 %[qca], v88 offset:" QC "\n\t"                                                           \
+    "v_cndmask_b32 v87, 0, v87, vcc\n\t"                                                                  \
+    "v_sub_u32 %[rem1], %[rem1], v87\n\t"                                                                  \
+    "v_add_u32 %[k], %[k], v87\n\t"                                                                        \
+    "v_lshrrev_b32 v70, 3, %[k]\n\t"               /* normalise the cursor for the next step */            \
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
-    "v_sub_u32 %[off], %[off], v107\n\t"                                                                    \
-    "v_sub_u32 v128, 64, %[k]\n\t"                                                                          \
-    "v_and_b32 v109, 127, %[off]\n\t"                                                                   \
+    "v_sub_u32 %[off], %[off], v70\n\t"                                                                    \
+    "v_sub_u32 v85, 64, %[k]\n\t"                                                                          \
+    "v_and_b32 v71, 127, %[off]\n\t"                                                                   \
     LIMIT                                           /* the next limit = min(64 - k, rem + 1[, steps before the last]) */ \
-    "v_add_u32 v109, v109, %[ringl]\n\t"                                                                    \
+    "v_add_u32 v71, v71, %[ringl]\n\t"                                                                    \
     "s_andn2_b64 %[smask], exec, vcc\n\t"           /* chains that need the general step; SCC = any */      \
     "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
-    "ds_write_b64 %[qwa], v[110:111] offset:" QW "\n\t" /* this step's window for stage B */                \
-    "ds_read_b64 " DL ", v109\n\t"                  /* the next step's window */                            \
+    "ds_write_b64 %[qwa], v[72:73] offset:" QW "\n\t" /* this step's window for stage B */                \
+    "ds_read_b64 " DL ", v71\n\t"                  /* the next step's window */                            \
     "s_mov_b64 exec, -1\n\t"                                                                                \
     RLOW                                                                                                    \
     "s_cbranch_scc1 " OUT "\n\t"
 #define Q4_PUBLISH(OUT)                                                                                     \
     "s_add_u32 %[i], %[i], 4\n\t"                                                                           \
-    "v_mov_b32 v102, %[i]\n\t"                                                                              \
-    "ds_write_b32 %[heada], v102\n\t"                                                                       \
+    "v_mov_b32 v68, %[i]\n\t"                                                                              \
+    "ds_write_b32 %[heada], v68\n\t"                                                                       \
     "s_cmp_lt_u32 %[i], %[nmax]\n\t"                                                                        \
     "s_cbranch_scc0 " OUT "\n\t"
 #define Q4_X1 "L_q4_x1_%="
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #define Q4_X3 "L_q4_x3_%="
 #define Q4_X4 "L_q4_x4_%="
 #define Q4_OUTO "L_q4_outo_%="
-#define Q4_RLOW "ds_read_b32 v136, %[chan4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
+#define Q4_RLOW "ds_read_b32 v89, %[chan4] offset:%[o_rlow]\n\t" /* for the next batch's ring check */
 #define Q4_QC(S) (512 + offsetof(Q4Shared, q1c) + (S) * kQ4Cols * 8)
 #define Q4_QW(S) (512 + offsetof(Q4Shared, q1w) + (S) * kQ4Cols * 8)
 #define Q4_HOT_LOOP(LIMIT, BOUND)                                                                                       \
@@ -510,18 +515,18 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     /* prologue = what the tail of a step before would have done.  The ring must hold the bytes at the  \
                        cursor BEFORE they are read (the very first entry: wave P may not have filled anything yet;      \
                        after a general step: the cursor has moved by more than a hot step). */                          \
-                    "v_mov_b32 v136, -1\n\t"  /* no ring_low read ahead yet: the first batch check takes the slow path */ \
+                    "v_mov_b32 v89, -1\n\t"  /* no ring_low read ahead yet: the first batch check takes the slow path */ \
                     Q4_RINGCHK("e")                                                                                     \
                     "L_q4_goe_%=:\n\t"                                                                                  \
-                    "v_and_b32 v109, 127, %[off]\n\t"                                                               \
-                    "v_sub_u32 v128, 64, %[k]\n\t"                                                                      \
-                    "v_add_u32 v109, v109, %[ringl]\n\t"                                                                \
+                    "v_and_b32 v71, 127, %[off]\n\t"                                                               \
+                    "v_sub_u32 v85, 64, %[k]\n\t"                                                                      \
+                    "v_add_u32 v71, v71, %[ringl]\n\t"                                                                \
                     LIMIT                                                                                               \
-                    "v_lshl_add_u32 v100, %[sa], 1, %[cb]\n\t"                                                          \
-                    "ds_read_u16 v103, v100\n\t"                                                                        \
+                    "v_lshl_add_u32 v66, %[sa], 1, %[cb]\n\t"                                                          \
+                    "ds_read_u16 v69, v66\n\t"                                                                        \
                     "s_mov_b64 exec, %[spare]\n\t"                                                                      \
-                    "ds_read_b64 v[132:133], v109\n\t"                                                                  \
-                    "ds_read_b64 v[134:135], v109\n\t"                                                                  \
+                    "ds_read_b64 v[90:91], v71\n\t"                                                                  \
+                    "ds_read_b64 v[92:93], v71\n\t"                                                                  \
                     "s_mov_b64 exec, -1\n\t"                                                                            \
                     "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
                     "s_and_b32 s86, %[i], 7\n\t"                                                                        \
@@ -542,16 +547,16 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     "s_cbranch_scc1 L_q4_go6_%=\n\t"                                                                    \
                     "s_branch L_q4_go7_%=\n"                                                                            \
                     Q4_CHECK("0", "%[tail0]", "%[o_tail0]")                                                             \
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
                     Q4_PUBLISH(Q4_OUTO)                                                                                 \
                     Q4_CHECK("4", "%[tail1]", "%[o_tail1]")                                                             \
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
-                    Q4_STEP("v132", "v133", "v[134:135]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
-                    Q4_STEP("v134", "v135", "v[132:133]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
                     Q4_PUBLISH(Q4_OUTO)                                                                                 \
                     "s_branch L_q4_top0_%=\n"                                                                           \
                     /* a step that leaves: the counter moves past it; after the first / third step of a batch the new   \
@@ -585,13 +590,13 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                       [qw0] "n"(Q4_QW(0)), [qw1] "n"(Q4_QW(1)), [qw2] "n"(Q4_QW(2)), [qw3] "n"(Q4_QW(3)),               \
                       [qw4] "n"(Q4_QW(4)), [qw5] "n"(Q4_QW(5)), [qw6] "n"(Q4_QW(6)), [qw7] "n"(Q4_QW(7))                \
                     : "memory", "vcc", "scc", "s86",                                                                    \
-                      "v100", "v101", "v102", "v103", "v107", "v109", "v110", "v111", "v112", "v113",                   \
-                      "v115", "v117", "v120", "v121", "v122", "v123", "v124", "v125", "v126",                           \
-                      "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136")
+                      "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",                   \
+                      "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",                           \
+                      "v85", "v86", "v87", "v88", "v90", "v91", "v92", "v93", "v89")
                 if (i < ncom) {
-                    Q4_HOT_LOOP("v_min_u32 v128, v128, %[rem1]\n\t", ncom);
+                    Q4_HOT_LOOP("v_min_u32 v85, v85, %[rem1]\n\t", ncom);
                 } else {
-                    Q4_HOT_LOOP("v_min3_u32 v128, v128, %[rem1], %[left]\n\tv_add_u32 %[left], -1, %[left]\n\t", nmax);
+                    Q4_HOT_LOOP("v_min3_u32 v85, v85, %[rem1], %[left]\n\tv_add_u32 %[left], -1, %[left]\n\t", nmax);
                 }
 #undef Q4_HOT_LOOP
 #undef Q4_STEP
