@@ -50,7 +50,7 @@ constexpr int kQ4Chains = 54;  // chains per workgroup: what LDS holds next to a
 static_assert(kQ4MaxChains >= kQ4Chains + 1 && kQ4Chains < kQ4Cols - 1 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
 
 #ifdef MZD_Q4_STATS
-__device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps
+__device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps, cycles in them
 #endif
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_quad(uint32_t v)  // quad_perm, all rows and banks, out-of-range lanes read 0
@@ -385,6 +385,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_Q4_STATS
         const long long stats_t0 = clock64();
         uint32_t n_general = 0;
+        long long general_cycles = 0;
 #endif
         // Steps [0, ncom) are more than 64 steps away from every chain's last sequence: "steps before the last" cannot be the
         // smallest term of a step's limit (64 - k is at most 64) and the loop variant that runs them leaves it out.
@@ -617,8 +618,12 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 const bool mine = ((smask >> lane) & 1) != 0;
 #ifdef MZD_Q4_STATS
                 n_general++;
+                const long long g_t0 = clock64();
 #endif
                 general_step(i - 1, mine);
+#ifdef MZD_Q4_STATS
+                general_cycles += clock64() - g_t0;
+#endif
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&shs->head1[wave], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -631,6 +636,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             atomicAdd(&g_q4_stats[3], (unsigned long long)(polls & 0xFFFF));
             atomicAdd(&g_q4_stats[4], (unsigned long long)(polls >> 16));
             atomicAdd(&g_q4_stats[5], (unsigned long long)n_general);
+            atomicAdd(&g_q4_stats[6], (unsigned long long)general_cycles);
         }
 #endif
         (void)polls;
