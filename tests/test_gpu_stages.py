@@ -261,10 +261,9 @@ def test_huf_seg_reports_the_lane_kernels_status_on_damaged_streams(corpus, orac
 
 # ---- BASELINE.json configs at their stated sizes: size-independent properties on every frame
 
-def _run_full_config(config, n_frames, ctx):
+def _run_full_config(config, n_frames, ctx, frame_bytes=131072):
     import torch
     from tools import synth_binding as sb
-    frame_bytes = 131072
     blob, off, ln, cks, nseq = sb.make_batch(config, 0, n_frames, frame_bytes, threads=0)
     plan = z.Plan(device_tables=True)
     assert plan.add_frames(blob, off, ln, threads=0) == 0
@@ -314,6 +313,14 @@ def test_config4_full_frames_65536_full_size(ctx):
     """BASELINE configs[3]: 65536 text-like single-block frames, Huffman literals + FSE sequences + match copy."""
     st = _run_full_config(4, 65536, ctx)
     assert st.n_huf_streams == 4 * 65536 and st.n_sequences > 65536 * 10000
+
+
+def test_small_frames_small_sequence_tables_two_workgroups_per_cu(ctx):
+    """131072 frames of 4 KiB: ~400 sequences each, so the batch's largest LL / ML / OF tables are small, k_seq_q4 sizes
+    its chains' LDS slots to them and two of its workgroups share a CU (and every chain's last step, the loop variant
+    near the end of a chain and the per-workgroup staging weigh far more than in the 128 KiB configs)."""
+    st = _run_full_config(4, 131072, ctx, frame_bytes=4096)
+    assert st.n_sequences > 131072 * 200
 
 
 # ---- BASELINE configs[4]: the sharded bench, launched by bench.py itself
