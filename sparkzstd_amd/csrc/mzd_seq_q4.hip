@@ -50,7 +50,7 @@ constexpr int kQ4Chains = 54;  // chains per workgroup: what LDS holds next to a
 static_assert(kQ4MaxChains >= kQ4Chains + 1 && kQ4Chains < kQ4Cols - 1 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
 
 #ifdef MZD_Q4_STATS
-__device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps, cycles in them
+__device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps, cycles in them, chains in general steps by reason (last sequence | escape cell << 20 | bits << 40)
 #endif
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_quad(uint32_t v)  // quad_perm, all rows and banks, out-of-range lanes read 0
@@ -240,6 +240,16 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             D = ld64u(inb + off);
         };
         auto peek = [&](int n) -> uint32_t { return (uint32_t)(((C << k) >> 1) >> (63 - n)); };
+        // the same window fed from the chain's LDS ring (general step: wave P keeps the bytes around the cursor there; a
+        // global load per refill was most of a general step's ~1500 cycles, and the other chain wavefronts wait for it)
+        auto ring64 = [&](uint32_t u) -> uint64_t { return ((const U64U *)(shs->ring[ch] + (u & (uint32_t)(kPipeRing - 1))))->v; };
+        auto refill_ring = [&]() {
+            const int nb = k >> 3, sh = nb * 8;
+            C = (C << sh) | ((D >> 1) >> (63 - sh));
+            off -= (uint32_t)nb;
+            k &= 7;
+            D = ring64(off);
+        };
         uint32_t sL = 0, sM = 0, sO = 0;
         bool live = has && t.n_seq > 0;
         if (live && spare) {
@@ -262,9 +272,11 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         uint32_t wk = (uint32_t)k;
         uint32_t rem1 = (uint32_t)rem + 1u;
         uint32_t last_i = t.n_seq - 1;
-        live = live && (bool)__shfl((int)(status == MZD_OK), lane | 3, 64);
+        live = live && (bool)dpp_quad<QP(3, 3, 3, 3)>((uint32_t)(status == MZD_OK));
         // ---- hand the chain's state to its four lanes
-        auto from_spare = [&](uint32_t v) -> uint32_t { return (uint32_t)__shfl((int)v, lane | 3, 64); };
+        // (within a chain's four lanes: DPP quad permutes, one instruction each; a __shfl is an LDS round trip, and ten of
+        // them were two thirds of a general step)
+        auto from_spare = [&](uint32_t v) -> uint32_t { return dpp_quad<QP(3, 3, 3, 3)>(v); };
         uint32_t st;  // this lane's FSE state, pre-biased by the table size
         uint32_t cb, shr, Kc, nbK;
         {
@@ -291,7 +303,11 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             next = x & 1023;
             ct = CTc[kind * 64 + (x >> 10)];
             if (next == 0) {  // escape: the symbol is only in the host cell
+#ifdef MZD_ABL_Q4_NOESC  /* ablation: timing experiment only, wrong results */
+                const uint32_t e = 0x2D020000u + toff * 0u + idx * 0u;
+#else
                 const uint32_t e = fse_entries[toff + idx];
+#endif
                 const uint32_t sym = e >> 24;
                 next = ((e & 0xFFFF) + size) >> ((e >> 16) & 0xFF);
                 ct = kind == 0 ? (c_ll_base[min(sym, 35u)] | ((uint32_t)c_ll_extra[min(sym, 35u)] << 24))
@@ -304,17 +320,25 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         // General step of sequence `idx` for the chains in `mine` (their queue entries of this step are rewritten as
         // mode 1), run by the chain's fourth lane on the chain's three states, as k_seq_pipe's.
         auto general_step = [&](uint32_t idx, bool mine) {
-            const uint32_t b0 = (uint32_t)lane & ~3u;
-            uint32_t gL = (uint32_t)__shfl((int)st, b0, 64), gM = (uint32_t)__shfl((int)st, b0 + 1, 64), gO = (uint32_t)__shfl((int)st, b0 + 2, 64);
+            uint32_t gL = dpp_quad<QP(0, 0, 0, 0)>(st), gM = dpp_quad<QP(1, 1, 1, 1)>(st), gO = dpp_quad<QP(2, 2, 2, 2)>(st);
             bool parkq = false;
             if (mine && spare) {
                 const bool lastseq = idx == last_i;
-                // the window as the general step keeps it: C = the 8 bytes at the cursor, D = the 8 below
+                // the window as the general step keeps it: C = the 8 bytes at the cursor, D = the 8 below.  The step reads
+                // down to 22 bytes below the cursor (two refills of up to 7 bytes); a batch's ring check only promises
+                // 40 - 28: tell wave P where the cursor is and wait until its ring reaches 24 below (it keeps 88)
+                __hip_atomic_store(&shs->progress[ch], woff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(&shs->ring_low[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > woff - 24u)
+                    __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
                 off = woff - 8u;
                 k = (int)wk;
-                C = ld64u(inb + woff);
-                D = ld64u(inb + off);
+                C = ring64(woff);
+                D = ring64(off);
                 const uint32_t xl = cL[gL], xm = cM[gM], xo = cO[gO];
+#ifdef MZD_Q4_STATS_REASONS  /* (an atomic per chain: distorts the timing of the build) */
+                atomicAdd(&g_q4_stats[7], lastseq ? 1ull : (((xl & 1023) == 0 || (xm & 1023) == 0) ? (1ull << 20) : (1ull << 40)));
+#endif
                 uint32_t nl = 1, nm = 1, cl = 0, cm = 0;
                 full_cell(0, xl, gL - sizeL, t.ll_off, sizeL, nl, cl);
                 full_cell(1, xm, gM - sizeM, t.ml_off, sizeM, nm, cm);
@@ -332,9 +356,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     ok = false;
                 }
                 if (ok) {
-                    const uint32_t ofx = peek((int)exO); k += (int)exO; refill();
+                    const uint32_t ofx = peek((int)exO); k += (int)exO; refill_ring();
                     const uint32_t mlx = peek((int)exM); k += (int)exM;
-                    const uint32_t llx = peek((int)exL); k += (int)exL; refill();
+                    const uint32_t llx = peek((int)exL); k += (int)exL; refill_ring();
                     const uint32_t aL = peek((int)nbL); k += (int)nbL;
                     const uint32_t aM = peek((int)nbM); k += (int)nbM;
                     const uint32_t aO = peek((int)nbO); k += (int)nbO;
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 }
             }
             // back to the chain's four lanes (the cursor normalised: wk < 8)
-            const bool minech = (bool)__shfl((int)(mine && spare), lane | 3, 64);
+            const bool minech = (bool)from_spare((uint32_t)(mine && spare));
             const uint32_t nL = from_spare(gL), nM = from_spare(gM), nO = from_spare(gO);
             const uint32_t nwoff = from_spare(woff), nwk = from_spare(wk), nrem1 = from_spare(rem1);
             if (minech) {
@@ -364,7 +388,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 wk = nwk & 7u;
                 rem1 = nrem1;
             }
-            if ((bool)__shfl((int)parkq, lane | 3, 64)) park();
+            if ((bool)from_spare((uint32_t)parkq)) park();
         };
 
         // ---- the hot loop.  The cursor is normalised at the END of a step (wk < 8 on entry).  Runs steps until a chain

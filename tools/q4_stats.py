@@ -25,5 +25,7 @@ w, steps, cyc, qf, rp, gen = st[0], st[1], st[2], st[3], st[4], st[5]
 print(f"chain wavefronts {w}, steps/wavefront {steps / w:.0f}, cycles/step {cyc / steps:.1f}, queue-full polls/batch {qf / (steps / 4):.3f}, "
       f"ring polls/batch {rp / (steps / 4):.3f}, general steps/wavefront {gen / w:.1f}, cycles per general step {st[6] / max(gen, 1):.0f} "
       f"({100.0 * st[6] / cyc:.1f} % of stage A's time)")
+r = st[7]
+print(f"chains in general steps, by reason: last sequence {r & 0xFFFFF}, escape cell {(r >> 20) & 0xFFFFF}, more bits than the window holds {r >> 40}")
 _, status, _ = rb.download(want_out=False)
 print("status ok", bool((status == 0).all()))
