@@ -58,6 +58,10 @@ __device__ __forceinline__ void touch_line_nowait(const uint8_t *p)
     asm volatile("global_load_dword v255, %0, off" : : "v"(p) : "memory", "v255");
 }
 
+// wave votes on a bool without the int round trip of __any / __ballot (v_cndmask 0/1 + v_cmp per vote): the condition's
+// lane mask is the ballot
+__device__ __forceinline__ uint64_t wave_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 #pragma unroll
@@ -2254,7 +2258,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     const uint32_t outEnd = tb.out_pos + wave_incl_scan_dpp(LL + ML);
                     const uint32_t dstM = outEnd - ML, dstL = dstM - LL, srcL = litEnd - LL;
                     const bool bad = valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstM);
-                    if (__any(bad)) {
+                    if (wave_any(bad)) {
                         if (lane == 0) atomicMax(&sh->error, MZD_ERR_OFFSET);
                     } else {
                         exec_tile_in_hbm(out, outPos, lits, litRle, rleWord, LL, ML, off, dstL, dstM, srcL, valid, lane);
@@ -2303,7 +2307,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                 const uint32_t outEnd = tb.out_pos + wave_incl_scan_dpp(LL + ML);
                 const uint32_t dstMb = outEnd - ML, srcL = litEnd - LL;  // block-relative
                 const bool bad = valid && ML > 0 && (off <= 0 || (uint64_t)off > outPos + dstMb);  // ringbuffer.go:206-214
-                if (__any(bad)) {
+                if (wave_any(bad)) {
                     if (lane == 0) atomicMax(&sh->error, MZD_ERR_OFFSET);
                 }
                 // chunk-relative positions
@@ -2313,10 +2317,10 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                 // ---- literals (sequence_execution.go:19-34): they depend on nothing
                 {
                     const uint32_t sLL = (valid && LL <= 32) ? LL : 0;  // up to two 16-byte loads per lane
-                    if (__any(sLL != 0)) {
+                    if (wave_any(sLL != 0)) {
                         U128U a{rleWord, rleWord, rleWord, rleWord}, c{rleWord, rleWord, rleWord, rleWord};
                         uint32_t wt = rleWord;
-                        const bool two = __any(sLL > 16);  // wave-uniform: a second 16-byte half exists somewhere
+                        const bool two = wave_any(sLL > 16);  // wave-uniform: a second 16-byte half exists somewhere
                         if (sLL) {
                             if (!litRle) {
 #ifndef MZD_ABL_EXEC_NOLIT  /* ablations: timing experiments only, wrong results */
@@ -2333,7 +2337,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                             publish(vmap, dstL, sLL);
                         }
                     }
-                    uint64_t longs = __ballot(valid && LL > 32);
+                    uint64_t longs = wave_ballot(valid && LL > 32);
                     EXEC_STAT(10, __popcll(longs));
                     EXEC_STAT(11, __popcll(__ballot(sLL != 0)));
                     while (longs) {
@@ -2357,11 +2361,11 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                     const bool g = pending && ML <= 32 && !overlap && srcM + (int)ML <= 0;
                     EXEC_STAT(1, __popcll(__ballot(pending)));
                     EXEC_STAT(2, __popcll(__ballot(g)));
-                    if (__any(g)) {
+                    if (wave_any(g)) {
                         const uint8_t *sp = bout + (int)chunkStart + srcM;  // may point into earlier blocks
                         U128U a{0, 0, 0, 0}, c{0, 0, 0, 0};
                         uint32_t wt = 0;
-                        const bool two = __any(g && ML > 16);
+                        const bool two = wave_any(g && ML > 16);
                         if (g) {
 #ifndef MZD_ABL_EXEC_NOFAR
                             a = *(const U128U *)sp;
@@ -2522,9 +2526,9 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                 // in C++.  Same stores in the same order as the C++ fast pass; DS operations of a wavefront execute in
                 // order, so the bytes are in LDS before their validity bits.
                 const bool fastK = fastKind && ML >= 3;  // (a match is >= 3 bytes by the format; the hand-written copy relies on it)
-                uint64_t F = __ballot(pending && fastK);
-                uint64_t S = __ballot(pending && isShort && !fastK);
-                uint64_t L = __ballot(pending && !isShort);
+                uint64_t F = wave_ballot(pending && fastK);
+                uint64_t S = wave_ballot(pending && isShort && !fastK);
+                uint64_t L = wave_ballot(pending && !isShort);
                 const uint32_t na = (uint32_t)(uintptr_t)(vmap + needw);
                 const uint32_t nlo = (uint32_t)needm, nhi = (uint32_t)(needm >> 32);
                 const uint32_t srcA = (uint32_t)(uintptr_t)lbuf + (uint32_t)srcM, dstA = (uint32_t)(uintptr_t)lbuf + dstM;
