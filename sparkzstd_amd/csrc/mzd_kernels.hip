@@ -2601,6 +2601,7 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                         "s_cbranch_execz L_ex_pub_%=\n\t"
                         MZD_EXEC_BLOCK(24, 28)
                         "L_ex_pub_%=:\n\t"
+                        // (one 64-bit atomic on the aligned pair of bitmap words + a rare third word: k_exec 11.0 -> 11.15 ms)
                         "s_mov_b64 exec, %[T]\n\t"
                         "ds_or_b32 %[pa], %[plo]\n\t"
                         "v_cmp_ne_u32 vcc, 0, %[phi]\n\t"
