@@ -130,7 +130,16 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     Q4Shared *shs = (Q4Shared *)(smem + 512);
     uint16_t *cells = (uint16_t *)(smem + kQ4FixedLds);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4, 5: stage B (even / odd batches); 6: C1; 7: C2; 8: P
+    // Which stage wavefronts 4..8 run (logical ids 4 = B even batches, 5 = B odd, 6 = C1, 7 = C2, 8 = P).  Wavefront w of
+    // a workgroup runs on SIMD w % 4 beside chain wavefront w % 4, and the four chain wavefronts advance in lockstep (they
+    // share the queue), so the busiest SIMD sets everybody's step.  Measured per step: P beside chain wavefront 0 and C2 as
+    // the third wavefront of that SIMD, B / B / C1 beside the others: 307 cycles; in the order of the stages: 316.
+#ifndef MZD_Q4_ROLES
+#define MZD_Q4_ROLES {8, 4, 5, 6, 7}
+#endif
+    const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4..8: the stages, see above
+    constexpr int kRoles[5] = MZD_Q4_ROLES;
+    const int lw = wave < kQ4ChainWaves ? wave : kRoles[wave - kQ4ChainWaves];
     const bool chainw = wave < kQ4ChainWaves;
     // the chain this lane works for: chain wavefronts 4 lanes per chain, the others one lane per chain
     const uint32_t quad = (uint32_t)lane >> 2, role = (uint32_t)lane & 3u;
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         t.in_off = 0; t.rec_off = 0; t.tile_off = 0; t.block = 0; t.hist_known = 0;
     }
     in += in_base;
-    if (wave == 8) {
+    if (lw == 8) {
         CTc[lane] = 0;
         CTc[64 + lane] = 0;
         shs->progress[lane] = (uint32_t)t.in_off + MZD_IN_PAD + t.in_size;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     // ---- stage the three tables of every chain of this workgroup (as k_seq_pipe: one flat loop, 8 loads in flight)
     {
         uint32_t *desc = (uint32_t *)&shs->q1w[0][0];  // [chain][4]: ll_off, ml_off, of_off, logs
-        if (wave == 4) {
+        if (lw == 4) {
             desc[4 * lane + 0] = t.ll_off;
             desc[4 * lane + 1] = t.ml_off;
             desc[4 * lane + 2] = t.of_off;
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     uint32_t nmax;
     {
         uint32_t *nm = (uint32_t *)&shs->q2[0][0];
-        if (wave == 4) {
+        if (lw == 4) {
             const uint32_t m = wave_max_u32(has ? t.n_seq : 0u);
             if (lane == 0) nm[0] = m;
         }
@@ -665,11 +674,11 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #endif
         (void)polls;
         if (spare && has && t.n_seq > 0) shs->stA[ch] = status;
-    } else if (wave == 4 || wave == 5) {
+    } else if (lw == 4 || lw == 5) {
         // ================= stage B: field extraction and values, four steps at a time.  TWO wavefronts: wave 4 takes the
         // even batches (queue slots 0..3), wave 5 the odd ones (slots 4..7) -- a wavefront issues an instruction every ~6
         // cycles, and the ~55 of a stage-B step would otherwise be longer than stage A's step.
-        const uint32_t par = (uint32_t)wave - 4u;
+        const uint32_t par = (uint32_t)lw - 4u;
         const int col = min(lane, kQ4Cols - 1);  // lanes 56..63 have no column: they shadow the last one
         uint32_t head_seen = 0, tail_seen = 0;
 #ifdef MZD_Q4_PROF
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_Q4_PROF
         if (blockIdx.x == 0 && lane == 0) printf("B%u: cycles %lld wait_in %lld wait_out %lld (steps %u)\n", par, clock64() - prof_t0, prof_in, prof_out, nmax);
 #endif
-    } else if (wave == 6) {
+    } else if (lw == 6) {
         // ================= stage C1: repeat-offset history (sequence_execution.go:65-114), record packing =================
         // Branch-free per sequence: errors are sticky (a failed block's records, sums and history are never used), the
         // history update is a chain of selects.  The steps that every chain of the workgroup still has (the first
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             bs->hist[2] = (int)h2 >> 3;
         }
         shs->stC[lane] = status;
-    } else if (wave == 7) {
+    } else if (lw == 7) {
         // ================= stage C2: running sums, tile bases, and the finished records leave for HBM =================
         // two 16-byte stores per lane and batch instead of four 8-byte ones (every store is a scatter over the chains'
         // record streams)
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #endif
     // decode-stage errors come first, as in the reference, where DecodeSequences runs to its end
     // before ExecuteSequences starts
-    if (wave == 6 && has && t.n_seq > 0) {
+    if (lw == 6 && has && t.n_seq > 0) {
         int st = shs->stA[lane];
         if (st == MZD_OK) st = shs->stC[lane];
         if (st == MZD_OK) st = shs->stC2[lane];
