@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""GPU box: what a consumer gets that uses the reference-shaped FrameReader ONE FRAME AT A TIME (one device batch,
+i.e. plan + upload + six launches + download, per frame) against the batch entry on the same frames.  The reader
+mirrors sparkzstd's API; throughput comes from batching (DecodeFrames / mzd_stream_*), and this tool puts the
+number on the difference.  usage: python tools/reader_bench.py [n_frames]"""
+import io, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sparkzstd_amd as z
+from tools import synth_binding as sb
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+blob, off, ln, cks, nseq = sb.make_batch(4, 0, n, 131072, threads=8)
+frames = [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+ctx = z.default_context()
+z.decode_frames(frames[:4], ctx)  # warm-up: context, kernels
+t0 = time.time()
+total = 0
+for f in frames:
+    r = z.FrameReader(io.BytesIO(f))
+    total += len(r.read())
+t1 = time.time()
+outs, sts = z.decode_frames(frames, ctx)
+t2 = time.time()
+assert all(s == 0 for s in sts) and total == sum(len(o) for o in outs)
+print(f"FrameReader, one frame per call: {n / (t1 - t0):.0f} frames/s, {total / (t1 - t0) / 1e6:.0f} MB/s "
+      f"({(t1 - t0) / n * 1e3:.2f} ms per frame)")
+print(f"decode_frames, one batch of {n}: {n / (t2 - t1):.0f} frames/s, {total / (t2 - t1) / 1e6:.0f} MB/s (host to host, pageable memory)")
