@@ -448,6 +448,26 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 tail1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail1);
                 polls = (uint32_t)__builtin_amdgcn_readfirstlane((int)polls);
                 if (live) left = last_i - i;
+#ifdef MZD_ABL_Q4_NOW1  /* ablations: timing experiments only, wrong results */
+#define MZD_Q4_W1 "s_nop 0\n\t"
+#else
+#define MZD_Q4_W1 "s_waitcnt lgkmcnt(3)\n\t"
+#endif
+#ifdef MZD_ABL_Q4_NOW2
+#define MZD_Q4_W2 "s_nop 0\n\t"
+#else
+#define MZD_Q4_W2 "s_waitcnt lgkmcnt(0)\n\t"
+#endif
+#ifdef MZD_ABL_Q4_ALIGNED  /* ablations: timing experiments only, wrong results */
+#define MZD_Q4_RMASK "120"
+#else
+#define MZD_Q4_RMASK "127"
+#endif
+#ifdef MZD_ABL_Q4_NOQW
+#define MZD_Q4_QWR(X) "s_nop 0\n\t"
+#else
+#define MZD_Q4_QWR(X) X
+#endif
 #define Q4_RINGCHK(TAG)                                                                                     \
     "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n"                                                      \
     "L_q4_ring" TAG "_%=:\n\t"                                                                              \
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 // goes.  LIMIT: the instruction(s) that finish the next step's limit in v85 (from 64 - k).
 #define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                        \
     "L_q4_go" TAG "_%=:\n\t"                                                                                \
-    "s_waitcnt lgkmcnt(3)\n\t"                      /* the cell (behind it: two queue writes, the ring read) */ \
+    MZD_Q4_W1                                       /* the cell (behind it: two queue writes, the ring read) */ \
     "v_lshrrev_b32 v76, %[shr], v69\n\t"          /* code field */                                        \
     "v_and_b32 v77, 0x3ff, v69\n\t"               /* next */                                              \
     "v_cndmask_b32_e64 v88, v69, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
@@ -497,7 +517,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "v_min_u32 v78, 0x4000000, v78\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
     "v_sub_u32 v78, v78, %[nbK]\n\t"              /* nb */                                                \
     "v_add_u32_dpp v79, v76, v76 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
-    "s_waitcnt lgkmcnt(0)\n\t"                      /* the window */                                        \
+    MZD_Q4_W2                                       /* the window */                                        \
     "v_mov_b32_dpp v72, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
     "v_add_u32_dpp v80, v78, v78 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
     "v_add_u32_dpp v81, v79, v79 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
@@ -512,7 +532,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "v_cmp_lt_u32 vcc, v87, v85\n\t"              /* go (the same in the four lanes of a chain) */        \
     "v_lshl_add_u32 v66, %[s" SB "], 1, %[cb]\n\t"                                                         \
     "ds_read_u16 v69, v66\n\t"                    /* the NEXT step's cell; the rest of the step runs behind it */ \
-    "ds_write_b16 %[qca], v88 offset:" QC "\n\t"                                                           \
+    MZD_Q4_QWR("ds_write_b16 %[qca], v88 offset:" QC "\n\t")                                               \
     "v_cndmask_b32 v87, 0, v87, vcc\n\t"                                                                  \
     "v_sub_u32 %[rem1], %[rem1], v87\n\t"                                                                  \
     "v_add_u32 %[k], %[k], v87\n\t"                                                                        \
@@ -520,12 +540,12 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
     "v_sub_u32 %[off], %[off], v70\n\t"                                                                    \
     "v_sub_u32 v85, 64, %[k]\n\t"                                                                          \
-    "v_and_b32 v71, 127, %[off]\n\t"                                                                   \
+    "v_and_b32 v71, " MZD_Q4_RMASK ", %[off]\n\t"                                                          \
     LIMIT                                           /* the next limit = min(64 - k, rem + 1[, steps before the last]) */ \
     "v_add_u32 v71, v71, %[ringl]\n\t"                                                                    \
     "s_andn2_b64 %[smask], exec, vcc\n\t"           /* chains that need the general step; SCC = any */      \
     "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
-    "ds_write_b64 %[qwa], v[72:73] offset:" QW "\n\t" /* this step's window for stage B */                \
+    MZD_Q4_QWR("ds_write_b64 %[qwa], v[72:73] offset:" QW "\n\t") /* this step's window for stage B */     \
     "ds_read_b64 " DL ", v71\n\t"                  /* the next step's window */                            \
     "s_mov_b64 exec, -1\n\t"                                                                                \
     RLOW                                                                                                    \
