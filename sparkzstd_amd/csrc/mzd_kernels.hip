@@ -337,8 +337,62 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         //    consumed) and issues the next load.  Bytes below the stream's start may be in those 16; only indices
         //    >= 2 of them are ever taken.  (Config 3, MaxBits 11: 3.43 -> 3.18 ms; with eight symbols per refill
         //    the extra shifts cost more than the gathers saved: 25.5 -> 25.7 ms.)
+        // A 16-byte load that serves TWO refills (the first takes its top bytes, the second the bytes `s` below the top --
+        // s <= 7 = what the first consumed -- and issues the next load).  Bytes below the stream's start may be in those
+        // 16; only indices >= 2 of them are ever taken.
+        const uint8_t *sb = br.s;
+        uint64_t Qhi = 0, Qlo = 0;
+        uint32_t s8 = 0;  // 8 * (bytes of Q already taken)
+        auto q_begin = [&]() {  // Q = the 16 bytes below the window; its upper half is the 8-byte lookahead the reader already holds
+            Qhi = br.D;
+            Qlo = ld64u(sb + max(br.ptr - 16, -16));
+        };
+        auto refill_first = [&]() {  // takes the top bytes of a fresh Q
+            const int nb = br.k >> 3, sh = nb * 8;
+            br.C = (br.C << sh) | ((Qhi >> 1) >> (63 - sh));
+            br.ptr -= nb;
+            br.k &= 7;
+            s8 = (uint32_t)sh;
+        };
+        auto refill_second = [&]() {  // takes the bytes s below the top of Q, then requests the next Q
+            const int nb = br.k >> 3, sh = nb * 8;
+            const uint64_t M = (Qhi << s8) | ((Qlo >> 1) >> (63 - s8));
+            br.C = (br.C << sh) | ((M >> 1) >> (63 - sh));
+            br.ptr -= nb;
+            br.k &= 7;
+            const U128U q = *(const U128U *)(sb + max(br.ptr - 16, -16));  // ONE 16-byte gather
+            Qlo = (uint64_t)q.x | ((uint64_t)q.y << 32);
+            Qhi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+        };
         if (mbw <= 5) {
-            // ELEVEN symbols between two refills (7 + 11 * 5 <= 64): 32 symbols per iteration with three refills
+            // ELEVEN symbols fit between two refills (7 + 11 * 5 <= 64).  k_huf is bound by the CU's address unit (TA_BUSY =
+            // the kernel's duration: every load and store of a wavefront is a 64-line scatter), so what counts is memory
+            // INSTRUCTIONS per symbol: 64 symbols per iteration in groups of 11, 11, 10, 11, 11, 10 -- six refills fed by
+            // three 16-byte loads -- and four 16-byte stores: 7 per 64 symbols (three 8-byte refill loads and two stores per
+            // 32 symbols before: 10 per 64).
+            if (cnt + 64 <= want && rem >= 64 * 5) {
+                q_begin();
+                do {
+                    uint32_t w[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) w[j] = 0;
+#pragma unroll
+                    for (int j = 0; j < 64; j++) {
+                        if (j == 0 || j == 22 || j == 43) refill_first();
+                        if (j == 11 || j == 32 || j == 54) refill_second();
+                        uint32_t idx = (uint32_t)((br.C << br.k) >> (64 - mb));
+                        uint32_t e = tbl[idx];
+                        w[j >> 2] |= (e & 0xFF) << (8 * (j & 3));
+                        int nb = (int)(e >> 8);
+                        br.k += nb;
+                        rem -= nb;
+                        if ((j & 15) == 15) *(U128U *)(out + cnt + (j & ~15)) = U128U{w[(j >> 2) - 3], w[(j >> 2) - 2], w[(j >> 2) - 1], w[j >> 2]};
+                    }
+                    cnt += 64;
+                } while (cnt + 64 <= want && rem >= 64 * 5);
+                br.D = br.load_below(br.ptr - 8);  // back to the 8-byte lookahead of the loops below
+            }
+            // what is left of the stream above 32 symbols: three 8-byte refills per 32 symbols
             while (cnt + 32 <= want && rem >= 32 * 5) {
                 uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -381,27 +435,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                 cnt += 16;
             }
         } else if (cnt + 16 <= want && rem >= 16 * 11) {
-            const uint8_t *sb = br.s;
-            // Q = the 16 bytes below the window; its upper half is the 8-byte lookahead the reader already holds
-            uint64_t Qhi = br.D, Qlo = ld64u(sb + max(br.ptr - 16, -16));
-            uint32_t s8 = 0;  // 8 * (bytes of Q already taken)
-            auto refill_first = [&]() {  // takes the top bytes of a fresh Q
-                const int nb = br.k >> 3, sh = nb * 8;
-                br.C = (br.C << sh) | ((Qhi >> 1) >> (63 - sh));
-                br.ptr -= nb;
-                br.k &= 7;
-                s8 = (uint32_t)sh;
-            };
-            auto refill_second = [&]() {  // takes the bytes s below the top of Q, then requests the next Q
-                const int nb = br.k >> 3, sh = nb * 8;
-                const uint64_t M = (Qhi << s8) | ((Qlo >> 1) >> (63 - s8));
-                br.C = (br.C << sh) | ((M >> 1) >> (63 - sh));
-                br.ptr -= nb;
-                br.k &= 7;
-                const U128U q = *(const U128U *)(sb + max(br.ptr - 16, -16));  // ONE 16-byte gather
-                Qlo = (uint64_t)q.x | ((uint64_t)q.y << 32);
-                Qhi = (uint64_t)q.z | ((uint64_t)q.w << 32);
-            };
+            q_begin();
             do {
                 uint32_t w[4];
 #pragma unroll
