@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--exec-chunk", type=int, default=0)
     ap.add_argument("--huf-min-lds", type=int, default=0)
-    ap.add_argument("--huf-variant", type=int, default=0, help="0 auto, 1 k_huf (lane per stream), 2 k_huf_seg (wavefront per stream)")
+    ap.add_argument("--huf-variant", type=int, default=0, help="0 auto, 1 k_huf beside the sequence stage, 2 k_huf_seg (wavefront per stream), 3 k_huf first (transposed bulk phase)")
     ap.add_argument("--no-split", action="store_true", help="do not overlap k_seq(tail) with k_exec(head)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-threads", type=int, default=0)

@@ -216,8 +216,10 @@ typedef struct mzd_options {
                                  just under 4 GiB -- the kernel addresses bitstreams with 32-bit offsets from the
                                  window; larger blobs are decoded window by window) */
     uint32_t huf_variant;     /* Huffman literal kernel: 0 = by the batch (k_huf_seg when streams are long and few, else
-                                 k_huf); 1 = k_huf (one lane per stream); 2 = k_huf_seg (one wavefront per stream, segments
-                                 decoded in parallel: Huffman codes self-synchronise) */
+                                 k_huf; k_huf FIRST, with its transposed bulk phase, when the batch also has sequences, many
+                                 streams and small tables); 1 = k_huf (one lane per stream) beside the sequence stage; 2 =
+                                 k_huf_seg (one wavefront per stream, segments decoded in parallel: Huffman codes
+                                 self-synchronise); 3 = k_huf first with the transposed bulk phase; see DESIGN.md */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

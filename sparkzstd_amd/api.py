@@ -187,7 +187,7 @@ class Context:
         opt.no_split = 1 if no_split else 0
         opt.assume_cus = assume_cus
         opt.verify_checksum = 1 if verify_checksum else 0  # extension: the reference never checks it
-        opt.huf_variant = huf_variant  # 0 auto, 1 k_huf (lane per stream), 2 k_huf_seg (wavefront per stream)
+        opt.huf_variant = huf_variant  # 0 auto, 1 k_huf beside the sequence stage, 2 k_huf_seg, 3 k_huf first with its transposed bulk phase
         opt.seq_window_kib = seq_window_kib  # testing: size of the blob window one k_seq_pipe launch covers
         err = ctypes.c_int()
         self._c = self._L.mzd_create(device, ctypes.byref(opt), ctypes.byref(err))

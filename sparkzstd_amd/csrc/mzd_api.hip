@@ -1122,7 +1122,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                          kQ4FixedLds + kQ4MaxChains * kSeqCellsPerChain * 2));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2 + 16 + kHufTStageBytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_seg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_set = true;
     }
@@ -1132,7 +1132,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
-    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 2) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3) return MZD_ERR_INVALID_ARG;
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1288,6 +1288,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_init_done, s));
+    // The lane-per-stream Huffman kernel beside the sequence stage cost that stage 2 ms of the pass (both fill the CU's
+    // address unit).  With sequences to decode and many streams it runs FIRST, alone, with its transposed bulk phase (global
+    // memory in 64-byte runs through an LDS staging area that does not fit beside the sequence stage).
+    // (huf_variant 3 forces it; by default it takes tables of at most 32 cells -- the bulk phase is for MaxBits <= 5 --
+    // and enough streams to fill the chip)
+    const bool huf_first = ctx->opt.huf_variant == 3 ||
+                           (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
+                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !getenv("MZD_EXP_HUF_BESIDE"));
     auto launch_huf = [&]() {
         if (!db->n_huf_tasks) return;
         // Which Huffman kernel: a lane per stream (k_huf) needs >= 64 streams per wavefront and many wavefronts per CU
@@ -1301,23 +1309,37 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = getenv("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
         if (seg)
-            k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
+            k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                db->d_litbuf, db->d_sums, seg_tbl);
-        else
+        else if (huf_first) {
+            const uint32_t tstage = (uint32_t)((huf_lds + 15) & ~(size_t)15);
+            k_huf<<<(db->n_huf_tasks + 63) / 64, 64, tstage + kHufTStageBytes, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks,
+                                                                                   db->d_huf_entries, db->d_litbuf, db->d_sums,
+                                                                                   db->huf_slot_cells, tstage);
+        } else
             k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
-                                                                  db->d_litbuf, db->d_sums, db->huf_slot_cells);
+                                                                  db->d_litbuf, db->d_sums, db->huf_slot_cells, 0u);
     };
     // k_seq(head) is submitted FIRST so that its workgroups (nearly all of a CU's LDS each) claim the
     // CUs; k_huf's small workgroups then fill what is left instead of delaying them.  (Tried: k_huf beside the LAST,
     // partial round of the sequence stage instead of the first, k_exec in one launch after both: 22.3-22.5 ms against
     // 21.2-21.8 ms per pass.)
-    launch_seq(0, fA);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
-    HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
-    launch_huf();
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
+    if (huf_first) {
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s));
+        launch_huf();
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s));
+        launch_seq(0, fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
+    } else {
+        launch_seq(0, fA);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
+        launch_huf();
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
+    }
     if (split) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_head_ready, s));
         HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_head_ready, 0));

@@ -287,9 +287,21 @@ __global__ __launch_bounds__(64) void k_huf_build(const HufBuildDesc *__restrict
 
 constexpr int kHufQuads = 16;
 
+// Staging area of the transposed bulk phase (tstage != 0): per lane a 128-byte ring of its stream (+ 8 bytes that repeat the
+// first 8, for reads that cross the end), 64 bytes of regenerated symbols, and what the lanes tell each other.
+constexpr int kHufTRing = 128, kHufTRow = kHufTRing + 16, kHufTOut = 64;  // (rows stay 16-byte aligned)
+struct HufTMeta {
+    uint32_t need[64];   // the stream wants its next chunk loaded
+    int32_t chunk[64];   // ... this one (64-byte chunks of the stream, counted from its start; -1: the zeros below it)
+    uint32_t bulk[64];   // the stream takes part in this iteration (its 64 symbols are to be stored)
+    uint64_t in_off[64];
+    uint64_t out_off[64];
+};
+constexpr int kHufTStageBytes = 64 * kHufTRow + 64 * kHufTOut + (int)sizeof(HufTMeta);
+
 __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, const HufTask *__restrict__ tasks,
                                             uint32_t n_tasks, const uint16_t *__restrict__ huf_entries,
-                                            uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t slot_cells)
+                                            uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t slot_cells, uint32_t tstage)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tbl_all = (uint16_t *)smem;
@@ -314,17 +326,168 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     // (all lanes still active here) largest MaxBits of the wavefront's tables: decides the bulk loop's refill spacing
     const uint32_t mbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(t.max_bits));
     const bool wide = mbw <= 7;
-    if ((t.in_size | t.out_size) == 0) return;  // null task
+    const bool tmode = tstage != 0 && mbw <= 5;  // wave-uniform
+    const bool nulltask = (t.in_size | t.out_size) == 0;
+    if (nulltask && !tmode) return;  // (with the transposed phase every lane stays: it loads and stores for other lanes' streams)
 
     const uint16_t *tbl = tbl_all + (size_t)(lane >> 2) * slot_cells;
     const int mb = (int)t.max_bits;
     BackBits br;
-    int rem = br.init(in + t.in_off, (int)t.in_size);
+    int rem = nulltask ? 0 : br.init(in + t.in_off, (int)t.in_size);
     int status = MZD_OK;
     if (rem < 0) status = MZD_ERR_BAD_PADDING;
     uint8_t *out = litbuf + t.out_off;
     uint32_t cnt = 0;
     const uint32_t want = t.out_size;
+
+    if (tmode) {
+        // ---- transposed bulk phase.  A lane per stream makes every load and store of the wavefront a 64-line scatter, and
+        // the CU's address unit is what k_huf fills (TA_BUSY = its duration; beside the sequence stage it cost that stage
+        // 2 ms of the pass).  Here global memory is touched only in 64-byte runs: FOUR lanes load a stream's next 64-byte
+        // chunk into the stream's LDS ring (16 streams per instruction) and four lanes store a stream's 64 regenerated
+        // bytes; the owner lane decodes from its ring (11 / 11 / 10 symbols between two 8-byte ring reads) into LDS.
+        // An iteration regenerates 64 symbols for every stream that still has 64 symbols and 320 bits to go; what is left
+        // of a stream takes the loops below.  Invariant at the start of an iteration: the ring holds the stream's bytes
+        // [64 clow, 64 clow + 128) and ptr - 40 >= 64 clow (an iteration consumes at most 40 bytes).
+        uint8_t *ringb = smem + tstage;
+        uint8_t *ostb = ringb + 64 * kHufTRow;
+        HufTMeta *mt = (HufTMeta *)(ostb + 64 * kHufTOut);
+        uint8_t *myring = ringb + lane * kHufTRow;
+        const int len = (int)t.in_size;
+        bool inb = !nulltask && status == MZD_OK && 64u <= want && rem >= 64 * 5;
+        uint64_t C = br.C;
+        int k = br.k, ptr = br.ptr;
+        int clow = ((len - 1) >> 6) + 1;  // nothing in the ring yet: the two fills below bring chunks ct and ct - 1
+        mt->in_off[lane] = t.in_off;
+        mt->out_off[lane] = t.out_off;
+        auto fill = [&](bool need) {  // the streams with `need` get chunk clow - 1 (cooperatively), clow moves down
+            mt->need[lane] = need ? 1u : 0u;
+            mt->chunk[lane] = clow - 1;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int sidx = 16 * i + (lane >> 2), piece = lane & 3;
+                if (mt->need[sidx]) {
+                    const int x0 = 64 * mt->chunk[sidx] + 16 * piece;  // stream-relative offset of these 16 bytes
+                    U128U q{0, 0, 0, 0};
+                    if (x0 > -16) {
+                        q = *(const U128U *)(in + mt->in_off[sidx] + x0);  // (the blob has MZD_IN_PAD readable bytes in front)
+                        if (x0 < 0) {  // bytes below the start of the stream read as zero (reversebitstream.go:23-27)
+                            const int z = -x0;  // 1..15 bytes
+                            uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+                            if (z >= 8) { lo = 0; hi = (hi >> (8 * (z - 8))) << (8 * (z - 8)); }
+                            else lo = (lo >> (8 * z)) << (8 * z);
+                            q = U128U{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                        }
+                    }
+                    uint8_t *r = ringb + sidx * kHufTRow;
+                    const int ro = x0 & (kHufTRing - 1);
+                    *(uint4 *)(r + ro) = uint4{q.x, q.y, q.z, q.w};  // row stride 136, offsets multiples of 16: 8-byte aligned
+                    if (ro == 0) *(uint2 *)(r + kHufTRing) = uint2{q.x, q.y};
+                }
+            }
+            if (need) clow -= 1;
+            __syncthreads();
+        };
+        auto ring64 = [&](int x) -> uint64_t { return ((const U64U *)(myring + (x & (kHufTRing - 1))))->v; };
+        if (__any(inb)) {
+            fill(inb);
+            fill(inb);
+            uint32_t it = 0;
+            // From here on a stream's next chunk is REQUESTED at the start of an iteration (when the cursor is within 88
+            // bytes of the ring's low end), travels while the 64 symbols are decoded, and goes into the ring at the END of
+            // the iteration -- if the chunk it replaces is dead by then (cursor + 8 <= 64 clow + 64; else it is dropped and
+            // requested again: the cursor was still more than 48 bytes above the low end).  The global latency hides behind
+            // the decode.
+            do {
+                mt->bulk[lane] = inb ? 1u : 0u;
+                mt->need[lane] = (inb && ptr - 88 < 64 * clow) ? 1u : 0u;
+                mt->chunk[lane] = clow - 1;
+                __syncthreads();
+                U128U q[4];
+                int qx[4];
+                bool qv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int sidx = 16 * i + (lane >> 2), piece = lane & 3;
+                    qv[i] = mt->need[sidx] != 0;
+                    qx[i] = 64 * mt->chunk[sidx] + 16 * piece;
+                    // (always a load, from a harmless address when there is nothing to fetch: a conditional one would make the
+                    // compiler wait for it right here; the blob has MZD_IN_PAD readable bytes in front of the first stream)
+                    q[i] = *(const U128U *)(qv[i] ? in + mt->in_off[sidx] + qx[i] : in);
+                }
+                if (inb) {
+                    uint32_t w[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) w[j] = 0;
+#pragma unroll
+                    for (int j = 0; j < 64; j++) {
+                        if (j == 0 || j == 11 || j == 22 || j == 32 || j == 43 || j == 54) {
+                            ptr -= k >> 3;
+                            k &= 7;
+                            C = ring64(ptr);
+                        }
+                        const uint32_t idx = (uint32_t)((C << k) >> (64 - mb));
+                        const uint32_t e = tbl[idx];
+                        w[j >> 2] |= (e & 0xFF) << (8 * (j & 3));
+                        const int nb = (int)(e >> 8);
+                        k += nb;
+                        rem -= nb;
+                    }
+                    // (the owner lane storing its 64 symbols itself -- four scattered 16-byte stores, no staging: 1.43 vs 1.31 ms)
+                    uint4 *o = (uint4 *)(ostb + lane * kHufTOut);
+                    o[0] = uint4{w[0], w[1], w[2], w[3]};
+                    o[1] = uint4{w[4], w[5], w[6], w[7]};
+                    o[2] = uint4{w[8], w[9], w[10], w[11]};
+                    o[3] = uint4{w[12], w[13], w[14], w[15]};
+                    cnt += 64;
+                }
+                // does the requested chunk go in?  (the cursor after this iteration's last ring read: ptr; k < 64)
+                const bool commit = mt->need[lane] != 0 && (ptr - (k >> 3)) + 8 <= 64 * clow + 64;
+                __syncthreads();  // everybody's ring reads and need / chunk reads are done; the staged symbols are in LDS
+                mt->need[lane] = commit ? 1u : 0u;
+                if (commit) clow -= 1;
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int sidx = 16 * i + (lane >> 2), piece = lane & 3;
+                    if (qv[i] && mt->need[sidx]) {
+                        U128U qq = q[i];
+                        const int x0 = qx[i];
+                        if (x0 < 0) {  // bytes below the start of the stream read as zero (reversebitstream.go:23-27)
+                            const int z = min(-x0, 16);
+                            uint64_t lo = (uint64_t)qq.x | ((uint64_t)qq.y << 32), hi = (uint64_t)qq.z | ((uint64_t)qq.w << 32);
+                            if (z >= 16) { lo = 0; hi = 0; }
+                            else if (z >= 8) { lo = 0; hi = (hi >> (8 * (z - 8))) << (8 * (z - 8)); }
+                            else lo = (lo >> (8 * z)) << (8 * z);
+                            qq = U128U{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                        }
+                        uint8_t *r = ringb + sidx * kHufTRow;
+                        const int ro = x0 & (kHufTRing - 1);
+                        *(uint4 *)(r + ro) = uint4{qq.x, qq.y, qq.z, qq.w};
+                        if (ro == 0) *(uint2 *)(r + kHufTRing) = uint2{qq.x, qq.y};
+                    }
+                    if (mt->bulk[sidx]) {
+                        const uint4 v = *(const uint4 *)(ostb + sidx * kHufTOut + 16 * piece);
+                        *(U128U *)(litbuf + mt->out_off[sidx] + 64ull * it + 16 * piece) = U128U{v.x, v.y, v.z, v.w};
+                    }
+                }
+                it++;
+                inb = inb && cnt + 64 <= want && rem >= 64 * 5;
+                __syncthreads();  // ring and staging are free for the next iteration
+            } while (__any(inb));
+            // back to the reader of the loops below: the 8 bytes at the cursor, whole consumed bytes dropped, lookahead
+            if (!nulltask && status == MZD_OK) {
+                ptr -= k >> 3;
+                k &= 7;
+                br.ptr = ptr;
+                br.k = k;
+                br.C = br.load_below(ptr);
+                br.D = br.load_below(ptr - 8);
+            }
+        }
+        if (nulltask) return;
+    }
 
     if (status == MZD_OK) {
         // bulk: 16 symbols per iteration while at least 16*11 bits and 16 output slots remain.  A refill is a

@@ -13,7 +13,7 @@ n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctxs = [z.Context(0, seq_variant=0), z.Context(0, seq_variant=1, exec_threads=256), z.Context(0, seq_variant=0, exec_threads=64, exec_chunk=4096, huf_variant=2),
-        z.Context(0, seq_variant=3, huf_variant=1)]
+        z.Context(0, seq_variant=3, huf_variant=1), z.Context(0, huf_variant=3)]
 bad = 0
 done = 0
 t0 = time.time()
