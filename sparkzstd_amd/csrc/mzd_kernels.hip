@@ -294,6 +294,7 @@ struct HufTMeta {
     uint32_t need[64];   // the stream wants its next chunk loaded
     int32_t chunk[64];   // ... this one (64-byte chunks of the stream, counted from its start; -1: the zeros below it)
     uint32_t bulk[64];   // the stream takes part in this iteration (its 64 symbols are to be stored)
+    int32_t badj[64];    // stream start's offset in its 64-byte line: chunks are aligned in memory
     uint64_t in_off[64];
     uint64_t out_off[64];
 };
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         // An iteration regenerates 64 symbols for every stream that still has 64 symbols and 320 bits to go; what is left
         // of a stream takes the loops below.  Invariant at the start of an iteration: the ring holds the stream's bytes
         // [64 clow, 64 clow + 128) and ptr - 40 >= 64 clow (an iteration consumes at most 40 bytes).
+        // The workgroup is ONE wavefront and a wavefront's LDS operations execute in order: what one lane wrote is there
+        // for the lane that reads it in a later instruction.  Only the compiler has to keep the order -- a __syncthreads()
+        // would also wait for the global stores of the iteration (7 900 of an iteration's 17 300 cycles).
+        auto lds_order = []() { asm volatile("" ::: "memory"); };
         uint8_t *ringb = smem + tstage;
         uint8_t *ostb = ringb + 64 * kHufTRow;
         HufTMeta *mt = (HufTMeta *)(ostb + 64 * kHufTOut);
@@ -357,21 +362,27 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         bool inb = !nulltask && status == MZD_OK && 64u <= want && rem >= 64 * 5;
         uint64_t C = br.C;
         int k = br.k, ptr = br.ptr;
-        int clow = ((len - 1) >> 6) + 1;  // nothing in the ring yet: the two fills below bring chunks ct and ct - 1
-        mt->in_off[lane] = t.in_off;
+        // chunks are 64-byte aligned in MEMORY (every load is one aligned 16-byte piece of one line): positions in the ring
+        // and chunk numbers are those of x + badj, x the stream-relative byte offset
+        const int badj = (int)((uintptr_t)(in + t.in_off) & 63);
+        int clow = ((len - 1 + badj) >> 6) + 1;  // nothing in the ring yet: the two fills below bring chunks ct and ct - 1
+        mt->in_off[lane] = t.in_off - (uint64_t)badj;  // (of shifted position 0)
         mt->out_off[lane] = t.out_off;
+        mt->badj[lane] = badj;
         auto fill = [&](bool need) {  // the streams with `need` get chunk clow - 1 (cooperatively), clow moves down
             mt->need[lane] = need ? 1u : 0u;
             mt->chunk[lane] = clow - 1;
-            __syncthreads();
+            lds_order();
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int sidx = 16 * i + (lane >> 2), piece = lane & 3;
                 if (mt->need[sidx]) {
-                    const int x0 = 64 * mt->chunk[sidx] + 16 * piece;  // stream-relative offset of these 16 bytes
+                    const int xs = 64 * mt->chunk[sidx] + 16 * piece;  // shifted position of these 16 bytes
+                    const int x0 = xs - mt->badj[sidx];                // stream-relative
                     U128U q{0, 0, 0, 0};
                     if (x0 > -16) {
-                        q = *(const U128U *)(in + mt->in_off[sidx] + x0);  // (the blob has MZD_IN_PAD readable bytes in front)
+                        const uint4 qa = *(const uint4 *)(in + mt->in_off[sidx] + xs);  // (the blob has MZD_IN_PAD readable bytes in front)
+                        q = U128U{qa.x, qa.y, qa.z, qa.w};
                         if (x0 < 0) {  // bytes below the start of the stream read as zero (reversebitstream.go:23-27)
                             const int z = -x0;  // 1..15 bytes
                             uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
@@ -381,15 +392,15 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                         }
                     }
                     uint8_t *r = ringb + sidx * kHufTRow;
-                    const int ro = x0 & (kHufTRing - 1);
-                    *(uint4 *)(r + ro) = uint4{q.x, q.y, q.z, q.w};  // row stride 136, offsets multiples of 16: 8-byte aligned
+                    const int ro = xs & (kHufTRing - 1);
+                    *(uint4 *)(r + ro) = uint4{q.x, q.y, q.z, q.w};
                     if (ro == 0) *(uint2 *)(r + kHufTRing) = uint2{q.x, q.y};
                 }
             }
             if (need) clow -= 1;
-            __syncthreads();
+            lds_order();
         };
-        auto ring64 = [&](int x) -> uint64_t { return ((const U64U *)(myring + (x & (kHufTRing - 1))))->v; };
+        auto ring64 = [&](int x) -> uint64_t { return ((const U64U *)(myring + ((x + badj) & (kHufTRing - 1))))->v; };
         if (__any(inb)) {
             fill(inb);
             fill(inb);
@@ -401,20 +412,23 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
             // the decode.
             do {
                 mt->bulk[lane] = inb ? 1u : 0u;
-                mt->need[lane] = (inb && ptr - 88 < 64 * clow) ? 1u : 0u;
+                mt->need[lane] = (inb && ptr + badj - 88 < 64 * clow) ? 1u : 0u;
                 mt->chunk[lane] = clow - 1;
-                __syncthreads();
+                lds_order();
                 U128U q[4];
-                int qx[4];
+                int qx[4], qz[4];
                 bool qv[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int sidx = 16 * i + (lane >> 2), piece = lane & 3;
                     qv[i] = mt->need[sidx] != 0;
-                    qx[i] = 64 * mt->chunk[sidx] + 16 * piece;
+                    qx[i] = 64 * mt->chunk[sidx] + 16 * piece;  // shifted position
                     // (always a load, from a harmless address when there is nothing to fetch: a conditional one would make the
                     // compiler wait for it right here; the blob has MZD_IN_PAD readable bytes in front of the first stream)
-                    q[i] = *(const U128U *)(qv[i] ? in + mt->in_off[sidx] + qx[i] : in);
+                    qz[i] = qx[i] - mt->badj[sidx];  // stream-relative: < 0 is below the start of the stream
+                    const uint4 qa = *(const uint4 *)(qv[i] && qz[i] > -16 ? in + mt->in_off[sidx] + qx[i]
+                                                                          : (const uint8_t *)((uintptr_t)in & ~(uintptr_t)15));
+                    q[i] = U128U{qa.x, qa.y, qa.z, qa.w};
                 }
                 if (inb) {
                     uint32_t w[16];
@@ -443,17 +457,17 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                     cnt += 64;
                 }
                 // does the requested chunk go in?  (the cursor after this iteration's last ring read: ptr; k < 64)
-                const bool commit = mt->need[lane] != 0 && (ptr - (k >> 3)) + 8 <= 64 * clow + 64;
-                __syncthreads();  // everybody's ring reads and need / chunk reads are done; the staged symbols are in LDS
+                const bool commit = mt->need[lane] != 0 && (ptr + badj - (k >> 3)) + 8 <= 64 * clow + 64;
+                lds_order();  // everybody's ring reads and need / chunk reads are done; the staged symbols are in LDS
                 mt->need[lane] = commit ? 1u : 0u;
                 if (commit) clow -= 1;
-                __syncthreads();
+                lds_order();
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int sidx = 16 * i + (lane >> 2), piece = lane & 3;
                     if (qv[i] && mt->need[sidx]) {
                         U128U qq = q[i];
-                        const int x0 = qx[i];
+                        const int x0 = qz[i];
                         if (x0 < 0) {  // bytes below the start of the stream read as zero (reversebitstream.go:23-27)
                             const int z = min(-x0, 16);
                             uint64_t lo = (uint64_t)qq.x | ((uint64_t)qq.y << 32), hi = (uint64_t)qq.z | ((uint64_t)qq.w << 32);
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                             qq = U128U{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
                         }
                         uint8_t *r = ringb + sidx * kHufTRow;
-                        const int ro = x0 & (kHufTRing - 1);
+                        const int ro = qx[i] & (kHufTRing - 1);
                         *(uint4 *)(r + ro) = uint4{qq.x, qq.y, qq.z, qq.w};
                         if (ro == 0) *(uint2 *)(r + kHufTRing) = uint2{qq.x, qq.y};
                     }
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                 }
                 it++;
                 inb = inb && cnt + 64 <= want && rem >= 64 * 5;
-                __syncthreads();  // ring and staging are free for the next iteration
+                lds_order();  // ring and staging are free for the next iteration
             } while (__any(inb));
             // back to the reader of the loops below: the 8 bytes at the cursor, whole consumed bytes dropped, lookahead
             if (!nulltask && status == MZD_OK) {
