@@ -1139,7 +1139,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // k_seq_pipe: two chains fewer than fit, so that ~6 KiB of every CU's LDS stay free and the small
     // k_huf workgroups run in k_seq's shadow instead of queueing for whole CUs (measured with 54 chains of 56:
     // 28.6 ms per step; 55: 29.5; 56: 32.2; 53: 29.2; 51: 30.9)
-    uint32_t nch = q4 ? (uint32_t)kQ4Chains : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
+    // The lane-per-stream Huffman kernel beside the sequence stage cost that stage 2 ms of the pass (both fill the CU's
+    // address unit).  With sequences to decode and many streams it runs FIRST, alone, with its transposed bulk phase (global
+    // memory in 64-byte runs through an LDS staging area that does not fit beside the sequence stage).
+    // (huf_variant 3 forces it; by default it takes tables of at most 32 cells -- the bulk phase is for MaxBits <= 5 --
+    // and enough streams to fill the chip)
+    const bool huf_first = ctx->opt.huf_variant == 3 ||
+                           (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
+                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !getenv("MZD_EXP_HUF_BESIDE"));
+    uint32_t nch = q4 ? (uint32_t)(huf_first || db->n_huf_tasks == 0 ? kQ4Chains : kQ4ChainsBeside) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
     if (const char *e = getenv("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
     // k_seq_q4 sizes a chain's LDS slot to the batch's largest tables (less to stage, more LDS left for the Huffman
     // workgroups beside it).  With small tables TWO workgroups share a CU: the kernel holds 94 VGPRs (five wavefronts per
@@ -1288,14 +1296,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (db->n_blocks) k_init<<<(db->n_blocks + 255) / 256, 256, 0, s>>>(db->d_sums, db->n_blocks);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_init_done, s));
-    // The lane-per-stream Huffman kernel beside the sequence stage cost that stage 2 ms of the pass (both fill the CU's
-    // address unit).  With sequences to decode and many streams it runs FIRST, alone, with its transposed bulk phase (global
-    // memory in 64-byte runs through an LDS staging area that does not fit beside the sequence stage).
-    // (huf_variant 3 forces it; by default it takes tables of at most 32 cells -- the bulk phase is for MaxBits <= 5 --
-    // and enough streams to fill the chip)
-    const bool huf_first = ctx->opt.huf_variant == 3 ||
-                           (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
-                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !getenv("MZD_EXP_HUF_BESIDE"));
     auto launch_huf = [&]() {
         if (!db->n_huf_tasks) return;
         // Which Huffman kernel: a lane per stream (k_huf) needs >= 64 streams per wavefront and many wavefronts per CU

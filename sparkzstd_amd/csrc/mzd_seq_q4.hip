@@ -26,7 +26,7 @@ namespace mzd {
 constexpr int kQ4ChainsPerWave = 14;  // quads 14 and 15 of a chain wavefront are parked
 constexpr int kQ4ChainWaves = 4;
 constexpr int kQ4Threads = 64 * (kQ4ChainWaves + 5);  // + stage B (two wavefronts, alternate batches), C1, C2, P
-constexpr int kQ4Cols = 56;  // queue columns: one per chain (<= 54) + the column parked quads write to (55)
+constexpr int kQ4Cols = 57;  // queue columns: one per chain (<= 56) + the column parked quads write to (56)
 
 struct Q4Shared {
     uint32_t head1[4];                 // steps produced by each chain wavefront (0xFFFFFFFF: has no chains)
@@ -46,8 +46,10 @@ struct Q4Shared {
 };
 constexpr int kQ4FixedLds = (512 + (int)sizeof(Q4Shared) + 15) & ~15;
 constexpr int kQ4MaxChains = (160 * 1024 - kQ4FixedLds) / (kSeqCellsPerChain * 2);
-constexpr int kQ4Chains = 54;  // chains per workgroup: what LDS holds next to a k_huf workgroup, and < kQ4Cols - 1
-static_assert(kQ4MaxChains >= kQ4Chains + 1 && kQ4Chains < kQ4Cols - 1 && offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
+constexpr int kQ4Chains = 56;        // chains per workgroup: every quad of the four chain wavefronts; all of a CU's LDS with full-size tables
+constexpr int kQ4ChainsBeside = 54;  // ... when the Huffman kernel runs beside this one: ~5 KiB of LDS stay free for its workgroups
+static_assert(kQ4MaxChains >= kQ4Chains && kQ4Chains <= kQ4Cols - 1 && kQ4Chains <= kQ4ChainWaves * kQ4ChainsPerWave &&
+                  offsetof(Q4Shared, ring) % 8 == 0 && offsetof(Q4Shared, q1w) % 8 == 0, "k_seq_q4 LDS layout");
 
 #ifdef MZD_Q4_STATS
 __device__ unsigned long long g_q4_stats[8];  // chain wavefronts, steps, cycles of stage A, queue-full polls, ring polls, general steps, cycles in them, chains in general steps by reason (last sequence | escape cell << 20 | bits << 40)
