@@ -7,10 +7,12 @@ configs[3]: 65536 independent single-block 128 KiB text-like frames per GPU (SUR
 generated deterministically by tools/synth (own zstd-format encoder).  Inputs, descriptors and
 tables are resident in HBM before the timed region; outputs stay in HBM.
 
-Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
-time).  Frames are independent, so ranks simply take disjoint frame ranges: no data-path collective.
-`python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N ranks (child
-processes, before anything touches the GPU) and relays rank 0's line; under torchrun
+Multi-GPU (BASELINE configs[4]): ONE 65536-frame batch, split into contiguous frame ranges, one process per GPU
+(8192 frames per GPU at N = 8; `scaling: "strong"`; `--weak` keeps 65536 frames PER GPU instead).  Frames are
+independent, so there is no data-path collective and no RCCL anywhere: the ranks only meet at a barrier and
+exchange their times / figures, over torch.distributed's gloo backend (TCP on 127.0.0.1; `--rendezvous nccl`
+for the RCCL equivalent).  `python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N
+ranks (child processes, before anything touches the GPU) and relays rank 0's line; under torchrun
 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
@@ -51,10 +53,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, help="SURVEY 8d config: 2 raw/rle, 3 huffman only, 4 full")
-    ap.add_argument("--frames-per-gpu", type=int, default=0, help="default: 65536 (config 4) / 4096 (configs 2, 3)")
+    ap.add_argument("--frames", "--frames-per-gpu", dest="frames_per_gpu", type=int, default=0,
+                    help="frames of the batch: split over the GPUs by default (strong scaling), per GPU with --weak; "
+                         "default 65536 (config 4) / 4096 (configs 2, 3)")
     ap.add_argument("--frame-bytes", type=int, default=131072, help="regenerated size of every frame (multiple of 256); above 128 KiB a frame has several blocks with cross-block matches and repeat-offset history")
-    ap.add_argument("--strong", action="store_true",
-                    help="BASELINE configs[4] literal reading: split ONE 65536-frame batch over the ranks")
+    ap.add_argument("--strong", action="store_true", help="(default) BASELINE configs[4]: ONE batch of --frames-per-gpu x 1 frames "
+                    "(65536) split over the ranks in contiguous ranges")
+    ap.add_argument("--weak", action="store_true", help="keep the whole batch PER GPU instead (weak scaling)")
+    ap.add_argument("--rendezvous", default=os.environ.get("MZD_BENCH_BACKEND", "gloo"), choices=["gloo", "nccl"],
+                    help="how the ranks meet for the barrier and the max-over-ranks time (the data path has no collective)")
+    ap.add_argument("--exec-variant", type=int, default=0, help="0 auto, 1 k_exec (workgroup per frame), 2 k_exec_b (wavefront per frame, lane per byte)")
     ap.add_argument("--seq-variant", type=int, default=0)
     ap.add_argument("--verify-checksum", action="store_true", help="frames carry the zstd content checksum and the device verifies it after the pass (k_xxh64; an extension, off by default like in the reference)")
     ap.add_argument("--device-plan", action="store_true", help="parse the frame / block / section headers on the device too (mzd_batch_upload_frames) instead of in the host planner")
@@ -240,8 +248,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
-    # test hooks (tests of the N>1 control flow on a 1-GPU box): MZD_BENCH_BACKEND=gloo, MZD_BENCH_DEVICE=0
-    backend = os.environ.get("MZD_BENCH_BACKEND", "nccl")
+    # test hook (tests of the N>1 control flow on a 1-GPU box): MZD_BENCH_DEVICE=0 puts every rank on one GPU
+    backend = a.rendezvous
     if "MZD_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["MZD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
@@ -258,12 +266,15 @@ def main():
     frame_bytes = a.frame_bytes
     assert frame_bytes % 256 == 0 and frame_bytes > 0
     base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
-    if a.strong:
-        per = base // world
-        first, scaling = rank * per, "strong"
-    else:
+    if a.weak and not a.strong:
         per = base
         first, scaling = rank * per, "weak"
+    else:
+        # contiguous ranges of ONE batch of `base` frames (sparkzstd_amd/sharding.py: the same split the library's
+        # multi-GPU helper makes); the remainder goes to the first ranks
+        from sparkzstd_amd.sharding import frame_range
+        first, end = frame_range(base, rank, world)
+        per, scaling = end - first, "strong"
 
     # ---- synthetic batch (host), planning (host), upload: all outside the timed region
     t0 = time.perf_counter()
@@ -303,7 +314,7 @@ def main():
     d_in[pad:pad + blob.size].copy_(torch.from_numpy(blob))
     d_out = torch.zeros(batch.out_size, dtype=torch.uint8, device="cuda")
     ctx = z.Context(local_rank, seq_variant=a.seq_variant, exec_threads=a.exec_threads, exec_chunk=a.exec_chunk, huf_min_lds=a.huf_min_lds, no_split=a.no_split,
-                    verify_checksum=a.verify_checksum, huf_variant=a.huf_variant)
+                    verify_checksum=a.verify_checksum, huf_variant=a.huf_variant, exec_variant=a.exec_variant)
     rb = ctx.upload(batch, device_in_ptr=d_in.data_ptr() + pad, device_out_ptr=d_out.data_ptr())
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t0
@@ -395,7 +406,7 @@ def main():
             ceiling = {"error": str(e)}
 
     if rank == 0:
-        total_frames = per * world
+        total_frames = sum(p["frames"] for p in per_gpu)
         d_bytes = total_frames * frame_bytes
         ms_per_step = elapsed / a.steps * 1e3
         value = d_bytes / (elapsed / a.steps) / 1e6
@@ -450,10 +461,12 @@ def main():
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": names.get(a.config, str(a.config)), "frames_per_gpu": per,
+            "config": {"workload": names.get(a.config, str(a.config)), "frames": total_frames, "frames_per_gpu": per,
                        "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes, "compressed_bytes_all_gpus": c_bytes_all,
                        "sequences_per_frame": round(float(nseq.mean()), 1), "distinct_frames_per_gpu": distinct,
-                       "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "parallelism": f"one batch of {total_frames} frames in contiguous ranges over {world} GPU(s), no collective"
+                                      if scaling == "strong" else f"{per} frames on each of {world} GPU(s), no collective",
+                       "rendezvous": backend if world > 1 else None,
                        "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 128,
                        "exec_chunk": a.exec_chunk or 8192},
             "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok, "ranks_seen": len(per_gpu), "per_gpu": per_gpu,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 3
+#define MZD_ABI_VERSION 4
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -220,6 +220,9 @@ typedef struct mzd_options {
                                  streams and small tables); 1 = k_huf (one lane per stream) beside the sequence stage; 2 =
                                  k_huf_seg (one wavefront per stream, segments decoded in parallel: Huffman codes
                                  self-synchronise); 3 = k_huf first with the transposed bulk phase; see DESIGN.md */
+    uint32_t exec_variant;    /* execution kernel: 0 = by the batch; 1 = k_exec (a workgroup per frame, a lane per sequence,
+                                 dataflow on an 8 KiB LDS chunk); 2 = k_exec_b (a wavefront per frame, a lane per output
+                                 byte, strictly in order; 3 KiB of LDS per frame); see DESIGN.md */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

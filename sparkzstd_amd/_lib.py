@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 3
+MZD_ABI_VERSION = 4
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -96,7 +96,7 @@ class Options(ctypes.Structure):
     _fields_ = [("seq_variant", ctypes.c_uint32), ("exec_threads", ctypes.c_uint32),
                 ("exec_chunk", ctypes.c_uint32), ("huf_min_lds", ctypes.c_uint32), ("no_split", ctypes.c_uint32),
                 ("assume_cus", ctypes.c_uint32), ("verify_checksum", ctypes.c_uint32), ("seq_window_kib", ctypes.c_uint32),
-                ("huf_variant", ctypes.c_uint32)]
+                ("huf_variant", ctypes.c_uint32), ("exec_variant", ctypes.c_uint32)]
 
 
 class BatchStats(ctypes.Structure):

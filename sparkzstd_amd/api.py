@@ -177,7 +177,7 @@ class Context:
 
     def __init__(self, device: int = 0, seq_variant: int = 0, exec_threads: int = 0, exec_chunk: int = 0,
                  huf_min_lds: int = 0, no_split: bool = False, assume_cus: int = 0, verify_checksum: bool = False,
-                 seq_window_kib: int = 0, huf_variant: int = 0):
+                 seq_window_kib: int = 0, huf_variant: int = 0, exec_variant: int = 0):
         self._L = _lib.load()
         opt = Options()
         opt.seq_variant = seq_variant
@@ -188,6 +188,7 @@ class Context:
         opt.assume_cus = assume_cus
         opt.verify_checksum = 1 if verify_checksum else 0  # extension: the reference never checks it
         opt.huf_variant = huf_variant  # 0 auto, 1 k_huf beside the sequence stage, 2 k_huf_seg, 3 k_huf first with its transposed bulk phase
+        opt.exec_variant = exec_variant  # 0 auto, 1 k_exec (workgroup per frame, lane per sequence), 2 k_exec_b (wavefront per frame, lane per byte)
         opt.seq_window_kib = seq_window_kib  # testing: size of the blob window one k_seq_pipe launch covers
         err = ctypes.c_int()
         self._c = self._L.mzd_create(device, ctypes.byref(opt), ctypes.byref(err))

@@ -16,6 +16,7 @@
 // unity build: the kernels live in their own file but are compiled in this translation unit
 #include "mzd_kernels.hip"
 #include "mzd_seq_q4.hip"
+#include "mzd_exec_b.hip"
 #include "mzd_parse.hip"
 
 using namespace mzd;
@@ -132,6 +133,14 @@ int upload_vec(mzd_ctx *ctx, const std::vector<T> &v, T **dptr)
     if (!v.empty()) HIP_TRY(ctx, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return MZD_OK;
 }
+
+// Experiment hooks (residency caps, chains per workgroup, entropy-stages-only runs) exist only in builds made with
+// -DMZD_EXPERIMENTS (tools/experiments); the release library reads no environment variable anywhere.
+#ifdef MZD_EXPERIMENTS
+inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+constexpr const char *exp_env(const char *) { return nullptr; }
+#endif
 
 const int kMaxSym[3] = {35, 31, 52};  // LL, OF, ML (predefined.go table lengths - 1)
 const int kMaxLog[3] = {9, 8, 9};
@@ -1108,7 +1117,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
     const size_t seq_lds = (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16;
     size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
-    if (const char *e = getenv("MZD_EXEC_MIN_LDS")) exec_lds = std::max<size_t>(exec_lds, (size_t)atoi(e));  // experiment: residency cap
+    if (const char *e = exp_env("MZD_EXEC_MIN_LDS")) exec_lds = std::max<size_t>(exec_lds, (size_t)atoi(e));  // experiment: residency cap
     // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
     // overflow L2 and every refill goes to MALL/HBM; a minimum LDS request per workgroup limits the
     // number of resident wavefronts (opt.huf_min_lds bytes, default 48 KiB -> 3 wavefronts per CU)
@@ -1132,7 +1141,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
-    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 2) return MZD_ERR_INVALID_ARG;
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1146,9 +1155,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // and enough streams to fill the chip)
     const bool huf_first = ctx->opt.huf_variant == 3 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
-                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !getenv("MZD_EXP_HUF_BESIDE"));
+                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !exp_env("MZD_EXP_HUF_BESIDE"));
     uint32_t nch = q4 ? (uint32_t)(huf_first || db->n_huf_tasks == 0 ? kQ4Chains : kQ4ChainsBeside) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
-    if (const char *e = getenv("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
+    if (const char *e = exp_env("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
     // k_seq_q4 sizes a chain's LDS slot to the batch's largest tables (less to stage, more LDS left for the Huffman
     // workgroups beside it).  With small tables TWO workgroups share a CU: the kernel holds 94 VGPRs (five wavefronts per
     // SIMD, a workgroup is nine wavefronts), so LDS decides -- 54 chains of up to ~580 cells each.
@@ -1181,7 +1190,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             ctx->ev.push_back(e);
         }
         if (ctx->run_split.size() < ctx->runs + 1) ctx->run_split.resize(ctx->runs + 1);
-        ctx->run_split[ctx->runs] = split;
+        ctx->run_split[ctx->runs] = (uint8_t)((split ? 1 : 0) | (huf_first ? 2 : 0));  // bit 1: k_huf ran first, on the caller's stream
         ev = ctx->ev.data() + ctx->runs * kEvPerRun;
     }
     auto launch_seq_tasks = [&](uint32_t first, uint32_t count, bool use_pipe, uint64_t base) {
@@ -1256,9 +1265,20 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             g = e;
         }
     };
-    const bool no_exec = getenv("MZD_DEBUG_SEQ_ONLY") != nullptr;  // debugging: entropy stages only (records via mzd_batch_debug_read)
+    const bool no_exec = exp_env("MZD_DEBUG_SEQ_ONLY") != nullptr;  // debugging: entropy stages only (records via mzd_batch_debug_read)
+    // Which execution kernel: k_exec_b (a wavefront per frame, a lane per output byte) for batches with sequences to
+    // execute; k_exec (a workgroup per frame) for pure Raw / RLE / literal-only batches, whose work is wide copies, and
+    // for frames of 4 GiB and more (k_exec_b keeps frame positions in 32 bits).
+    bool exec_b = ctx->opt.exec_variant == 2;  // (0 = k_exec until k_exec_b is the faster one on the bench batch)
+    for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
+        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
     auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {
         if (!count || no_exec) return;
+        if (exec_b) {
+            k_exec_b<<<count, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames + first, db->d_blocks, db->d_sums, db->d_recs,
+                                           db->d_litbuf, db->d_status + first, db->d_out_len + first);
+            return;
+        }
         k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames + first, db->d_blocks, db->d_sums,
                                                      db->d_recs, db->d_tiles, db->d_litbuf, db->d_status + first,
                                                      db->d_out_len + first, exec_cap);
@@ -1307,7 +1327,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                      db->huf_out_bytes / streams >= 2048);
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
-        if (const char *e = getenv("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
+        if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
         if (seg)
             k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                db->d_litbuf, db->d_sums, seg_tbl);
@@ -1386,6 +1406,14 @@ extern "C" int mzd_debug_huf_seg_stats(unsigned long long *out, int reset)
 {
     if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_huf_seg_stats), sizeof(unsigned long long) * 8);
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_huf_seg_stats), z, sizeof z); }
+    return 0;
+}
+#endif
+#ifdef MZD_XB_STATS
+extern "C" int mzd_debug_xb_stats(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_xb_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_xb_stats), z, sizeof z); }
     return 0;
 }
 #endif
@@ -1488,10 +1516,11 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
     };
     for (size_t r = 0; r < ctx->runs; r++) {
         hipEvent_t *e = ctx->ev.data() + r * kEvPerRun;
-        const bool split = ctx->run_split[r];
+        const bool split = ctx->run_split[r] & 1, huf_first = ctx->run_split[r] & 2;
         acc[0] += el(e[0], e[1]);
-        acc[1] += el(e[9], e[2]);                                           // k_huf on the second stream
-        acc[2] += el(e[1], e[3]) + (split ? el(e[3], e[4]) : 0.0);          // k_seq head (+ tail, incl. its wait for k_huf)
+        acc[1] += el(e[9], e[2]);                                           // k_huf (second stream, or first on the caller's)
+        // k_seq head (+ tail, incl. its wait for k_huf); with k_huf first on the same stream the head starts at ITS end
+        acc[2] += el(huf_first ? e[2] : e[1], e[3]) + (split ? el(e[3], e[4]) : 0.0);
         acc[3] += el(e[4], e[5]) + (split ? el(e[6], e[7]) : 0.0);
         acc[4] += el(e[0], e[8]);
         if (ctx->opt.verify_checksum) acc[5] += el(e[5], e[11]) + (split ? el(e[7], e[10]) : 0.0);

@@ -12,9 +12,10 @@ from tests.conftest import check_expected
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    return z.Context(0)
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["exec_auto", "k_exec", "k_exec_b"])
+def ctx(request):
+    """every test that takes `ctx` runs with both execution kernels (and the default choice between them)"""
+    return z.Context(0, exec_variant=request.param)
 
 
 def _decode(frames, ctx):
@@ -22,11 +23,13 @@ def _decode(frames, ctx):
     return outs, sts
 
 
-@pytest.mark.parametrize("seq_variant,exec_threads", [(0, 256), (1, 256), (3, 256), (0, 128), (1, 128), (3, 128), (0, 64), (1, 64), (3, 64)])
-def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads):
+@pytest.mark.parametrize("seq_variant,exec_threads,exec_variant",
+                         [(0, 256, 1), (1, 256, 1), (3, 256, 1), (0, 128, 1), (1, 128, 1), (3, 128, 1), (0, 64, 1), (1, 64, 1), (3, 64, 1),
+                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0)])
+def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads, exec_variant):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
-    c = z.Context(0, seq_variant=seq_variant, exec_threads=exec_threads)
+    c = z.Context(0, seq_variant=seq_variant, exec_threads=exec_threads, exec_variant=exec_variant)
     outs, sts = _decode([comp for _, comp, *_ in corpus], c)
     bad = [(corpus[i][0], sts[i]) for i in range(len(corpus)) if sts[i] != 0]
     assert not bad, bad
@@ -205,8 +208,8 @@ def test_corrupt_input_reports_status_not_fault(corpus, ctx):
     check_expected(name, outs2[0], length, sha, exp)
 
 
-@pytest.mark.parametrize("seq_variant", [0, 1, 3])
-def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant):
+@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2)])
+def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant, exec_variant):
     """Every corpus frame, mutated 6 times (random byte flips past the frame header, seeded), all
     in ONE device batch.  The device must not fault; a frame it reports as decoded must be one
     the oracle decodes to the same bytes, and a frame the oracle rejects must carry a status."""
@@ -221,7 +224,7 @@ def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_var
             for pos in rng.integers(8, len(b), size=nflip):
                 b[int(pos)] ^= int(rng.integers(1, 256))
             frames.append(bytes(b))
-    c = z.Context(0, seq_variant=seq_variant)
+    c = z.Context(0, seq_variant=seq_variant, exec_variant=exec_variant)
     outs, sts = _decode(frames, c)
     n_ok = 0
     for f, o, s in zip(frames, outs, sts):

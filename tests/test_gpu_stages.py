@@ -329,15 +329,16 @@ def test_small_frames_small_sequence_tables_two_workgroups_per_cu(ctx):
 
 # ---- BASELINE configs[4]: the sharded bench, launched by bench.py itself
 
-@pytest.mark.parametrize("extra", [[], ["--strong"]])
+@pytest.mark.parametrize("extra", [[], ["--weak"]])
 def test_bench_launches_its_own_ranks(extra):
     """`python bench.py --gpus 2` with no launcher around it: the parent spawns two ranks before touching the GPU;
     each decodes its own contiguous frame range (framedecompressor.go:42-52: frames share nothing), rank 0 prints
-    one line that names both ranks.  On a one-GPU box both ranks share device 0 and rendezvous over gloo."""
+    one line that names both ranks.  Default = BASELINE configs[4]: ONE batch split over the ranks ("strong");
+    --weak keeps the batch per GPU.  The ranks meet over gloo (no RCCL anywhere); on a one-GPU box both share device 0."""
     import torch
     env = dict(os.environ)
     if torch.cuda.device_count() < 2:
-        env.update(MZD_BENCH_BACKEND="gloo", MZD_BENCH_DEVICE="0")
+        env.update(MZD_BENCH_DEVICE="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
@@ -347,6 +348,7 @@ def test_bench_launches_its_own_ranks(extra):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["bit_exact"] is True
     assert sorted(p["rank"] for p in line["per_gpu"]) == [0, 1]
-    per = 1024 if extra else 2048
-    assert all(p["frames"] == per for p in line["per_gpu"]) and line["scaling"] == ("strong" if extra else "weak")
+    per = 2048 if extra else 1024
+    assert all(p["frames"] == per for p in line["per_gpu"]) and line["scaling"] == ("weak" if extra else "strong")
+    assert line["config"]["rendezvous"] == "gloo" and line["config"]["frames"] == 2 * per
     assert line["value"] > 0 and all(p["algorithmic_GBs"] > 0 for p in line["per_gpu"])
