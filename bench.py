@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, help="SURVEY 8d config: 2 raw/rle, 3 huffman only, 4 full")
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "corpus"],
+                    help="corpus: the reference's own 100 decodecorpus frames (tests/golden/decodecorpus: real zstd output, mixed block "
+                         "types / table modes / window sizes, multi-block), replicated to --corpus-gib of output at distinct HBM addresses")
+    ap.add_argument("--corpus-gib", type=float, default=4.0)
     ap.add_argument("--frames", "--frames-per-gpu", dest="frames_per_gpu", type=int, default=0,
                     help="frames of the batch: split over the GPUs by default (strong scaling), per GPU with --weak; "
                          "default 65536 (config 4) / 4096 (configs 2, 3)")
@@ -79,8 +83,10 @@ def parse():
                          "take longer, fewer distinct frames are generated and physically replicated")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--traffic-from", default="", help="JSON written by tools/profile_round.sh in the same gpurun "
-                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r2_traffic_cfg<N>.json. "
+                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r3_traffic_<workload>.json. "
                     "Quoted only if its kernel_src_sha16 and workload match this run")
+    ap.add_argument("--issue-from", default="", help="JSON written by tools/profile_counters.sh (SQ counters per kernel); default: "
+                    "profiles/r3_issue_<workload>.json; quoted under the same condition")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured copy ceiling (mzd_measure_copy)")
     return ap.parse_args()
 
@@ -131,13 +137,15 @@ def usable_cores():
     return n, quota
 
 
-def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
+def cpu_baseline(blob, off, ln, exp_len, budget_s):
     """Oracle ("port" of the reference algorithm, plain C) on the host cores, bounded sample of the
     SAME frames.  Reported next to the GPU number; never the thing measured as `value`."""
     from tests.oracle_binding import load_oracle
     orc = load_oracle()
     cores, quota = usable_cores()
     n_total = len(off)
+    cap = int(exp_len.max()) if n_total else 0
+    csum = np.concatenate([[0], np.cumsum(exp_len.astype(np.float64))])  # output bytes of the first k frames
 
     def run(first, count, nthreads):
         per = (count + nthreads - 1) // nthreads
@@ -150,16 +158,16 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
             n = b - a
             # every frame of a thread regenerates into the same pre-faulted buffer: the baseline is
             # not charged for page faults or for writing 8 GB to DRAM (optimistic for the CPU)
-            dst = np.zeros(frame_bytes + 64, dtype=np.uint8)
+            dst = np.zeros(cap + 64, dtype=np.uint8)
             doff = np.zeros(n, dtype=np.uint64)
-            dcap = np.full(n, frame_bytes, dtype=np.uint64)
+            dcap = np.full(n, cap, dtype=np.uint64)
             olen = np.empty(n, dtype=np.uint64)
             st = np.empty(n, dtype=np.int32)
             o = np.ascontiguousarray(off[a:b])
             l = np.ascontiguousarray(ln[a:b])
-            outs.append((dst, olen, st, o, l, doff, dcap, n))
+            outs.append((dst, olen, st, o, l, doff, dcap, n, np.ascontiguousarray(exp_len[a:b])))
         t0 = time.perf_counter()
-        for (dst, olen, st, o, l, doff, dcap, n) in outs:
+        for (dst, olen, st, o, l, doff, dcap, n, _) in outs:
             th = threading.Thread(target=orc.lib.orc_decode_frames,
                                   args=(blob.ctypes.data, o.ctypes.data, l.ctypes.data, n, dst.ctypes.data,
                                         doff.ctypes.data, dcap.ctypes.data, olen.ctypes.data, st.ctypes.data))
@@ -168,7 +176,7 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
         for th in ths:
             th.join()
         dt = time.perf_counter() - t0
-        ok = all(int(x[2].max()) == 0 and int(x[1].min()) == frame_bytes for x in outs)
+        ok = all(int(x[2].max()) == 0 and bool((x[1] == x[8]).all()) for x in outs)
         return dt, ok
 
     calib = min(n_total, 8 * cores)
@@ -186,17 +194,17 @@ def cpu_baseline(blob, off, ln, frame_bytes, budget_s):
     # the same port on ONE thread ("(i) 1 thread, (ii) all host cores")
     n1 = int(max(8, min(n_total, rate / max(cores, 1) * min(3.0, budget_s / 3))))
     dt1, ok1 = run(0, n1, 1)
-    res = {"value": round(sample * frame_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+    res = {"value": round(csum[sample] / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
            "sample": f"first {sample} frames of the same batch, oracle (C restatement of the reference "
                      f"algorithm) on {cores} host threads ({os.cpu_count()} hardware threads, cgroup quota "
                      f"{quota}), {dt:.2f}s per pass", "ok": bool(ok and ok2 and ok1),
-           "one_thread": {"value": round(n1 * frame_bytes / dt1 / 1e6, 1), "unit": "MB/s", "cores": 1,
+           "one_thread": {"value": round(csum[n1] / dt1 / 1e6, 1), "unit": "MB/s", "cores": 1,
                           "sample": f"first {n1} frames, {dt1:.2f}s"}}
-    res["libzstd"] = libzstd_line(blob, off, ln, frame_bytes, n1, cores)
+    res["libzstd"] = libzstd_line(blob, off, ln, exp_len, n1, cores)
     return res
 
 
-def libzstd_line(blob, off, ln, frame_bytes, n1, cores):
+def libzstd_line(blob, off, ln, exp_len, n1, cores):
     """Context only: libzstd through dlopen if the box has one -- third-party, NOT the
     reference and not a port of it; null when absent."""
     import ctypes
@@ -209,16 +217,19 @@ def libzstd_line(blob, off, ln, frame_bytes, n1, cores):
     except (OSError, AttributeError):
         return None
 
+    cap = int(exp_len.max())
+    csum = np.concatenate([[0], np.cumsum(exp_len.astype(np.float64))])
+
     def run(first, count, nthreads):
         per = (count + nthreads - 1) // nthreads
         oks = []
 
         def work(a, b):
-            dst = np.zeros(frame_bytes + 64, dtype=np.uint8)
+            dst = np.zeros(cap + 64, dtype=np.uint8)
             good = True
             for i in range(a, b):
                 r = Z.ZSTD_decompress(dst.ctypes.data, dst.size, blob.ctypes.data + int(off[i]), int(ln[i]))
-                good = good and r == frame_bytes
+                good = good and r == int(exp_len[i])
             oks.append(good)
         ths = [threading.Thread(target=work, args=(first + t * per, min(first + count, first + (t + 1) * per))) for t in range(nthreads)]
         t0 = time.perf_counter()
@@ -231,8 +242,8 @@ def libzstd_line(blob, off, ln, frame_bytes, n1, cores):
     dt1, ok1 = run(0, n, 1)
     nall = min(len(off), n * cores)
     dta, oka = run(0, nall, cores)
-    return {"version": int(Z.ZSTD_versionNumber()), "one_thread_MBs": round(n * frame_bytes / dt1 / 1e6, 1),
-            "all_threads_MBs": round(nall * frame_bytes / dta / 1e6, 1), "cores": cores, "ok": bool(ok1 and oka),
+    return {"version": int(Z.ZSTD_versionNumber()), "one_thread_MBs": round(csum[n] / dt1 / 1e6, 1),
+            "all_threads_MBs": round(csum[nall] / dta / 1e6, 1), "cores": cores, "ok": bool(ok1 and oka),
             "note": "context only: third-party libzstd via dlopen, not the reference"}
 
 
@@ -265,7 +276,21 @@ def main():
 
     frame_bytes = a.frame_bytes
     assert frame_bytes % 256 == 0 and frame_bytes > 0
+    corpus = None
+    if a.workload == "corpus":
+        # the reference's own golden frames (tests/golden/decodecorpus, committed with their sha256 / length manifest):
+        # one REPLICA = the 100 frames in order; the batch is as many replicas as give --corpus-gib of output
+        gdir = os.path.join(ROOT, "tests", "golden", "decodecorpus")
+        manifest = json.load(open(os.path.join(gdir, "manifest.json")))
+        names = sorted(manifest)
+        cframes = [np.frombuffer(open(os.path.join(gdir, n + ".zst"), "rb").read(), dtype=np.uint8) for n in names]
+        clens = np.array([manifest[n]["length"] for n in names], dtype=np.uint64)
+        reps_total = max(world, int(a.corpus_gib * 2**30 / float(clens.sum()) + 0.5))
+        corpus = {"names": names, "sha": [manifest[n]["sha256"] for n in names], "lens": clens, "frames": cframes, "reps": reps_total}
+        assert not a.frames_per_gpu, "--workload corpus sizes the batch with --corpus-gib"
     base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
+    if corpus:
+        base = corpus["reps"]  # the unit that is split over the ranks is the replica
     if a.weak and not a.strong:
         per = base
         first, scaling = rank * per, "weak"
@@ -279,17 +304,30 @@ def main():
     # ---- synthetic batch (host), planning (host), upload: all outside the timed region
     t0 = time.perf_counter()
     gen_threads = a.gen_threads or max(1, usable_cores()[0] // max(1, world))
+    if corpus:
+        one = np.concatenate(corpus["frames"])
+        o1 = np.concatenate([[0], np.cumsum([f.size for f in corpus["frames"]])[:-1]]).astype(np.uint64)
+        l1 = np.array([f.size for f in corpus["frames"]], dtype=np.uint64)
+        reps = per
+        blob = np.tile(one, reps)
+        off = np.concatenate([o1 + np.uint64(r * one.size) for r in range(reps)])
+        ln = np.tile(l1, reps)
+        exp_len = np.tile(corpus["lens"], reps)
+        cks, nseq, distinct = None, np.zeros(1), len(corpus["names"])
+        per = reps * len(corpus["names"])  # frames of this rank from here on
     # calibrate, then generate as many DISTINCT frames as the time budget allows (normally all of them)
     sb.set_content_checksum(a.verify_checksum)
-    calib = min(per, 8 * gen_threads)
-    tc = time.perf_counter()
-    sb.make_batch(a.config, first, calib, frame_bytes, threads=gen_threads)
-    rate = calib / max(time.perf_counter() - tc, 1e-3)  # frames per second on this rank's threads
-    distinct = per
-    while distinct > 1024 and distinct / rate > a.gen_seconds:
-        distinct //= 2
-    blob, off, ln, cks, nseq = sb.make_batch(a.config, first, distinct, frame_bytes, threads=gen_threads)
-    if distinct < per:
+    calib = 0 if corpus else min(per, 8 * gen_threads)
+    if not corpus:
+        tc = time.perf_counter()
+        sb.make_batch(a.config, first, calib, frame_bytes, threads=gen_threads)
+        rate = calib / max(time.perf_counter() - tc, 1e-3)  # frames per second on this rank's threads
+        distinct = per
+        while distinct > 1024 and distinct / rate > a.gen_seconds:
+            distinct //= 2
+        blob, off, ln, cks, nseq = sb.make_batch(a.config, first, distinct, frame_bytes, threads=gen_threads)
+        exp_len = np.full(per, frame_bytes, dtype=np.uint64)
+    if not corpus and distinct < per:
         # physical replication: content repeats, HBM addresses do not (SURVEY 8d option iii)
         reps = (per + distinct - 1) // distinct
         blob = np.ascontiguousarray(blob)
@@ -306,7 +344,8 @@ def main():
     assert rc == 0, f"planner failed: {rc}"
     batch = plan.finalize()
     t_plan = time.perf_counter() - t0
-    assert batch.n_frames == per and batch.out_size == per * frame_bytes + 256
+    assert batch.n_frames == per and (corpus or batch.out_size == per * frame_bytes + 256)
+    my_d_bytes = int(exp_len.sum())  # regenerated bytes of this rank's frames
 
     t0 = time.perf_counter()
     pad = 64
@@ -363,7 +402,19 @@ def main():
     ok = True
     if not a.no_verify:
         _, status, out_len = rb.download(want_out=False)
-        ok = bool((status == 0).all() and (out_len == frame_bytes).all())
+        ok = bool((status == 0).all() and (out_len == exp_len).all())
+    if not a.no_verify and corpus:
+        # every frame by status and length (above); by sha256 against the manifest: the whole first replica and one frame
+        # of every other replica (a different one each time), read back from their slabs in HBM
+        lay = rb.frame_layout()[0]
+        nf = len(corpus["names"])
+        sample = list(range(nf)) + [r * nf + (r * 37) % nf for r in range(1, per // nf)]
+        for i in sample:
+            o, n = int(lay[i]), int(exp_len[i])
+            got = d_out[o:o + n].cpu().numpy().tobytes()
+            ok = ok and hashlib.sha256(got).hexdigest() == corpus["sha"][i % nf]
+        corpus["sha_checked"] = len(sample)
+    if not a.no_verify and not corpus:
         exp = torch.from_numpy(cks.view(np.int64)).cuda()
         words = frame_bytes // 8
         wts = (2 * torch.arange(words, dtype=torch.int64, device="cuda") + 1)
@@ -380,9 +431,9 @@ def main():
     # every rank's own figures (frames, own wall time per step, own path time from its HIP events, algorithmic GB/s)
     kms_all = dict(kms)
     my_path_ms = kms_all.get("path") or sum(v for k, v in kms_all.items() if v > 0)
-    my_alg = int(stats.compressed_bytes) + per * frame_bytes
+    my_alg = int(stats.compressed_bytes) + my_d_bytes
     mine = torch.tensor([float(rank), float(torch.cuda.current_device()), float(per), my_elapsed / a.steps * 1e3, my_path_ms,
-                         my_alg / (my_path_ms * 1e-3) / 1e9 if my_path_ms > 0 else 0.0, float(int(stats.compressed_bytes))],
+                         my_alg / (my_path_ms * 1e-3) / 1e9 if my_path_ms > 0 else 0.0, float(int(stats.compressed_bytes)), float(my_d_bytes)],
                         dtype=torch.float64, device=red_dev)
     if world > 1:
         gathered = [torch.zeros_like(mine) for _ in range(world)]
@@ -393,11 +444,12 @@ def main():
                 "ms_per_step": round(g[3].item(), 4), "path_ms": round(g[4].item(), 4),
                 "algorithmic_GBs": round(g[5].item(), 1), "hbm_frac": round(g[5].item() / HBM_PEAK_GBS, 4)} for g in gathered]
     c_bytes_all = sum(int(g[6].item()) for g in gathered)
+    d_bytes_all = sum(int(g[7].item()) for g in gathered)
 
     # measured copy ceiling: a plain 16 B/lane streaming kernel that reads C and writes D bytes (this rank's)
     ceiling = None
     if rank == 0 and not a.no_ceiling:
-        rb_bytes, wb_bytes = int(stats.compressed_bytes), per * frame_bytes
+        rb_bytes, wb_bytes = int(stats.compressed_bytes), my_d_bytes
         try:
             cms = ctx.measure_copy(rb_bytes, wb_bytes, 10)
             ceiling = {"GBs": round((rb_bytes + wb_bytes) / (cms * 1e-3) / 1e9, 1), "ms": round(cms, 4),
@@ -407,38 +459,56 @@ def main():
 
     if rank == 0:
         total_frames = sum(p["frames"] for p in per_gpu)
-        d_bytes = total_frames * frame_bytes
+        d_bytes = d_bytes_all
         ms_per_step = elapsed / a.steps * 1e3
         value = d_bytes / (elapsed / a.steps) / 1e6
         # roofline of the dominant kernel set: algorithmic bytes = compressed bytes read once +
         # decompressed bytes written once, per launch (= one pass over this rank's batch)
         c_bytes = int(stats.compressed_bytes)
-        alg = c_bytes + per * frame_bytes
+        alg = c_bytes + my_d_bytes
         path_ms = kms.pop("path", None) or sum(v for k, v in kms.items() if v > 0)
         xxh_ms = kms.pop("k_xxh64", None)  # optional extension, reported on its own below
         dom = max(kms, key=lambda k: kms[k]) if kms else None
         achieved = alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else None
         # HBM traffic per launch from PMC passes (FETCH_SIZE + WRITE_SIZE, separate --pmc runs, tools/profile_round.sh):
         # quoted only when the file was measured on THIS device code and THIS workload
-        traffic, traffic_note = None, None
-        tpath = a.traffic_from or os.path.join(ROOT, "profiles", f"r2_traffic_cfg{a.config}.json")
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("kernel_src_sha16") != kernel_src_sha16():
-                traffic_note = f"{os.path.basename(tpath)} was measured on other device code ({tj.get('kernel_src_sha16')}): not quoted"
-            elif tj.get("config") != a.config or tj.get("frames_per_gpu") != per or tj.get("frame_bytes") != frame_bytes:
-                traffic_note = f"{os.path.basename(tpath)} is for another workload: not quoted"
-            else:
-                traffic = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in tj["kernels"].items() if k != "k_init")
-                traffic_note = (f"{os.path.basename(tpath)}: FETCH_SIZE (raw; gfx950 under-counts wide streaming reads up to 2x) + "
-                                f"WRITE_SIZE summed over the pass's kernels")
-        except FileNotFoundError:
-            traffic_note = "no counter file for this workload"
-        except Exception as e:  # noqa: BLE001
-            traffic_note = f"unreadable counter file: {e}"
+        wl_tag = "corpus" if corpus else f"cfg{a.config}"
+
+        def stamped(path, what):
+            """a counter file of the builder's (tools/profile_round.sh / profile_counters.sh), quoted only when it was measured on
+            THIS device code and THIS workload; -> (json or None, note that says whose number it is and from when)"""
+            try:
+                j = json.load(open(path))
+            except FileNotFoundError:
+                return None, f"no {what} file for this workload ({os.path.basename(path)})"
+            except Exception as e:  # noqa: BLE001
+                return None, f"unreadable {what} file: {e}"
+            if j.get("kernel_src_sha16") != kernel_src_sha16():
+                return None, f"{os.path.basename(path)} was measured on other device code ({j.get('kernel_src_sha16')}): not quoted"
+            same = j.get("workload", "synthetic") == a.workload and (
+                (corpus and j.get("corpus_gib", 4.0) == a.corpus_gib) or
+                (not corpus and j.get("frames_per_gpu") == per and j.get("config") == a.config and j.get("frame_bytes") == frame_bytes))
+            if not same:
+                return None, f"{os.path.basename(path)} is for another workload: not quoted"
+            m = j.get("measured", {})
+            return j, (f"{os.path.basename(path)}: measured by {m.get('by', 'the builder')} on {m.get('date', 'an earlier day')}, NOT in this run; "
+                       f"same device sources ({j.get('kernel_src_sha16')}) and workload")
+
+        traffic = None
+        tj, traffic_note = stamped(a.traffic_from or os.path.join(ROOT, "profiles", f"r3_traffic_{wl_tag}.json"), "traffic")
+        if tj:
+            traffic = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in tj["kernels"].items() if k != "k_init")
+            traffic_note += "; FETCH_SIZE (raw; gfx950 under-counts wide streaming reads up to 2x) + WRITE_SIZE summed over the pass's kernels"
+        # what each kernel keeps busy inside the CU: the path is latency- and issue-bound, an HBM fraction alone does not show progress
+        ij, issue_note = stamped(a.issue_from or os.path.join(ROOT, "profiles", f"r3_issue_{wl_tag}.json"), "issue")
+        issue = {"source": issue_note}
+        if ij:
+            issue["kernels"] = {k: {f: v[f] for f in ("valu_wave_insts", "valu_frac", "lds_pipe_frac", "ta_busy_frac", "kernel_cycles") if f in v}
+                                for k, v in ij["kernels"].items()}
+            issue["note"] = ij.get("note")
         roof = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": traffic, "traffic_source": traffic_note,
+                "traffic": traffic, "traffic_source": traffic_note, "issue": issue,
                 "copy_ceiling": ceiling,
                 "frac_of_copy_ceiling": round(achieved / ceiling["GBs"], 4) if achieved and ceiling and ceiling.get("GBs") else None,
                 "kernel": f"hot path = k_huf -> k_seq -> k_exec (k_seq tail round overlaps k_exec of the head frames); "
@@ -449,21 +519,25 @@ def main():
                 "dominant_kernel_alone_GBs": round(alg / (kms[dom] * 1e-3) / 1e9, 1) if dom else None}
         if xxh_ms:
             # k_xxh64 streams the regenerated bytes once: its own HBM roofline (D bytes / its time)
-            roof["k_xxh64"] = {"ms": round(xxh_ms, 4), "achieved_GBs": round(per * frame_bytes / (xxh_ms * 1e-3) / 1e9, 1),
-                               "frac": round(per * frame_bytes / (xxh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            roof["k_xxh64"] = {"ms": round(xxh_ms, 4), "achieved_GBs": round(my_d_bytes / (xxh_ms * 1e-3) / 1e9, 1),
+                               "frac": round(my_d_bytes / (xxh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         cpu = None
         if a.cpu_seconds > 0:
-            cpu = cpu_baseline(blob, off, ln, frame_bytes, a.cpu_seconds)
+            cpu = cpu_baseline(blob, off, ln, exp_len, a.cpu_seconds)
         names = {2: "config2 raw/rle single-block 128KiB frames", 3: "config3 4-stream huffman literals, 0 sequences",
                  4: "config4 text-like 128KiB frames: huffman literals + FSE sequences + match copy"}
         line = {
             "metric": "decompressed MB/s + %HBM-peak, 64k-frame batch, 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": names.get(a.config, str(a.config)), "frames": total_frames, "frames_per_gpu": per,
-                       "frame_bytes": frame_bytes, "compressed_bytes_per_gpu": c_bytes, "compressed_bytes_all_gpus": c_bytes_all,
-                       "sequences_per_frame": round(float(nseq.mean()), 1), "distinct_frames_per_gpu": distinct,
+            "vs_baseline": None, "dtype": "u8",
+            "data": "real: the reference's decodecorpus frames (tests/golden/decodecorpus), replicated" if corpus else "synthetic",
+            "config": {"workload": (f"decodecorpus: the reference's {len(corpus['names'])} golden frames x {base} replicas at distinct HBM addresses "
+                                    f"(content repeats, addresses do not); {corpus.get('sha_checked', 0)} frames checked by sha256, all by status and length")
+                       if corpus else names.get(a.config, str(a.config)), "frames": total_frames, "frames_per_gpu": per,
+                       "frame_bytes": None if corpus else frame_bytes, "decompressed_bytes_all_gpus": d_bytes_all,
+                       "compressed_bytes_per_gpu": c_bytes, "compressed_bytes_all_gpus": c_bytes_all,
+                       "sequences_per_frame": round(float(stats.n_sequences) / max(per, 1), 1), "distinct_frames_per_gpu": distinct,
                        "parallelism": f"one batch of {total_frames} frames in contiguous ranges over {world} GPU(s), no collective"
                                       if scaling == "strong" else f"{per} frames on each of {world} GPU(s), no collective",
                        "rendezvous": backend if world > 1 else None,
@@ -472,6 +546,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok, "ranks_seen": len(per_gpu), "per_gpu": per_gpu,
             "kernel_src_sha16": kernel_src_sha16(),
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
+            "exec_variant": a.exec_variant,
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 3), "upload": round(t_upload, 3),
                         "tables": "host" if a.host_tables else "device",
                         "headers": "device" if a.device_plan else "host",

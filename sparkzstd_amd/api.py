@@ -127,10 +127,10 @@ class ResidentBatch:
             raise MzdError(-n, "mzd_batch_read_huf_table: " + self.ctx.last_error())
         return out[:n].copy()
 
-    def debug_read(self, what: int, dtype, offset_bytes: int = 0, count: int = None) -> np.ndarray:
+    def debug_read(self, what: int, dtype, offset_bytes: int, count: int) -> np.ndarray:
         """Scratch of the batch after run() (mzd_batch_debug_read): what = _lib.MZD_DEBUG_*; `count` items of
-        `dtype` from byte offset `offset_bytes`."""
-        out = np.empty(count, dtype=dtype)
+        `dtype` from byte offset `offset_bytes` (the library checks the range against the array's extent)."""
+        out = np.empty(int(count), dtype=dtype)
         rc = self.ctx._L.mzd_batch_debug_read(self.ctx._c, self._h, what, offset_bytes,
                                               out.ctypes.data if out.size else None, out.nbytes)
         if rc:

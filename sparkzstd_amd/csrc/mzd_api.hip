@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -102,6 +103,12 @@ struct mzd_dbatch {
     std::vector<uint64_t> frame_out_off, frame_out_cap;  // host: output slab of every frame
     std::vector<uint64_t> frame_in_lo, frame_in_hi;      // host: extent of the frame's sequence bitstreams in the blob (lo > hi: none)
     float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
+    // heterogeneous batches (real data: blocks of 10 and of 40 000 sequences side by side): work lists ordered by size, so
+    // that the units a workgroup / wavefront holds at a time are of similar length and the long ones start first
+    bool seq_sorted = false;           // d_seq_tasks is in descending n_seq order (not in frame order: no head / tail split)
+    bool huf_sorted = false;           // d_huf_tasks' quads are grouped by table size class, longest streams first
+    uint32_t huf_class_end[3] = {0, 0, 0};  // quads of class 0 (tables <= 32 cells), 1 (<= 256), 2 end here
+    uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
     uint64_t out_size = 0;
     uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
     uint64_t huf_out_bytes = 0;                        // literals the Huffman stage regenerates (scratch or in place)
@@ -251,6 +258,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_litbuf);
     (void)hipFree(db->d_status);
     (void)hipFree(db->d_out_len);
+    (void)hipFree(db->d_frame_order);
     free_parse_temps(db->tmp);
     delete db;
 }
@@ -522,6 +530,56 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         frame_in_hi[f] = in_hi;
     }
     frame_seq_task[b->n_frames] = (uint32_t)seq_tasks.size();
+    // ---- heterogeneous work lists are ordered by size (see mzd_dbatch)
+    bool seq_sorted = false, huf_sorted = false;
+    uint32_t huf_class_end[3] = {0, 0, 0};
+    std::vector<uint32_t> frame_order;
+    {
+        uint64_t sum = 0;
+        uint32_t mx = 0;
+        for (const SeqTask &t : seq_tasks) { sum += t.n_seq; mx = std::max(mx, t.n_seq); }
+        // (the sorted list is decoded in ONE launch that addresses the bitstreams with 32-bit offsets from the blob's start)
+        if (seq_tasks.size() > 64 && (uint64_t)mx * seq_tasks.size() >= 2 * sum && b->in_size < (1ull << 32) - 2 * MZD_IN_PAD - 4096) {
+            std::stable_sort(seq_tasks.begin(), seq_tasks.end(), [](const SeqTask &x, const SeqTask &y) { return x.n_seq > y.n_seq; });
+            seq_sorted = true;
+        }
+        const size_t nq = huf_tasks.size() / 4;
+        uint64_t hsum = 0;
+        uint32_t hmx = 0, bits_lo = 99, bits_hi = 0;
+        std::vector<uint64_t> key(nq);  // class << 40 | (0xFFFFFFFF - longest stream of the quad) << 8 ... ascending sort
+        for (size_t q = 0; q < nq; q++) {
+            uint32_t longest = 0, mb = 1;
+            for (int k = 0; k < 4; k++) { longest = std::max(longest, huf_tasks[4 * q + k].out_size); mb = std::max(mb, huf_tasks[4 * q + k].max_bits); }
+            hsum += longest;
+            hmx = std::max(hmx, longest);
+            bits_lo = std::min(bits_lo, mb);
+            bits_hi = std::max(bits_hi, mb);
+            const uint64_t cls = mb <= 5 ? 0 : (mb <= 8 ? 1 : 2);
+            key[q] = (cls << 40) | ((uint64_t)(0xFFFFFFFFu - longest) << 8);
+        }
+        if (nq > 64 && ((uint64_t)hmx * nq >= 2 * hsum || (bits_lo <= 8 && bits_hi > 8) || (bits_lo <= 5 && bits_hi > 5))) {
+            std::vector<uint32_t> idx(nq);
+            for (size_t q = 0; q < nq; q++) idx[q] = (uint32_t)q;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+            std::vector<HufTask> sorted(huf_tasks.size());
+            for (size_t q = 0; q < nq; q++) {
+                for (int k = 0; k < 4; k++) sorted[4 * q + k] = huf_tasks[4 * (size_t)idx[q] + k];
+                huf_class_end[key[idx[q]] >> 40] = (uint32_t)q + 1;
+            }
+            for (int c = 1; c < 3; c++) huf_class_end[c] = std::max(huf_class_end[c], huf_class_end[c - 1]);
+            huf_tasks.swap(sorted);
+            huf_sorted = true;
+        }
+        // frames: the largest first (a frame is one workgroup / wavefront of the execution stage from start to end)
+        uint64_t csum = 0, cmx = 0;
+        for (uint32_t f = 0; f < b->n_frames; f++) { csum += b->frames[f].out_capacity; cmx = std::max<uint64_t>(cmx, b->frames[f].out_capacity); }
+        if (b->n_frames > 64 && cmx * b->n_frames >= 2 * csum) {
+            frame_order.resize(b->n_frames);
+            for (uint32_t f = 0; f < b->n_frames; f++) frame_order[f] = f;
+            std::stable_sort(frame_order.begin(), frame_order.end(),
+                             [&](uint32_t x, uint32_t y) { return b->frames[x].out_capacity > b->frames[y].out_capacity; });
+        }
+    }
     st.table_bytes = (uint64_t)b->n_fse_entries * 4 + (uint64_t)b->n_huf_entries * 2;
     st.scratch_bytes = rec_total * 8 + tile_total * 8 + lit_total;
 
@@ -533,6 +591,9 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->n_seq_tasks = (uint32_t)seq_tasks.size();
     for (int k = 0; k < 3; k++) db->seq_cells[k] = 1u << std::min<uint32_t>(seq_logs[k], k == 2 ? 8u : 9u);
     db->huf_slot_cells = 1u << max_huf_bits;
+    db->seq_sorted = seq_sorted;
+    db->huf_sorted = huf_sorted;
+    for (int c = 0; c < 3; c++) db->huf_class_end[c] = huf_class_end[c];
     db->frame_seq_task = std::move(frame_seq_task);
     db->frame_in_lo = std::move(frame_in_lo);
     db->frame_in_hi = std::move(frame_in_hi);
@@ -588,6 +649,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     TRY_OR_FAIL(upload_vec(ctx, blocks, &db->d_blocks));
     TRY_OR_FAIL(upload_vec(ctx, huf_tasks, &db->d_huf_tasks));
     TRY_OR_FAIL(upload_vec(ctx, seq_tasks, &db->d_seq_tasks));
+    if (!frame_order.empty()) TRY_OR_FAIL(upload_vec(ctx, frame_order, &db->d_frame_order));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_sums, std::max<size_t>(b->n_blocks, 1) * sizeof(BlockSum)));
     // ---- FSE tables: the host array (cells or packed counts) goes up as it is; k_fse_build lays the
     // decoding tables out on the device, copying the ones that came built and building the others
@@ -1153,7 +1215,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // memory in 64-byte runs through an LDS staging area that does not fit beside the sequence stage).
     // (huf_variant 3 forces it; by default it takes tables of at most 32 cells -- the bulk phase is for MaxBits <= 5 --
     // and enough streams to fill the chip)
-    const bool huf_first = ctx->opt.huf_variant == 3 ||
+    // Heterogeneous batches (work lists ordered by size at upload, frames executed largest first) run their stages one after
+    // the other on the caller's stream: the head / tail split and k_huf in the sequence stage's shadow are for batches whose
+    // lists are in frame order.
+    const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr;
+    const bool huf_first = serial || ctx->opt.huf_variant == 3 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
                             db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !exp_env("MZD_EXP_HUF_BESIDE"));
     uint32_t nch = q4 ? (uint32_t)(huf_first || db->n_huf_tasks == 0 ? kQ4Chains : kQ4ChainsBeside) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
@@ -1166,7 +1232,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     const uint32_t wg_per_cu = q4 && 2 * q4_lds(nch) <= (size_t)160 * 1024 ? 2u : 1u;
     const uint64_t per_round = (uint64_t)nch * wg_per_cu * (uint64_t)(ctx->opt.assume_cus ? ctx->opt.assume_cus : (uint32_t)ctx->num_cus);
     uint32_t fA = db->n_frames;
-    if (!ctx->opt.no_split && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
+    if (!ctx->opt.no_split && !serial && db->n_seq_tasks > per_round && db->n_seq_tasks % per_round != 0) {
         const uint64_t lim = (db->n_seq_tasks / per_round) * per_round;
         // last frame boundary at or below the limit
         uint32_t lo = 0, hi = db->n_frames;
@@ -1217,6 +1283,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // front slack of a WINDOW of the blob: the frames are cut into runs whose bitstreams span < 4 GiB, one launch
     // per run (one run unless the blob is that large); a single frame beyond that takes k_seq.
     auto launch_seq = [&](uint32_t f0, uint32_t f1) {
+        if (db->seq_sorted) {  // the whole list, longest chains first (its bitstreams are within 4 GiB of the blob's start)
+            launch_seq_tasks(0, db->n_seq_tasks, pipe, 0);
+            return;
+        }
         if (!pipe) {
             launch_seq_tasks(db->frame_seq_task[f0], db->frame_seq_task[f1] - db->frame_seq_task[f0], false, 0);
             return;
@@ -1274,14 +1344,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
     auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {
         if (!count || no_exec) return;
+        // frames in the order of d_frame_order when the batch has one (largest first), else in batch order
         if (exec_b) {
-            k_exec_b<<<count, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames + first, db->d_blocks, db->d_sums, db->d_recs,
-                                           db->d_litbuf, db->d_status + first, db->d_out_len + first);
+            // (opt.exec_chunk: extra dynamic LDS per frame = a residency cap; frames in flight vs cache footprint of their slabs)
+            k_exec_b<<<count, 64, ctx->opt.exec_chunk, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                                                            db->d_litbuf, db->d_status, db->d_out_len, db->d_frame_order, first);
             return;
         }
-        k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames + first, db->d_blocks, db->d_sums,
-                                                     db->d_recs, db->d_tiles, db->d_litbuf, db->d_status + first,
-                                                     db->d_out_len + first, exec_cap);
+        k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
+                                                     db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
+                                                     db->d_out_len, exec_cap, db->d_frame_order, first);
     };
     // optional integrity check of the regenerated frames (extension: the reference never verifies it)
     auto launch_verify = [&](hipStream_t st, uint32_t first, uint32_t count) {
@@ -1328,6 +1400,29 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
+        if (db->huf_sorted && !seg) {
+            // one launch per table-size class: a wavefront's LDS is 16 tables of the CLASS's size, not of the batch's largest
+            // (MaxBits 11 next to MaxBits 5: 64 KiB per wavefront for everybody otherwise), and its 64 streams are of similar length
+            static const uint32_t kClassCells[3] = {32, 256, 2048};
+            uint32_t q0 = 0;
+            for (int c = 0; c < 3; c++) {
+                const uint32_t q1 = db->huf_class_end[c];
+                if (q1 > q0) {
+                    const uint32_t cells = std::min(db->huf_slot_cells, kClassCells[c]), n = 4 * (q1 - q0);
+                    const size_t lds = std::max<size_t>((size_t)kHufQuads * cells * 2, ctx->opt.huf_min_lds);
+                    if (c == 0 && (hv == 0 || hv == 3) && n >= 64u * (uint32_t)std::max(ctx->num_cus, 1)) {
+                        const uint32_t tstage = (uint32_t)((lds + 15) & ~(size_t)15);
+                        k_huf<<<(n + 63) / 64, 64, tstage + kHufTStageBytes, s>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries,
+                                                                                  db->d_litbuf, db->d_sums, cells, tstage);
+                    } else {
+                        k_huf<<<(n + 63) / 64, 64, lds, s>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries, db->d_litbuf,
+                                                           db->d_sums, cells, 0u);
+                    }
+                }
+                q0 = std::max(q0, q1);
+            }
+            return;
+        }
         if (seg)
             k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                db->d_litbuf, db->d_sums, seg_tbl);

@@ -5,43 +5,58 @@
 // (the 8-byte sequence records of the entropy stage, the regenerated literals) and the same statuses; another shape:
 //
 //   k_exec    a lane per SEQUENCE, 8 KiB of the block in LDS, a per-byte validity bitmap and a dataflow loop over
-//             the pending matches.  Its LDS pipe is what fills (every copy is a byte-misaligned LDS access: a cycle
-//             per active lane), and its 8.5 KiB per frame keep it from sharing a CU with the sequence stage.
-//   k_exec_b  the output is produced strictly IN ORDER, 64 bytes per pass, lane j making byte P + j:
-//               1. which sequence owns the byte: every sequence marks the first byte of its literal run and of its
-//                  match in a small LDS "head map" (one byte per output position, written once per 64-sequence
-//                  tile); a pass reads its 64 map bytes and a wave-wide max-scan (DPP) hands every lane the last
-//                  head at or below it;
-//               2. where the byte comes from: two ds_bpermute fetch the owner's displacement (match: -offset,
-//                  literal: literal cursor - output position), source = position + displacement;
-//               3. the byte itself: a literal (from a 512-byte LDS ring of the block's literals), a NEAR match byte
-//                  (the last 2 KiB of output live in an LDS ring), a FAR match byte (global memory: everything
-//                  older left for the frame's slab in 512-byte units), or a byte this very pass produces
-//                  (offset < 64: resolved between the lanes by pointer jumping, at most six rounds);
-//               4. one aligned byte store into the window ring.
-//             No byte-misaligned LDS access, no bitmap, no atomics, no barrier: all LDS instructions are aligned
-//             whole-wavefront ones (~16 LDS-pipe cycles per 64 bytes), and a frame needs 3 KiB of LDS, so a CU holds
-//             32 of them -- or a few beside a sequence-stage workgroup that owns the rest of the LDS.
+//             the pending matches.  Every copy is a byte-misaligned LDS access (a cycle per active lane in the LDS
+//             pipe), and its 8.5 KiB per frame keep it from sharing a CU with the sequence stage.
+//   k_exec_b  the output is produced strictly IN ORDER, 64 bytes per pass, lane j making byte P + j.  The work is
+//             organised in STRETCHES (up to 1024 output bytes and 512 literals of one 64-sequence tile); a stretch's
+//             setup leaves in LDS
+//               * a bitmap with one bit per output byte: "a literal run or a match starts here" (a HEAD);
+//               * a table with one 8-byte entry per head, in output order: {displacement D, mask M} such that the
+//                 byte at position p of that run comes from LDS address (p + D) & M --
+//                   literal        the stretch's literals, copied from the literal buffer into LDS in one go
+//                   staged match   16 source bytes per sequence, loaded from the frame's slab into LDS by the setup:
+//                                  every match whose source is final in memory.  All of a stretch's loads are in
+//                                  flight together; no pass waits for memory
+//                   window match   the last 2 KiB of output live in an LDS ring (position & 0x7ff, that is M)
+//             and a pass is: read its 64 bits of the bitmap, count the heads at or below every lane (v_mbcnt), read
+//             the table entry, read the byte, store it into the window ring -- ~13 vector and 5 LDS instructions,
+//             all aligned whole-wavefront ones.  Two rare cases take a longer pass (the setup marks the passes): a
+//             window match made by its own pass (offset <= lane; resolved between the lanes by pointer jumping, six
+//             rounds at most) and a window match that is neither staged nor in the ring any more (a long far match:
+//             the pass reads the slab itself).  The ring leaves for the slab in 512-byte units.
+//             No byte-misaligned LDS access, no validity bitmap, no barrier; 4.7 KiB of LDS per frame, 32 frames per CU.
 //
 // Hazards are ordered by construction: a wavefront's LDS operations execute in order (a pass's reads precede its
-// stores), global stores of the window units are waited for (vmcnt) before the NEXT unit is issued, and a far read
-// can only touch units at least two units old.
+// store); the slab is read only below `confirmed` (window units whose stores a wait on memory has seen complete) or
+// after such a wait.
 #pragma once
 
 namespace mzd {
 
-constexpr uint32_t kXbWin = 2048;      // near window (ring, position & (kXbWin - 1))
-constexpr uint32_t kXbMap = 512;       // head map (ring, position & (kXbMap - 1)); heads are written at most this far ahead
-constexpr uint32_t kXbLit = 512;       // literal ring: two units
-constexpr uint32_t kXbLitUnit = 256;   // 64 lanes x 4 bytes
-constexpr uint32_t kXbFlush = 512;     // 64 lanes x 8 bytes leave for global memory at a time
-static_assert(kXbWin >= 2 * kXbFlush + 64 + 64 + 256, "a far read must never meet the unit whose stores are still in flight");
+constexpr uint32_t kXbWin = 2048;      // window ring
+constexpr uint32_t kXbLit = 512;       // literals of the current stretch
+constexpr uint32_t kXbStage = 1024;    // staged matches of the current tile: 16 source bytes per sequence lane
+constexpr uint32_t kXbStretch = 1024;  // output bytes per stretch at most (16 passes; one bit each in the bitmap)
+constexpr uint32_t kXbFlush = 512;     // 64 lanes x 8 bytes leave for the slab at a time
+constexpr int kXbNear = (int)kXbWin - 64;  // a window match byte less than this far behind its pass start is read from the ring
 
-constexpr uint32_t kXbStage = 1024;    // far matches of the current tile: 16 source bytes per sequence lane
+struct XbLds {
+    uint8_t win[kXbWin];              // 0x000
+    uint8_t lit[kXbLit];              // 0x800
+    uint8_t stage[kXbStage];          // 0xa00
+    uint2 table[130];                 // 0xe00: [0] the run that continues from the stretch before, [1 + k] head k of the stretch
+    uint32_t bits[kXbStretch / 32];   // heads
+    uint32_t special;                 // passes with a window match the plain pass cannot serve (bit = pass of the stretch)
+    uint32_t pad[3];
+};
+static_assert(offsetof(XbLds, lit) == kXbWin && offsetof(XbLds, table) % 8 == 0 && offsetof(XbLds, bits) % 8 == 0 && sizeof(XbLds) % 16 == 0,
+              "alignment of the LDS areas");
+static_assert(kXbStretch + 64 + kXbFlush <= kXbWin, "a window unit is issued before the ring wraps onto it (a stretch starts with less than a unit pending)");
+
 #ifdef MZD_XB_STATS
-// tools/xb_stats.py: 0 tiles, 1 fast tiles, 2 fast passes, 3 general passes, 4 passes with a byte made by the pass itself,
-// 5 fast passes that went to memory themselves, 6 staged matches, 7 matches, 8 cycles in fast-tile setup, 9 cycles in fast
-// passes, 10 cycles in general tiles, 11 cycles total, 12 frames
+// tools/xb_stats.py: 0 tiles, 1 stretches, 2 plain passes, 3 special passes, 4 passes with a byte made by the pass itself,
+// 5 passes that went to memory themselves, 6 staged matches, 7 matches, 8 cycles in tile setup, 9 cycles in stretch
+// setup, 10 cycles in passes, 11 cycles total, 12 frames
 __device__ unsigned long long g_xb_stats[16];
 #define XB_STAT(i, n) (xbst[i] += (unsigned long long)(n))
 #define XB_CLOCK() __builtin_readcyclecounter()
@@ -49,28 +64,6 @@ __device__ unsigned long long g_xb_stats[16];
 #define XB_STAT(i, n) do { } while (0)
 #define XB_CLOCK() 0ull
 #endif
-struct XbLds {
-    uint8_t win[kXbWin];      // 0x000
-    uint8_t lit[kXbLit];      // 0x800
-    uint8_t map[kXbMap];      // 0xa00
-    uint8_t stage[kXbStage];  // 0xc00
-};
-static_assert(offsetof(XbLds, lit) == 0x800 && offsetof(XbLds, map) == 0xa00 && offsetof(XbLds, stage) == 0xc00 && kXbWin == 0x800 &&
-              kXbLit == 0x200 && kXbMap == 0x200 && kXbStage == 0x400, "xb_pass addresses the rings with immediate masks and offsets");
-// head map entry: (sequence lane << 2) | code; 0 = no head at this byte
-enum { kXbLitHead = 1, kXbMatchHead = 2, kXbStagedHead = 3 };
-
-// wave64 inclusive max-scan on the DPP path (values are unsigned, 0 = nothing): row_shr 1/2/4/8, row_bcast 15/31
-__device__ __forceinline__ uint32_t wave_incl_max_dpp(uint32_t v)
-{
-    v = max(v, dpp_shr<0x111, 0xf, 0xf>(v));
-    v = max(v, dpp_shr<0x112, 0xf, 0xf>(v));
-    v = max(v, dpp_shr<0x114, 0xf, 0xe>(v));
-    v = max(v, dpp_shr<0x118, 0xf, 0xc>(v));
-    v = max(v, dpp_shr<0x142, 0xa, 0xf>(v));
-    v = max(v, dpp_shr<0x143, 0xc, 0xf>(v));
-    return v;
-}
 
 __device__ __forceinline__ void xb_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -81,10 +74,9 @@ __device__ __forceinline__ void xb_flush_bytes(XbLds &sh, uint8_t *out, uint32_t
     flushed = upto;
 }
 
-// one step of the steady-state flush: the 512-byte unit at `flushed` (or the bytes up to the next unit boundary)
-__device__ __forceinline__ void xb_flush_step(XbLds &sh, uint8_t *out, uint32_t &flushed, int lane, bool wait = true)
+// the 512-byte unit at `flushed` (or the bytes up to the next unit boundary) leaves for the slab
+__device__ __forceinline__ void xb_flush_step(XbLds &sh, uint8_t *out, uint32_t &flushed, int lane)
 {
-    if (wait) xb_wait_vm();  // the previous unit has arrived: every unit but the one issued below is final in memory
     if ((flushed & (kXbFlush - 1)) == 0) {
         const uint32_t x = flushed + 8u * (uint32_t)lane;
         const uint64_t v = *(const uint64_t *)&sh.win[x & (kXbWin - 1)];
@@ -96,18 +88,18 @@ __device__ __forceinline__ void xb_flush_step(XbLds &sh, uint8_t *out, uint32_t 
 }
 
 // after a bulk write straight to the slab (Raw / RLE blocks, literal-only blocks): the window ring takes the last
-// bytes of the frame back from memory so that the next block's near matches find them
-__device__ __forceinline__ void xb_reload_window(XbLds &sh, const uint8_t *out, uint32_t outPos, uint32_t &validFrom,
-                                                 uint32_t &flushed, int lane)
+// bytes of the frame back from memory so that the next block's window matches find them
+__device__ __forceinline__ void xb_reload_window(XbLds &sh, const uint8_t *out, uint32_t outPos, uint32_t &flushed, uint32_t &confirmed,
+                                                 int lane)
 {
     xb_wait_vm();  // the bulk stores are in memory (same CU: visible to the loads below)
     const uint32_t lo = outPos > kXbWin ? outPos - kXbWin : 0u;
-    const uint32_t lo4 = (lo + 3u) & ~3u;
+    const uint32_t lo4 = (lo + 3u) & ~3u;  // (the ring is trusted kXbNear + 63 bytes back: 1 to 3 bytes less than it holds here)
     const uint32_t hi4 = outPos & ~3u;
     for (uint32_t x = lo4 + 4u * (uint32_t)lane; x < hi4; x += 256) *(uint32_t *)&sh.win[x & (kXbWin - 1)] = ((const U32U *)(out + x))->v;
     for (uint32_t x = max(lo4, hi4) + (uint32_t)lane; x < outPos; x += 64) sh.win[x & (kXbWin - 1)] = out[x];
-    validFrom = min(lo4, outPos);
     flushed = outPos;
+    confirmed = outPos;
 }
 
 __device__ __forceinline__ void xb_bulk_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane)
@@ -125,19 +117,12 @@ __device__ __forceinline__ void xb_bulk_fill(uint8_t *dst, uint32_t byte, uint32
     for (uint32_t i = (n16 << 4) + (uint32_t)lane; i < n; i += 64) dst[i] = (uint8_t)v;
 }
 
-// one 256-byte unit of the block's literals, a dword per lane (zero beyond the regenerated size)
-__device__ __forceinline__ uint32_t xb_lit_unit(const uint8_t *lits, uint32_t unit_off, uint32_t lit_regen, int lane)
-{
-    const uint32_t i = unit_off + 4u * (uint32_t)lane;
-    return i < lit_regen ? ((const U32U *)(lits + i))->v : 0u;
-}
-
-
 // lanes whose source byte is produced by this very pass (offset <= lane): pointer jumping between the lanes -- a lane either
 // takes its source lane's byte or, while that one is still waiting itself, its source lane.  At most six rounds.
-__device__ __forceinline__ uint32_t xb_resolve_in_pass(uint32_t val, uint32_t srcl, bool dep)
+__device__ __noinline__ uint32_t xb_resolve_in_pass(uint32_t val, int r, uint32_t lane)
 {
-    uint32_t done = dep ? 0u : 1u;
+    uint32_t srcl = r >= 0 ? (uint32_t)r : lane;
+    uint32_t done = r >= 0 ? 0u : 1u;
     do {
         const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)val);
         const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)done);
@@ -154,105 +139,40 @@ __device__ __forceinline__ uint32_t xb_resolve_in_pass(uint32_t val, uint32_t sr
     return val;
 }
 
-// One pass of the steady state, hand-written: 64 output bytes [P, P + 64) (the lanes of `act`; all of them except in a
-// tile's last pass).  Preconditions (the caller's fast-tile test): the XbLds block sits at LDS address 0; the heads of
-// every sequence that starts inside the pass are in the map; the window ring holds [P - kXbWin, P); the literal ring
-// holds every literal the pass consumes; everything below P - kXbWin has been issued to the slab.
-// A byte's source by the code of the head that owns it:
-//   1 literal        literal ring,  index p + dlv of the owner
-//   2 match          window ring, position p + offx (= -offset) -- or, older than the window, the slab (rare: the tile
-//                    setup stages far matches; what is left are long ones and sources not yet confirmed in memory)
-//   3 staged match   stage, p + offx (= 16 * owner lane - match start)
-// The compiler's version of the same statement (the general loop in k_exec_b) spends ~55 scalar and ~12 branch
-// instructions per pass on exec-mask bookkeeping; this one has 9 scalar ones and one branch.
-// gfx950 wait states kept by hand (the hazard recogniser does not look into inline asm): 2 between a VALU write of a
-// VGPR and a DPP read, 1 before a v_readlane of it, 2 between a VALU write of an SGPR / VCC and a VALU read of it.
-//   r (out): source position relative to P for window-ring match lanes (>= 0: produced by this pass), -1 for all others
-__device__ __forceinline__ void xb_pass(uint32_t P, uint64_t act, uint32_t lane, int offx, int dlv, uint32_t &carry,
-                                        const uint8_t *out, uint32_t litMask, uint32_t &val, int &r, uint64_t &dep)
+
+// index of the table entry that owns every byte of a pass: sbase + (heads of the pass at or below the lane) - 1
+__device__ __forceinline__ uint32_t xb_owner(uint64_t H, uint32_t sbase, uint32_t lblo, uint32_t lbhi)
 {
-    uint32_t p, m, e, t, g, x, y, q, a, b, c, l, f;
-    uint64_t far, sn;
-    asm volatile(
-        "v_add_u32 %[p], %[P], %[lane]\n\t"
-        "v_mov_b32 %[e], 0\n\t"
-        "v_and_b32 %[m], 0x1ff, %[p]\n\t"
-        "s_mov_b64 exec, %[act]\n\t"
-        "ds_read_u8 %[e], %[m] offset:0xa00\n\t"        // head map
-        "s_mov_b64 exec, -1\n\t"
-        "v_mov_b32 %[t], 0\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        // inclusive max-scan: the last head at or below every byte
-        "v_max_u32_dpp %[e], %[e], %[e] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[e], %[e], %[e] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[e], %[e], %[e] row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[e], %[e], %[e] row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[e], %[e], %[e] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_mov_b32_dpp %[t], %[e] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_max3_u32 %[g], %[e], %[t], %[carry]\n\t"    // (sequence lane << 2) | code
-        "v_and_b32 %[c], 3, %[g]\n\t"
-        "v_readlane_b32 %[carry], %[g], 63\n\t"
-        "ds_bpermute_b32 %[x], %[g], %[offx]\n\t"       // the owner's match displacement (lane = address bits 7:2)
-        "ds_bpermute_b32 %[y], %[g], %[dlv]\n\t"        // the owner's literal cursor - output position
-        "v_cmp_lt_u32 vcc, 1, %[c]\n\t"                 // match byte (codes 2, 3)
-        "v_cmp_eq_u32 %[sn], 2, %[c]\n\t"               // ... from the window ring
-        "s_and_b64 vcc, vcc, %[act]\n\t"
-        "s_and_b64 %[sn], %[sn], %[act]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cndmask_b32 %[q], %[y], %[x], vcc\n\t"
-        "v_add_u32 %[q], %[p], %[q]\n\t"                // code 2: source position in the frame; 1: index in the block's literals; 3: stage offset
-        "v_add_u32 %[r], %[lane], %[x]\n\t"
-        "v_cndmask_b32 %[r], -1, %[r], %[sn]\n\t"
-        "v_and_b32 %[a], 0x7ff, %[q]\n\t"               // window ring
-        "v_and_or_b32 %[b], %[q], %[litmask], %[c800]\n\t"  // literal ring
-        "v_cndmask_b32 %[a], %[b], %[a], vcc\n\t"
-        "v_cmp_eq_u32 vcc, 3, %[c]\n\t"
-        "v_and_or_b32 %[b], %[q], %[c3ff], %[cc00]\n\t"  // stage
-        "v_cmp_le_i32 %[dep], 0, %[r]\n\t"
-        "v_cndmask_b32 %[a], %[a], %[b], vcc\n\t"
-        "v_cmp_gt_i32 %[far], %[negw], %[r]\n\t"        // older than the window
-        "ds_read_u8 %[l], %[a]\n\t"
-        "s_cmp_eq_u64 %[far], 0\n\t"
-        "s_cbranch_scc1 L_xb_nofar_%=\n\t"
-        "s_waitcnt vmcnt(0)\n\t"                        // every window unit issued so far has arrived in the slab
-        "s_mov_b64 exec, %[far]\n\t"
-        "global_load_ubyte %[f], %[q], %[outb]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_waitcnt vmcnt(0)\n"
-        "L_xb_nofar_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cndmask_b32 %[val], %[l], %[f], %[far]\n\t"
-        : [p] "=&v"(p), [m] "=&v"(m), [e] "=&v"(e), [t] "=&v"(t), [g] "=&v"(g), [x] "=&v"(x), [y] "=&v"(y), [q] "=&v"(q),
-          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [l] "=&v"(l), [f] "=&v"(f), [far] "=&s"(far), [dep] "=&s"(dep), [sn] "=&s"(sn),
-          [val] "=&v"(val), [r] "=&v"(r), [carry] "+s"(carry)
-        : [P] "s"(P), [act] "s"(act), [lane] "v"(lane), [offx] "v"(offx), [dlv] "v"(dlv), [outb] "s"(out),
-          [litmask] "s"(litMask), [c800] "v"(0x800u), [c3ff] "s"(0x3ffu), [cc00] "v"(0xc00u), [negw] "s"(-(int)kXbWin)
-        : "memory", "vcc", "scc");
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H, sbase));
+    const uint32_t own = ((uint32_t)H & lblo) | ((uint32_t)(H >> 32) & lbhi);
+    return below - (own ? 0u : 1u);
 }
 
 __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
-                                                  int32_t *frame_status, uint64_t *frame_out_len)
+                                                  int32_t *frame_status, uint64_t *frame_out_len,
+                                                  const uint32_t *__restrict__ order, uint32_t first)
 {
     __shared__ __attribute__((aligned(16))) XbLds sh;
+    const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
-    const DFrame fr = frames[blockIdx.x];
+    // this wavefront's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)
+    const uint32_t fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    const DFrame fr = frames[fidx];
     uint8_t *out = out_blob + fr.out_offset;
 
     int error = fr.plan_status;
     uint32_t outPos = 0;         // bytes of this frame produced so far (frames of 4 GiB and more take k_exec)
-    uint32_t flushed = 0;        // [0, flushed) has left for the slab (the last unit may still be in flight)
-    uint32_t validFrom = 0;      // the window ring holds [max(validFrom, outPos - kXbWin), outPos)
-    uint32_t confirmed = 0;      // [0, confirmed) is known to have ARRIVED in the slab (a wait on memory came after its stores)
+    uint32_t flushed = 0;        // [0, flushed) has left for the slab (the youngest units may still be in flight)
+    uint32_t confirmed = 0;      // [0, confirmed) has ARRIVED in the slab: a wait on memory came after its stores
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
-    for (uint32_t i = 4u * (uint32_t)lane; i < kXbMap; i += 256) *(uint32_t *)&sh.map[i] = 0u;
-    const bool fastOK = (uint32_t)(uintptr_t)&sh == 0u;  // xb_pass addresses the rings with immediate offsets
+    if (lane < (int)(kXbStretch / 32)) sh.bits[lane] = 0u;
+    if (lane == 0) sh.special = 0u;
+    // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
+    uint32_t v7ff = kXbWin - 1;
+    uint32_t lblo = lane < 32 ? 1u << lane : 0u, lbhi = lane < 32 ? 0u : 1u << (lane - 32);
+    asm volatile("" : "+v"(v7ff), "+v"(lblo), "+v"(lbhi));
 #ifdef MZD_XB_STATS
     unsigned long long xbst[16] = {0};
     const unsigned long long xb_t0 = XB_CLOCK();
@@ -270,8 +190,7 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
-            xb_reload_window(sh, out, outPos, validFrom, flushed, lane);
-            confirmed = outPos;
+            xb_reload_window(sh, out, outPos, flushed, confirmed, lane);
             continue;
         }
 
@@ -298,23 +217,12 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
-            xb_reload_window(sh, out, outPos, validFrom, flushed, lane);
-            confirmed = outPos;
+            xb_reload_window(sh, out, outPos, flushed, confirmed, lane);
             continue;
         }
-
-        // ---- the literal ring: units of 256 bytes, [litLo, litLo + 512) resident, the next unit on its way in `pend`
-        uint32_t litLo = 0, litC = 0;  // litC: literal cursor (literals consumed by the passes so far)
-        uint32_t pend = 0;
-        const uint32_t litMask = litRle ? 0u : kXbLit - 1;
-        const uint32_t litEnd = litRle ? 0u : b.lit_regen;  // refills stop here
-        if (litRle) {
-            sh.lit[0] = lits[0];
-        } else {
-            const uint32_t u0 = xb_lit_unit(lits, 0, b.lit_regen, lane), u1 = xb_lit_unit(lits, kXbLitUnit, b.lit_regen, lane);
-            pend = xb_lit_unit(lits, 2 * kXbLitUnit, b.lit_regen, lane);
-            *(uint32_t *)&sh.lit[4 * lane] = u0;
-            *(uint32_t *)&sh.lit[kXbLitUnit + 4 * lane] = u1;
+        if (litRle) {  // RLE literals (literals.go:390-396): every literal of every stretch is this byte
+            const uint64_t v = lits[0] * 0x0101010101010101ull;
+            *(uint64_t *)&sh.lit[8 * lane] = v;
         }
 
         // ---- tiles of 64 sequences; the literals after the last sequence (sequence_execution.go:55-59) ride along as
@@ -326,7 +234,9 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
         uint32_t tileStart = outPos;  // frame-relative position of the tile's first byte
         uint32_t litRun = 0;          // literals of the block that earlier tiles consumed
         uint64_t rec_n = (uint32_t)lane < b.n_seq ? brec[lane] : 0ull;
-        for (uint32_t t = 0; t < ntiles && error == MZD_OK; t++) {
+        for (uint32_t t = 0; t < ntiles; t++) {
+            const unsigned long long xb_t1 = XB_CLOCK();
+            (void)xb_t1;
             const uint64_t rec = rec_n;
             const uint32_t si = t * 64 + (uint32_t)lane;
             {
@@ -347,121 +257,136 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
             const uint32_t tileLits = (uint32_t)__builtin_amdgcn_readlane((int)sLL, 63);
             const uint32_t tileOut = (uint32_t)__builtin_amdgcn_readlane((int)sOut, 63);
             const uint32_t mstart = tileStart + sOut - ML, lstart = mstart - LL;  // frame-relative
+            const uint32_t lsrc = litRun + sLL - LL;                             // the sequence's first literal (index in the block)
             const bool bad = isSeq && ML > 0 && (off <= 0 || (uint32_t)off > mstart);  // ringbuffer.go:206-214
             if (wave_any(bad)) {
                 error = MZD_ERR_OFFSET;
                 break;
             }
-            const int offv = -off;                                         // match byte p comes from p + offv
-            const int dlv = (int)(litRun + sLL - LL) - (int)lstart;        // literal byte p is literal p + dlv of the block
             const uint32_t E = tileStart + tileOut;
-
-            uint32_t P = tileStart, hlim = tileStart, carry = 0;
+            // a match byte at position p comes from LDS offset (p + md.x) & md.y: the window ring until a stretch setup stages it
+            uint2 md = make_uint2((uint32_t)(-off), kXbWin - 1);
+            const uint32_t litD = (uint32_t)offsetof(XbLds, lit) + lsrc - lstart;  // literal byte p: LDS offset p + litD - la
+            const bool ringSpecial = off < 64 || off > kXbNear;  // (as long as the match stays a window match)
+            uint32_t la = litRun;  // literal cursor at the stretch's start
+            uint32_t P = tileStart;
+            uint32_t p = P + (uint32_t)lane;
             XB_STAT(0, 1);
             XB_STAT(7, __popcll(wave_ballot(isSeq && ML > 0)));
-            const unsigned long long xb_t1 = XB_CLOCK();
-            (void)xb_t1;
-            // ---- the steady state: a tile whose passes need nothing but the pass itself (xb_pass)
-            if (fastOK && tileStart >= validFrom + kXbWin && tileOut <= 1024 && tileLits <= kXbLitUnit) {
-                // matches whose source is final in the slab (the window units of earlier tiles, confirmed by the last wait on
-                // memory): 16 source bytes per sequence into the stage, ALL of the tile's loads in flight together -- a pass
-                // then finds the byte in LDS instead of waiting for memory itself
-                const uint32_t q0 = mstart - (uint32_t)off;
-                const bool stg = isSeq && ML > 0 && ML <= 16 && q0 + ML <= confirmed;
-                U128U sv{0, 0, 0, 0};
-                if (stg) sv = *(const U128U *)(out + q0);
-                while (litRun - litLo >= kXbLitUnit && litLo + kXbLit < litEnd) {
-                    *(uint32_t *)&sh.lit[(litLo & (kXbLit - 1)) + 4 * lane] = pend;
-                    litLo += kXbLitUnit;
-                    pend = xb_lit_unit(lits, litLo + kXbLit, b.lit_regen, lane);
-                }
-                xb_wait_vm();  // the staged bytes are here, and so is every window unit issued by earlier tiles
-                confirmed = flushed;
-                *(uint4 *)&sh.stage[16 * lane] = make_uint4(sv.x, sv.y, sv.z, sv.w);
-                while (tileStart - flushed >= kXbFlush) xb_flush_step(sh, out, flushed, lane, false);
-                const int offx = stg ? (int)(16u * (uint32_t)lane) - (int)mstart : offv;
-                XB_STAT(1, 1);
-                XB_STAT(6, __popcll(wave_ballot(stg)));
+            XB_STAT(8, XB_CLOCK() - xb_t1);
+
+            while (P < E) {
+                // ---- a stretch: setup for up to 1024 output bytes / 512 literals, then its passes
                 const unsigned long long xb_t2 = XB_CLOCK();
                 (void)xb_t2;
-                XB_STAT(8, xb_t2 - xb_t1);
-                const uint32_t mcode = ((uint32_t)lane << 2) | (stg ? (uint32_t)kXbStagedHead : (uint32_t)kXbMatchHead);
-                for (uint32_t lo = tileStart; lo < E; lo += kXbMap) {
-                    // the heads of this stretch of the tile (the map reaches kXbMap bytes); the stretch's passes only read them
-                    if (LL > 0 && lstart - lo < kXbMap) sh.map[lstart & (kXbMap - 1)] = (uint8_t)((lane << 2) | kXbLitHead);
-                    if (ML > 0 && mstart - lo < kXbMap) sh.map[mstart & (kXbMap - 1)] = (uint8_t)mcode;
-                    const uint32_t stretchEnd = min(E, lo + kXbMap);
-                    for (; P < stretchEnd; P += 64) {
-                        const uint32_t n = stretchEnd - P;
-                        const uint64_t act = n >= 64 ? ~0ull : (1ull << n) - 1;
-                        uint32_t val;
-                        int r;
-                        uint64_t dep;
-                        xb_pass(P, act, (uint32_t)lane, offx, dlv, carry, out, litMask, val, r, dep);
-                        XB_STAT(2, 1);
-                        XB_STAT(4, dep != 0);
-                        XB_STAT(5, wave_any(r < -(int)kXbWin));
-                        if (dep) val = xb_resolve_in_pass(val, r >= 0 ? (uint32_t)r : (uint32_t)lane, r >= 0);
-                        if ((act >> lane) & 1) sh.win[(P + (uint32_t)lane) & (kXbWin - 1)] = (uint8_t)val;
+                uint32_t sEnd = min(E, P + kXbStretch);
+                // literal cursor at the stretch's end: the last sequence that starts at or before it (the lanes' starts ascend;
+                // lane 0 starts at tileStart); a stretch that would need more than 512 literals ends where the 512th does
+                uint32_t lb;
+                {
+                    const int k = 63 - __builtin_clzll(wave_ballot(lstart <= sEnd));
+                    const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)lstart, k), ks = (uint32_t)__builtin_amdgcn_readlane((int)lsrc, k);
+                    const uint32_t kn = (uint32_t)__builtin_amdgcn_readlane((int)LL, k);
+                    lb = ks + min(kn, sEnd - kl);
+                }
+                if (lb - la > kXbLit) {
+                    const int k = 63 - __builtin_clzll(wave_ballot(lsrc <= la + kXbLit));  // the run that holds literal la + 512
+                    const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)lstart, k), ks = (uint32_t)__builtin_amdgcn_readlane((int)lsrc, k);
+                    sEnd = kl + (la + kXbLit - ks);
+                    lb = la + kXbLit;
+                }
+                const uint32_t sLen = sEnd - P;
+                const bool litIn = LL > 0 && lstart - P < sLen;   // the sequence's literal run / match starts in this stretch
+                const bool mIn = ML > 0 && mstart - P < sLen;
+                const bool contL = lstart < P && P < mstart;      // ... or continues from the stretch before (one lane at most)
+                const bool contM = mstart < P && P < mstart + ML;
+                // matches whose source is final in the slab: 16 source bytes into the stage, all of the stretch's loads in
+                // flight together, so that no pass has to wait for memory itself
+                // (a match not farther back than the ring reaches is served by the ring whatever pass it falls into)
+                const uint32_t q0 = mstart - (uint32_t)off;
+                const bool stg = mIn && ML <= 16 && off > kXbNear && q0 + ML <= confirmed;
+                U128U sv{0, 0, 0, 0};
+                if (stg) sv = *(const U128U *)(out + q0);
+                // the stretch's literals: [la, la + 512) of the block's literals
+                uint64_t lv = 0;
+                {
+                    const uint32_t li = la + 8u * (uint32_t)lane;
+                    if (!litRle && li < lb) lv = ((const U64U *)(lits + li))->v;  // (lb <= lit_regen)
+                }
+                // table index of the sequence's heads: 1 + the heads of the lanes below (+ its own literal head)
+                const uint64_t litMask = wave_ballot(litIn), mMask = wave_ballot(mIn);
+                const uint32_t hb = __builtin_amdgcn_mbcnt_hi((uint32_t)(litMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)litMask, 1u)) +
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mMask, 0u));
+                if (stg) md = make_uint2((uint32_t)offsetof(XbLds, stage) + 16u * (uint32_t)lane - mstart, 0xFFFFFFFFu);
+                const uint2 ld = make_uint2(litD - la, 0xFFFFFFFFu);
+                if (litIn || contL) sh.table[contL ? 0u : hb] = ld;
+                if (mIn || contM) sh.table[contM ? 0u : hb + (litIn ? 1u : 0u)] = md;
+                if (litIn) atomicOr(&sh.bits[(lstart - P) >> 5], 1u << ((lstart - P) & 31));
+                if (mIn) atomicOr(&sh.bits[(mstart - P) >> 5], 1u << ((mstart - P) & 31));
+                // passes that hold a byte of a window match with a very small or very large offset
+                const bool spec = (mIn || contM) && md.y == kXbWin - 1 && ringSpecial;
+                if (wave_any(spec)) {
+                    if (spec) {
+                        const uint32_t f0 = (max(mstart, P) - P) >> 6, f1 = (min(mstart + ML, sEnd) - 1 - P) >> 6;
+                        atomicOr(&sh.special, (2u << f1) - (1u << f0));
                     }
-                    *(uint64_t *)&sh.map[8 * lane] = 0ull;  // every head of the stretch has been used
                 }
-                P = E;
-                litC = litRun + tileLits;
+#ifndef MZD_ABL_XB_LATE  /* ablation, timing only (wrong bytes): what the passes cost when the stretch's loads travel behind them */
+                xb_wait_vm();  // the staged bytes and the literals are here, and so is every window unit issued before
+                confirmed = flushed;
+                if (stg) *(uint4 *)&sh.stage[16 * lane] = make_uint4(sv.x, sv.y, sv.z, sv.w);
+                if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = lv;
+#else
+                confirmed = flushed;
+#endif
+                while (P - flushed >= kXbFlush) xb_flush_step(sh, out, flushed, lane);
+                uint32_t special = __builtin_amdgcn_readfirstlane((int)sh.special);
+                XB_STAT(1, 1);
+                XB_STAT(6, __popcll(wave_ballot(stg)));
                 XB_STAT(9, XB_CLOCK() - xb_t2);
-            }
-#ifdef MZD_XB_STATS
-            const unsigned long long xb_t3 = XB_CLOCK();
-            const bool xb_general = P < E;
+                const unsigned long long xb_t3 = XB_CLOCK();
+                (void)xb_t3;
+
+                uint32_t sbase = 1;
+                const uint64_t *hbits = (const uint64_t *)sh.bits;
+                for (uint32_t k = 0; P < sEnd; k++, P += 64, p += 64, special >>= 1) {
+                    const uint64_t H = hbits[k];
+                    const uint32_t own = xb_owner(H, sbase, lblo, lbhi);
+                    sbase = (uint32_t)__builtin_amdgcn_readlane((int)own, 63) + 1u;
+                    const uint2 e = sh.table[own];
+                    const uint32_t s = p + e.x;
+                    uint32_t val = lds[s & e.y];
+                    if (special & 1u) {
+                        // window matches of this pass: made by the pass itself (offset <= lane) or behind the ring
+                        const uint32_t n = sEnd - P;
+                        const bool act = (uint32_t)lane < n && e.y == kXbWin - 1;
+                        const int r = act ? (int)(e.x + (uint32_t)lane) : -1;  // lane - offset
+                        const bool far = act && r < -kXbNear;
+                        XB_STAT(3, 1);
+                        XB_STAT(4, wave_any(r >= 0));
+                        XB_STAT(5, wave_any(far));
+                        if (wave_any(far)) {
+                            xb_wait_vm();  // every window unit issued so far has arrived in the slab
+                            if (far) val = out[s];
+                        }
+                        if (wave_any(r >= 0)) val = xb_resolve_in_pass(val, r, (uint32_t)lane);
+                    } else {
+                        XB_STAT(2, 1);
+                    }
+                    sh.win[p & v7ff] = (uint8_t)val;  // (beyond the tile's end: bytes the next tile overwrites before anything reads them)
+                }
+#ifdef MZD_ABL_XB_LATE
+                xb_wait_vm();
+                if (stg) *(uint4 *)&sh.stage[16 * lane] = make_uint4(sv.x, sv.y, sv.z, sv.w);
+                if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = lv;
 #endif
-            while (P < E) {
-                // heads of the tile's sequences, as far ahead as the map reaches
-                if (P + 64 > hlim && hlim < E) {
-                    const uint32_t lo = hlim, span = P + kXbMap - hlim;
-                    if (LL > 0 && lstart - lo < span) sh.map[lstart & (kXbMap - 1)] = (uint8_t)((lane << 2) | kXbLitHead);
-                    if (ML > 0 && mstart - lo < span) sh.map[mstart & (kXbMap - 1)] = (uint8_t)((lane << 2) | kXbMatchHead);
-                    hlim = P + kXbMap;
-                }
-                // literal ring: the unit below the cursor's is dead
-                while (litC - litLo >= kXbLitUnit && litLo + kXbLit < litEnd) {
-                    *(uint32_t *)&sh.lit[(litLo & (kXbLit - 1)) + 4 * lane] = pend;
-                    litLo += kXbLitUnit;
-                    pend = xb_lit_unit(lits, litLo + kXbLit, b.lit_regen, lane);
-                }
-                const uint32_t p = P + (uint32_t)lane;
-                const bool act = p < E;
-                uint32_t e = 0;
-                if (act) {
-                    e = sh.map[p & (kXbMap - 1)];
-                    sh.map[p & (kXbMap - 1)] = 0;
-                }
-                uint32_t g = max(wave_incl_max_dpp(e), carry);  // the last head at or below this byte: (sequence lane << 2) | kind
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)g, 63);
-                const bool isM = (g & 2u) != 0;
-                const int X = __builtin_amdgcn_ds_bpermute((int)(g & 0xFCu), offv);
-                const int Y = __builtin_amdgcn_ds_bpermute((int)(g & 0xFCu), dlv);
-                const uint32_t q = p + (uint32_t)(isM ? X : Y);  // match: frame-relative source position; literal: index in the block's literals
-                const uint32_t vlo = max(validFrom, P > kXbWin ? P - kXbWin : 0u);
-                const bool mAct = act && isM;
-                const bool dep = mAct && q >= P;   // produced by this very pass (offset <= lane)
-                const bool far = mAct && q < vlo;  // older than the window: final in the slab
-                uint32_t val = 0;
-                if (far) val = out[q];
-                if (act && !dep && !far) {
-                    const uint32_t a = isM ? (uint32_t)offsetof(XbLds, win) + (q & (kXbWin - 1)) : (uint32_t)offsetof(XbLds, lit) + (q & litMask);
-                    val = ((const uint8_t *)&sh)[a];
-                }
-                const uint64_t litm = wave_ballot(act && !isM);
-                if (litm) litC = (uint32_t)__builtin_amdgcn_readlane((int)q, 63 - __builtin_clzll(litm)) + 1u;
-                if (wave_any(dep)) val = xb_resolve_in_pass(val, dep ? q - P : (uint32_t)lane, dep);
-                XB_STAT(3, 1);
-                if (act) sh.win[p & (kXbWin - 1)] = (uint8_t)val;
-                P = min(P + 64, E);
-                if (P - flushed >= kXbFlush) xb_flush_step(sh, out, flushed, lane);
+                P = sEnd;  // (a stretch cut short by its literals ends inside a pass)
+                p = P + (uint32_t)lane;
+                if (lane < (int)(kXbStretch / 64)) ((uint64_t *)sh.bits)[lane] = 0ull;  // every head of the stretch has been used
+                if (lane == 0) sh.special = 0u;
+                la = lb;
+                XB_STAT(10, XB_CLOCK() - xb_t3);
             }
-#ifdef MZD_XB_STATS
-            if (xb_general) xbst[10] += XB_CLOCK() - xb_t3;
-#endif
             tileStart = E;
             litRun += tileLits;
         }
@@ -484,8 +409,8 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
     if (lane == 0) {
         int e = error;
         if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
-        frame_status[blockIdx.x] = e;
-        frame_out_len[blockIdx.x] = outPos;
+        frame_status[fidx] = e;
+        frame_out_len[fidx] = outPos;
     }
 }
 

@@ -2368,15 +2368,18 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
                                                const TileBase *__restrict__ tiles, const uint8_t *__restrict__ litbuf,
-                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap)
+                                               int32_t *frame_status, uint64_t *frame_out_len, uint32_t cap,
+                                               const uint32_t *__restrict__ order, uint32_t first)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // this workgroup's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)
+    const uint32_t fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
     uint8_t *buf = smem;                                        // cap + 32 bytes
     uint32_t *vmap = (uint32_t *)(smem + cap + 32);             // cap / 32 + 4 words
     ExecShared *sh = (ExecShared *)(smem + cap + 32 + (cap / 32 + 4) * 4);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-    const DFrame fr = frames[blockIdx.x];
+    const DFrame fr = frames[fidx];
     uint8_t *out = out_blob + fr.out_offset;
 
     if (tid == 0) sh->error = fr.plan_status;
@@ -2944,8 +2947,8 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
     if (tid == 0) {
         int e = sh->error;
         if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
-        frame_status[blockIdx.x] = e;
-        frame_out_len[blockIdx.x] = outPos;
+        frame_status[fidx] = e;
+        frame_out_len[fidx] = outPos;
     }
 }
 

@@ -41,9 +41,18 @@ def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads, exec_v
 @pytest.mark.parametrize("assume_cus", [1, 3, 20])
 def test_split_batch_two_streams(corpus, assume_cus):
     """k_seq(tail) on the caller's stream overlapped with k_exec(head) on the library's second
-    stream: force the split on the small corpus batch by pretending the device has few CUs."""
+    stream: force the split on a small batch by pretending the device has few CUs.  The split is for batches whose work
+    lists are in frame order (homogeneous frames: here 300 text-like ones of 8 KiB); the corpus, whose lists are ordered by
+    size at upload, runs its stages one after the other through the same context."""
+    from tools import synth_binding as sb
     c = z.Context(0, assume_cus=assume_cus)
+    blob, off, ln, ck, ns = sb.make_batch(4, 11, 300, frame_bytes=8192, threads=4)
+    frames = [blob[int(o):int(o + l)].tobytes() for o, l in zip(off, ln)]
     for _ in range(2):  # twice: the resident state is reset per run
+        outs, sts = _decode(frames, c)
+        assert sts == [0] * len(frames)
+        for o, k in zip(outs, ck):
+            assert len(o) == 8192 and sb.checksum64(o) == int(k)
         outs, sts = _decode([comp for _, comp, *_ in corpus], c)
         assert sts == [0] * len(corpus)
         for (name, comp, length, sha, exp), got in zip(corpus, outs):

@@ -8,3 +8,4 @@ for v in ${VARIANTS:-2 1}; do
   timeout 300 python bench.py --cpu-seconds 0 --no-ceiling --steps 5 --exec-variant $v --no-split 2>>gpurun_out/err_$v.log | pick "cfg4 nosplit exec_variant=$v"
 done
 tail -5 gpurun_out/err_2.log
+[ -f tmp_ab/libmzd_xbstats.so ] && MZD_LIB=$PWD/tmp_ab/libmzd_xbstats.so timeout 300 python tools/xb_stats.py 16384 2>&1 | grep -v amdgpu.ids

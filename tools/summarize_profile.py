@@ -6,7 +6,7 @@ gpurun_out/<tag>_cfg<N>_{stats,fetch,write} into
                                              the hash of the device sources and the workload they were measured on
                                              (bench.py quotes the file only when both match its own run).
 usage: summarize_profile.py <tag> <config> <launched steps incl. warmup> "<profiled command>" """
-import collections, csv, glob, json, os, re, sys
+import collections, csv, datetime, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_src_sha16  # noqa: E402
@@ -43,9 +43,15 @@ fetch, calls = per_kernel("fetch")
 write, _ = per_kernel("write")
 if fetch is not None and write is not None:
     frames = {2: 4096, 3: 4096, 4: 65536}.get(cfg)
-    m = re.search(r"--frames-per-gpu (\d+)", cmd)
+    m = re.search(r"--frames(?:-per-gpu)? (\d+)", cmd)
     if m:
         frames = int(m.group(1))
+    m = re.search(r"--frame-bytes (\d+)", cmd)
+    frame_bytes = int(m.group(1)) if m else 131072
+    m = re.search(r"--workload (\w+)", cmd)
+    workload = m.group(1) if m else "synthetic"
+    m = re.search(r"--corpus-gib ([\d.]+)", cmd)
+    corpus_gib = float(m.group(1)) if m else 4.0
     kern = {}
     for k in sorted(set(fetch) | set(write)):
         if k in ("k_fse_build", "k_huf_build", "k_parse", "k_copy_ceiling"):
@@ -60,8 +66,9 @@ if fetch is not None and write is not None:
                 "streaming reads by 2x and is uncalibrated for other access widths; Infinity-Cache hits are included. bytes = KB * "
                 "1024; fetch_bytes_x2 applies the guide's streaming correction as an upper bound.",
         "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- {cmd}",
-        "round": 2, "build": tag, "kernel_src_sha16": kernel_src_sha16(), "config": cfg, "frames_per_gpu": frames,
-        "frame_bytes": 131072, "kernels": kern,
+        "measured": {"by": "the builder (tools/profile_round.sh inside a gpurun call)", "date": datetime.date.today().isoformat()},
+        "build": tag, "kernel_src_sha16": kernel_src_sha16(), "config": cfg, "workload": workload, "corpus_gib": corpus_gib, "frames_per_gpu": frames,
+        "frame_bytes": frame_bytes, "kernels": kern,
     }
     json.dump(out, open(os.path.join(go, f"{tag}_traffic_cfg{cfg}.json"), "w"), indent=1)
     print(json.dumps(kern))

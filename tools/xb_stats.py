@@ -17,10 +17,11 @@ L.mzd_debug_xb_stats(buf, 1)
 outs, sts = z.decode_frames(frames, ctx)
 assert all(s == 0 for s in sts)
 L.mzd_debug_xb_stats(buf, 0)
-names = ["tiles", "fast tiles", "fast passes", "general passes", "fast passes with in-pass bytes", "fast passes that went to memory",
-         "staged matches", "matches", "cycles fast-tile setup", "cycles fast passes", "cycles general tiles", "cycles total", "frames"]
+names = ["tiles", "stretches", "plain passes", "generic passes", "passes with in-pass bytes", "passes that went to memory",
+         "staged matches", "matches", "cycles tile setup", "cycles stretch setup", "cycles passes", "cycles total", "frames"]
 t = max(buf[0], 1)
 for i, nm in enumerate(names):
     print(f"{nm:34s} {buf[i]:14d}  per tile {buf[i] / t:10.3f}")
-print("cycles per fast pass", buf[9] / max(buf[2], 1), " setup per fast tile", buf[8] / max(buf[1], 1),
-      " per general pass", buf[10] / max(buf[3], 1), " other per tile", (buf[11] - buf[8] - buf[9] - buf[10]) / t)
+np_ = max(buf[2] + buf[3], 1)
+print("cycles per pass", buf[10] / np_, " per stretch setup", buf[9] / max(buf[1], 1), " per tile setup", buf[8] / t,
+      " other per tile", (buf[11] - buf[8] - buf[9] - buf[10]) / t)
