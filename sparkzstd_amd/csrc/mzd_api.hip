@@ -48,8 +48,10 @@ struct ParseTemps {
     uint32_t *d_fse_src = nullptr;
     mzd::HufBuildDesc *d_huf_tabs = nullptr;
     uint16_t *d_huf_src = nullptr;
+    uint32_t *d_keys = nullptr, *d_perm = nullptr;  // ordering of heterogeneous work lists: keys out, permutation in
+    uint8_t *d_sorted = nullptr;                    // the list being gathered
     size_t cap_foff = 0, cap_flen = 0, cap_scratch = 0, cap_counts = 0, cap_bases = 0, cap_fse_tabs = 0, cap_fse_src = 0,
-           cap_huf_tabs = 0, cap_huf_src = 0;
+           cap_huf_tabs = 0, cap_huf_src = 0, cap_keys = 0, cap_perm = 0, cap_sorted = 0;
 };
 static void free_parse_temps(ParseTemps &t)
 {
@@ -62,9 +64,13 @@ static void free_parse_temps(ParseTemps &t)
     (void)hipFree(t.d_fse_src);
     (void)hipFree(t.d_huf_tabs);
     (void)hipFree(t.d_huf_src);
+    (void)hipFree(t.d_keys);
+    (void)hipFree(t.d_perm);
+    (void)hipFree(t.d_sorted);
     t = ParseTemps();
 }
 struct DevCaps {  // bytes allocated behind the pointers of a recycled batch (0 = exact / unknown)
+    size_t frame_order = 0;
     size_t in = 0, out = 0, frames = 0, blocks = 0, sums = 0, huf_tasks = 0, seq_tasks = 0, fse = 0, huf = 0, recs = 0, tiles = 0,
            lit = 0, status = 0, out_len = 0;
 };
@@ -148,6 +154,77 @@ inline const char *exp_env(const char *name) { return getenv(name); }
 #else
 constexpr const char *exp_env(const char *) { return nullptr; }
 #endif
+
+
+// ---- heterogeneous work lists are ordered by size (see mzd_dbatch): chains of one workgroup run until the longest is done,
+// the 64 Huffman streams of a wavefront until the longest is done, a frame is one serial job of the execution stage.
+struct ListOrder {
+    std::vector<uint32_t> seq_perm, huf_perm, frame_order;  // empty: leave the list in frame order
+    uint32_t huf_class_end[3] = {0, 0, 0};
+};
+// seq_nseq[i]: sequences of chain i; huf_key[q]: MaxBits << 24 | longest stream of quad q (capped); frame_cap[f]: output bound
+void plan_order(const uint32_t *seq_nseq, size_t ns, const uint32_t *huf_key, size_t nq, const uint64_t *frame_cap, size_t nf,
+                uint64_t in_size, ListOrder &o)
+{
+    uint64_t sum = 0;
+    uint32_t mx = 0;
+    for (size_t i = 0; i < ns; i++) { sum += seq_nseq[i]; mx = std::max(mx, seq_nseq[i]); }
+    // (the sorted list is decoded in ONE launch that addresses the bitstreams with 32-bit offsets from the blob's start)
+    if (ns > 64 && (uint64_t)mx * ns >= 2 * sum && in_size < (1ull << 32) - 2 * MZD_IN_PAD - 4096) {
+        o.seq_perm.resize(ns);
+        for (size_t i = 0; i < ns; i++) o.seq_perm[i] = (uint32_t)i;
+        std::stable_sort(o.seq_perm.begin(), o.seq_perm.end(), [&](uint32_t x, uint32_t y) { return seq_nseq[x] > seq_nseq[y]; });
+    }
+    uint64_t hsum = 0;
+    uint32_t hmx = 0, bits_lo = 99, bits_hi = 0;
+    std::vector<uint64_t> key(nq);  // class << 40 | (0xFFFFFF - longest stream of the quad): ascending
+    for (size_t q = 0; q < nq; q++) {
+        const uint32_t longest = huf_key[q] & 0xFFFFFFu, mb = huf_key[q] >> 24;
+        hsum += longest;
+        hmx = std::max(hmx, longest);
+        bits_lo = std::min(bits_lo, mb);
+        bits_hi = std::max(bits_hi, mb);
+        const uint64_t cls = mb <= 5 ? 0 : (mb <= 8 ? 1 : 2);
+        key[q] = (cls << 40) | (uint64_t)(0xFFFFFFu - longest);
+    }
+    if (nq > 64 && ((uint64_t)hmx * nq >= 2 * hsum || (bits_lo <= 8 && bits_hi > 8) || (bits_lo <= 5 && bits_hi > 5))) {
+        o.huf_perm.resize(nq);
+        for (size_t q = 0; q < nq; q++) o.huf_perm[q] = (uint32_t)q;
+        std::stable_sort(o.huf_perm.begin(), o.huf_perm.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+        for (size_t q = 0; q < nq; q++) o.huf_class_end[key[o.huf_perm[q]] >> 40] = (uint32_t)q + 1;
+        for (int c = 1; c < 3; c++) o.huf_class_end[c] = std::max(o.huf_class_end[c], o.huf_class_end[c - 1]);
+    }
+    uint64_t csum = 0, cmx = 0;
+    for (size_t f = 0; f < nf; f++) { csum += frame_cap[f]; cmx = std::max(cmx, frame_cap[f]); }
+    if (nf > 64 && cmx * nf >= 2 * csum) {
+        o.frame_order.resize(nf);
+        for (size_t f = 0; f < nf; f++) o.frame_order[f] = (uint32_t)f;
+        std::stable_sort(o.frame_order.begin(), o.frame_order.end(), [&](uint32_t x, uint32_t y) { return frame_cap[x] > frame_cap[y]; });
+    }
+}
+inline uint32_t huf_quad_key(const HufTask *q4)
+{
+    uint32_t longest = 0, mb = 1;
+    for (int k = 0; k < 4; k++) { longest = std::max(longest, q4[k].out_size); mb = std::max(mb, q4[k].max_bits); }
+    return (mb << 24) | std::min(longest, 0xFFFFFFu);
+}
+// the same keys from work lists that were written on the device (k_parse), and the reordering itself
+__global__ void k_task_keys(const SeqTask *st, uint32_t ns, const HufTask *ht, uint32_t nq, uint32_t *ks, uint32_t *kh)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ns) ks[i] = st[i].n_seq;
+    if (i < nq) {
+        uint32_t longest = 0, mb = 1;
+        for (int k = 0; k < 4; k++) { longest = max(longest, ht[4 * (size_t)i + k].out_size); mb = max(mb, ht[4 * (size_t)i + k].max_bits); }
+        kh[i] = (mb << 24) | min(longest, 0xFFFFFFu);
+    }
+}
+template <class T>
+__global__ void k_gather(const T *src, T *dst, const uint32_t *perm, uint32_t n, uint32_t group)  // dst[i][k] = src[perm[i]][k]
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * group) dst[i] = src[(size_t)perm[i / group] * group + i % group];
+}
 
 const int kMaxSym[3] = {35, 31, 52};  // LL, OF, ML (predefined.go table lengths - 1)
 const int kMaxLog[3] = {9, 8, 9};
@@ -531,55 +608,29 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     }
     frame_seq_task[b->n_frames] = (uint32_t)seq_tasks.size();
     // ---- heterogeneous work lists are ordered by size (see mzd_dbatch)
-    bool seq_sorted = false, huf_sorted = false;
-    uint32_t huf_class_end[3] = {0, 0, 0};
-    std::vector<uint32_t> frame_order;
+    ListOrder order;
     {
-        uint64_t sum = 0;
-        uint32_t mx = 0;
-        for (const SeqTask &t : seq_tasks) { sum += t.n_seq; mx = std::max(mx, t.n_seq); }
-        // (the sorted list is decoded in ONE launch that addresses the bitstreams with 32-bit offsets from the blob's start)
-        if (seq_tasks.size() > 64 && (uint64_t)mx * seq_tasks.size() >= 2 * sum && b->in_size < (1ull << 32) - 2 * MZD_IN_PAD - 4096) {
-            std::stable_sort(seq_tasks.begin(), seq_tasks.end(), [](const SeqTask &x, const SeqTask &y) { return x.n_seq > y.n_seq; });
-            seq_sorted = true;
+        std::vector<uint32_t> ks(seq_tasks.size()), kh(huf_tasks.size() / 4);
+        std::vector<uint64_t> caps(b->n_frames);
+        for (size_t i = 0; i < ks.size(); i++) ks[i] = seq_tasks[i].n_seq;
+        for (size_t q = 0; q < kh.size(); q++) kh[q] = huf_quad_key(&huf_tasks[4 * q]);
+        for (uint32_t f = 0; f < b->n_frames; f++) caps[f] = b->frames[f].out_capacity;
+        plan_order(ks.data(), ks.size(), kh.data(), kh.size(), caps.data(), caps.size(), b->in_size, order);
+        if (!order.seq_perm.empty()) {
+            std::vector<SeqTask> sorted(seq_tasks.size());
+            for (size_t i = 0; i < sorted.size(); i++) sorted[i] = seq_tasks[order.seq_perm[i]];
+            seq_tasks.swap(sorted);
         }
-        const size_t nq = huf_tasks.size() / 4;
-        uint64_t hsum = 0;
-        uint32_t hmx = 0, bits_lo = 99, bits_hi = 0;
-        std::vector<uint64_t> key(nq);  // class << 40 | (0xFFFFFFFF - longest stream of the quad) << 8 ... ascending sort
-        for (size_t q = 0; q < nq; q++) {
-            uint32_t longest = 0, mb = 1;
-            for (int k = 0; k < 4; k++) { longest = std::max(longest, huf_tasks[4 * q + k].out_size); mb = std::max(mb, huf_tasks[4 * q + k].max_bits); }
-            hsum += longest;
-            hmx = std::max(hmx, longest);
-            bits_lo = std::min(bits_lo, mb);
-            bits_hi = std::max(bits_hi, mb);
-            const uint64_t cls = mb <= 5 ? 0 : (mb <= 8 ? 1 : 2);
-            key[q] = (cls << 40) | ((uint64_t)(0xFFFFFFFFu - longest) << 8);
-        }
-        if (nq > 64 && ((uint64_t)hmx * nq >= 2 * hsum || (bits_lo <= 8 && bits_hi > 8) || (bits_lo <= 5 && bits_hi > 5))) {
-            std::vector<uint32_t> idx(nq);
-            for (size_t q = 0; q < nq; q++) idx[q] = (uint32_t)q;
-            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+        if (!order.huf_perm.empty()) {
             std::vector<HufTask> sorted(huf_tasks.size());
-            for (size_t q = 0; q < nq; q++) {
-                for (int k = 0; k < 4; k++) sorted[4 * q + k] = huf_tasks[4 * (size_t)idx[q] + k];
-                huf_class_end[key[idx[q]] >> 40] = (uint32_t)q + 1;
-            }
-            for (int c = 1; c < 3; c++) huf_class_end[c] = std::max(huf_class_end[c], huf_class_end[c - 1]);
+            for (size_t q = 0; q < order.huf_perm.size(); q++)
+                for (int k = 0; k < 4; k++) sorted[4 * q + k] = huf_tasks[4 * (size_t)order.huf_perm[q] + k];
             huf_tasks.swap(sorted);
-            huf_sorted = true;
-        }
-        // frames: the largest first (a frame is one workgroup / wavefront of the execution stage from start to end)
-        uint64_t csum = 0, cmx = 0;
-        for (uint32_t f = 0; f < b->n_frames; f++) { csum += b->frames[f].out_capacity; cmx = std::max<uint64_t>(cmx, b->frames[f].out_capacity); }
-        if (b->n_frames > 64 && cmx * b->n_frames >= 2 * csum) {
-            frame_order.resize(b->n_frames);
-            for (uint32_t f = 0; f < b->n_frames; f++) frame_order[f] = f;
-            std::stable_sort(frame_order.begin(), frame_order.end(),
-                             [&](uint32_t x, uint32_t y) { return b->frames[x].out_capacity > b->frames[y].out_capacity; });
         }
     }
+    const bool seq_sorted = !order.seq_perm.empty(), huf_sorted = !order.huf_perm.empty();
+    const uint32_t *huf_class_end = order.huf_class_end;
+    std::vector<uint32_t> &frame_order = order.frame_order;
     st.table_bytes = (uint64_t)b->n_fse_entries * 4 + (uint64_t)b->n_huf_entries * 2;
     st.scratch_bytes = rec_total * 8 + tile_total * 8 + lit_total;
 
@@ -978,6 +1029,51 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     if (n_huf_tab)
         k_huf_build<<<(uint32_t)((n_huf_tab + 63) / 64), 64, 0, s>>>(tp.d_huf_tabs, (uint32_t)n_huf_tab, tp.d_huf_src, db->d_huf_entries);
     HIP_OR_FAIL(hipGetLastError());
+    // ---- heterogeneous work lists are ordered by size (see mzd_dbatch): the keys come back from the device, the lists are
+    // gathered there
+    db->seq_sorted = db->huf_sorted = false;
+    bool have_order = false;
+    if (n_seq > 64 || n_hufb > 64 || n_frames > 64) {
+        const uint32_t ns = (uint32_t)n_seq, nq = (uint32_t)n_hufb, nk = std::max(ns, nq);
+        std::vector<uint32_t> keys((size_t)ns + nq);
+        if (nk) {
+            ENSURE(tp.d_keys, tp.cap_keys, ((size_t)ns + nq) * 4);
+            k_task_keys<<<(nk + 255) / 256, 256, 0, s>>>(db->d_seq_tasks, ns, db->d_huf_tasks, nq, tp.d_keys, tp.d_keys + ns);
+            HIP_OR_FAIL(hipMemcpyAsync(keys.data(), tp.d_keys, keys.size() * 4, hipMemcpyDeviceToHost, s));
+            HIP_OR_FAIL(hipStreamSynchronize(s));
+        }
+        ListOrder order;
+        plan_order(keys.data(), ns, keys.data() + ns, nq, db->frame_out_cap.data(), n_frames, in_size, order);
+        ENSURE(tp.d_perm, tp.cap_perm, (size_t)std::max<uint32_t>(nk, 1) * 4);
+        if (!order.seq_perm.empty()) {
+            ENSURE(tp.d_sorted, tp.cap_sorted, (size_t)ns * sizeof(SeqTask));
+            HIP_OR_FAIL(hipMemcpyAsync(tp.d_perm, order.seq_perm.data(), (size_t)ns * 4, hipMemcpyHostToDevice, s));
+            k_gather<SeqTask><<<(ns + 255) / 256, 256, 0, s>>>(db->d_seq_tasks, (SeqTask *)tp.d_sorted, tp.d_perm, ns, 1u);
+            HIP_OR_FAIL(hipMemcpyAsync(db->d_seq_tasks, tp.d_sorted, (size_t)ns * sizeof(SeqTask), hipMemcpyDeviceToDevice, s));
+            HIP_OR_FAIL(hipStreamSynchronize(s));  // (the host permutation array is reused below)
+            db->seq_sorted = true;
+        }
+        if (!order.huf_perm.empty()) {
+            ENSURE(tp.d_sorted, tp.cap_sorted, (size_t)nq * 4 * sizeof(HufTask));
+            HIP_OR_FAIL(hipMemcpyAsync(tp.d_perm, order.huf_perm.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+            k_gather<HufTask><<<(4 * nq + 255) / 256, 256, 0, s>>>(db->d_huf_tasks, (HufTask *)tp.d_sorted, tp.d_perm, nq, 4u);
+            HIP_OR_FAIL(hipMemcpyAsync(db->d_huf_tasks, tp.d_sorted, (size_t)nq * 4 * sizeof(HufTask), hipMemcpyDeviceToDevice, s));
+            HIP_OR_FAIL(hipStreamSynchronize(s));
+            db->huf_sorted = true;
+            for (int c = 0; c < 3; c++) db->huf_class_end[c] = order.huf_class_end[c];
+        }
+        if (!order.frame_order.empty()) {
+            ENSURE(db->d_frame_order, db->cap.frame_order, (size_t)n_frames * 4);
+            HIP_OR_FAIL(hipMemcpyAsync(db->d_frame_order, order.frame_order.data(), (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+            HIP_OR_FAIL(hipStreamSynchronize(s));
+            have_order = true;
+        }
+    }
+    if (!have_order && db->d_frame_order) {  // a recycled slot whose previous batch had an order
+        (void)hipFree(db->d_frame_order);
+        db->d_frame_order = nullptr;
+        db->cap.frame_order = 0;
+    }
     HIP_OR_FAIL(hipStreamSynchronize(s));
     float a = 0, b2 = 0, c2 = 0;
     (void)hipEventElapsedTime(&a, t0, t1);
@@ -1336,10 +1432,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
     };
     const bool no_exec = exp_env("MZD_DEBUG_SEQ_ONLY") != nullptr;  // debugging: entropy stages only (records via mzd_batch_debug_read)
-    // Which execution kernel: k_exec_b (a wavefront per frame, a lane per output byte) for batches with sequences to
-    // execute; k_exec (a workgroup per frame) for pure Raw / RLE / literal-only batches, whose work is wide copies, and
-    // for frames of 4 GiB and more (k_exec_b keeps frame positions in 32 bits).
-    bool exec_b = ctx->opt.exec_variant == 2;  // (0 = k_exec until k_exec_b is the faster one on the bench batch)
+    // Which execution kernel: k_exec (a workgroup of two wavefronts per frame, a lane per sequence) for batches of frames of one
+    // size, pure Raw / RLE / literal-only batches (wide copies) and frames of 4 GiB and more (k_exec_b keeps frame positions in
+    // 32 bits); k_exec_b (a wavefront per frame, a lane per output byte) for heterogeneous batches, where a large frame is a
+    // long serial job and twice as many frames are in flight.
+    // measured (round 3): the 65 536 text-like 128 KiB frames k_exec 10.9 ms, k_exec_b 11.7 ms; the reference's corpus
+    // replicated to 4 GiB (frames of 0 to 1 MiB, executed largest first) k_exec 10.1 ms, k_exec_b 9.3 ms
+    bool exec_b = ctx->opt.exec_variant == 2 || (ctx->opt.exec_variant == 0 && db->d_frame_order != nullptr && db->n_seq_tasks > 0);
     for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
         if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
     auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {

@@ -44,7 +44,7 @@ struct XbLds {
     uint8_t win[kXbWin];              // 0x000
     uint8_t lit[kXbLit];              // 0x800
     uint8_t stage[kXbStage];          // 0xa00
-    uint2 table[130];                 // 0xe00: [0] the run that continues from the stretch before, [1 + k] head k of the stretch
+    uint2 table[130];                 // 0xe00: [0] the run that continues from the stretch before, [1 + k] head k of the stretch, [129] spare
     uint32_t bits[kXbStretch / 32];   // heads
     uint32_t special;                 // passes with a window match the plain pass cannot serve (bit = pass of the stretch)
     uint32_t pad[3];
@@ -324,6 +324,8 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
                 if (litIn) atomicOr(&sh.bits[(lstart - P) >> 5], 1u << ((lstart - P) & 31));
                 if (mIn) atomicOr(&sh.bits[(mstart - P) >> 5], 1u << ((mstart - P) & 31));
                 // passes that hold a byte of a window match with a very small or very large offset
+                // (masked stores on purpose: 64 lanes on one LDS word serialise -- unconditional stores with a spare slot
+                // for the lanes without a head made the kernel 12 % slower)
                 const bool spec = (mIn || contM) && md.y == kXbWin - 1 && ringSpecial;
                 if (wave_any(spec)) {
                     if (spec) {
@@ -369,7 +371,14 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
                             xb_wait_vm();  // every window unit issued so far has arrived in the slab
                             if (far) val = out[s];
                         }
-                        if (wave_any(r >= 0)) val = xb_resolve_in_pass(val, r, (uint32_t)lane);
+                        if (wave_any(r >= 0)) {
+                            // nearly always one level deep: the source lane's byte is there already
+                            const uint32_t srcl = r >= 0 ? (uint32_t)r : (uint32_t)lane;
+                            const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)val);
+                            const int r2 = __builtin_amdgcn_ds_bpermute((int)(srcl << 2), r);
+                            if (!wave_any(r >= 0 && r2 >= 0)) val = r >= 0 ? v2 : val;
+                            else val = xb_resolve_in_pass(val, r, (uint32_t)lane);
+                        }
                     } else {
                         XB_STAT(2, 1);
                     }
