@@ -14,17 +14,17 @@
 //               * a table with one 8-byte entry per head, in output order: {displacement D, mask M} such that the
 //                 byte at position p of that run comes from LDS address (p + D) & M --
 //                   literal        the stretch's literals, copied from the literal buffer into LDS in one go
-//                   staged match   16 source bytes per sequence, loaded from the frame's slab into LDS by the setup:
+//                   staged match   32 source bytes per sequence, loaded from the frame's slab into LDS by the setup:
 //                                  every match whose source is final in memory.  All of a stretch's loads are in
 //                                  flight together; no pass waits for memory
-//                   window match   the last 2 KiB of output live in an LDS ring (position & 0x7ff, that is M)
+//                   window match   the last 4 KiB of output live in an LDS ring (position & 0xfff, that is M)
 //             and a pass is: read its 64 bits of the bitmap, count the heads at or below every lane (v_mbcnt), read
 //             the table entry, read the byte, store it into the window ring -- ~13 vector and 5 LDS instructions,
 //             all aligned whole-wavefront ones.  Two rare cases take a longer pass (the setup marks the passes): a
 //             window match made by its own pass (offset <= lane; resolved between the lanes by pointer jumping, six
 //             rounds at most) and a window match that is neither staged nor in the ring any more (a long far match:
 //             the pass reads the slab itself).  The ring leaves for the slab in 512-byte units.
-//             No byte-misaligned LDS access, no validity bitmap, no barrier; 4.7 KiB of LDS per frame, 32 frames per CU.
+//             No byte-misaligned LDS access, no validity bitmap, no barrier; 7.7 KiB of LDS per frame.
 //
 // Hazards are ordered by construction: a wavefront's LDS operations execute in order (a pass's reads precede its
 // store); the slab is read only below `confirmed` (window units whose stores a wait on memory has seen complete) or
@@ -33,21 +33,23 @@
 
 namespace mzd {
 
-constexpr uint32_t kXbWin = 2048;      // window ring
+constexpr uint32_t kXbWin = 4096;      // window ring (what the stage cannot serve yet -- sources younger than the last wait on memory saw -- must still be in it)
 constexpr uint32_t kXbLit = 512;       // literals of the current stretch
-constexpr uint32_t kXbStage = 1024;    // staged matches of the current tile: 16 source bytes per sequence lane
+constexpr uint32_t kXbStage = 2048;    // staged matches of the current tile: 32 source bytes per sequence lane
+constexpr uint32_t kXbStageMl = 32;    // longest match that is staged
 constexpr uint32_t kXbStretch = 1024;  // output bytes per stretch at most (16 passes; one bit each in the bitmap)
 constexpr uint32_t kXbFlush = 512;     // 64 lanes x 8 bytes leave for the slab at a time
 constexpr int kXbNear = (int)kXbWin - 64;  // a window match byte less than this far behind its pass start is read from the ring
 
 struct XbLds {
-    uint8_t win[kXbWin];              // 0x000
-    uint8_t lit[kXbLit];              // 0x800
-    uint8_t stage[kXbStage];          // 0xa00
-    uint2 table[130];                 // 0xe00: [0] the run that continues from the stretch before, [1 + k] head k of the stretch, [129] spare
+    uint8_t win[kXbWin];
+    uint8_t lit[kXbLit];
+    uint8_t stage[kXbStage];
+    uint2 table[130];                 // [0] the run that continues from the stretch before, [1 + k] head k of the stretch, [129] spare
     uint32_t bits[kXbStretch / 32];   // heads
     uint32_t special;                 // passes with a window match the plain pass cannot serve (bit = pass of the stretch)
-    uint32_t pad[3];
+    uint32_t special2;                // passes with a byte that the pass before makes
+    uint32_t pad[2];
 };
 static_assert(offsetof(XbLds, lit) == kXbWin && offsetof(XbLds, table) % 8 == 0 && offsetof(XbLds, bits) % 8 == 0 && sizeof(XbLds) % 16 == 0,
               "alignment of the LDS areas");
@@ -67,30 +69,30 @@ __device__ unsigned long long g_xb_stats[16];
 
 __device__ __forceinline__ void xb_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// bytes [flushed, upto) of the frame leave the window for the slab, byte by byte (block ends, unaligned remainders)
-__device__ __forceinline__ void xb_flush_bytes(XbLds &sh, uint8_t *out, uint32_t &flushed, uint32_t upto, int lane)
+// bytes [flushed, upto) of the frame leave the window for the slab, byte by byte (block ends, unaligned remainders).
+// (`flushed` and the like travel by value: a variable whose address an outlined function takes lives in scratch memory, and
+// every reload of it waits for ALL of the wavefront's memory operations -- the prefetched ones included)
+__device__ __noinline__ uint32_t xb_flush_bytes(XbLds &sh, uint8_t *out, uint32_t flushed, uint32_t upto, int lane)
 {
     for (uint32_t x = flushed + (uint32_t)lane; x < upto; x += 64) out[x] = sh.win[x & (kXbWin - 1)];
-    flushed = upto;
+    return upto;
 }
 
-// the 512-byte unit at `flushed` (or the bytes up to the next unit boundary) leaves for the slab
-__device__ __forceinline__ void xb_flush_step(XbLds &sh, uint8_t *out, uint32_t &flushed, int lane)
+// the 512-byte unit at `flushed` (or the bytes up to the next unit boundary) leaves for the slab; -> the new `flushed`
+__device__ __forceinline__ uint32_t xb_flush_step(XbLds &sh, uint8_t *out, uint32_t flushed, int lane)
 {
     if ((flushed & (kXbFlush - 1)) == 0) {
         const uint32_t x = flushed + 8u * (uint32_t)lane;
         const uint64_t v = *(const uint64_t *)&sh.win[x & (kXbWin - 1)];
         ((U64U *)(out + x))->v = v;
-        flushed += kXbFlush;
-    } else {
-        xb_flush_bytes(sh, out, flushed, (flushed + kXbFlush) & ~(kXbFlush - 1), lane);
+        return flushed + kXbFlush;
     }
+    return xb_flush_bytes(sh, out, flushed, (flushed + kXbFlush) & ~(kXbFlush - 1), lane);
 }
 
 // after a bulk write straight to the slab (Raw / RLE blocks, literal-only blocks): the window ring takes the last
 // bytes of the frame back from memory so that the next block's window matches find them
-__device__ __forceinline__ void xb_reload_window(XbLds &sh, const uint8_t *out, uint32_t outPos, uint32_t &flushed, uint32_t &confirmed,
-                                                 int lane)
+__device__ __noinline__ void xb_reload_window(XbLds &sh, const uint8_t *out, uint32_t outPos, int lane)
 {
     xb_wait_vm();  // the bulk stores are in memory (same CU: visible to the loads below)
     const uint32_t lo = outPos > kXbWin ? outPos - kXbWin : 0u;
@@ -98,17 +100,15 @@ __device__ __forceinline__ void xb_reload_window(XbLds &sh, const uint8_t *out, 
     const uint32_t hi4 = outPos & ~3u;
     for (uint32_t x = lo4 + 4u * (uint32_t)lane; x < hi4; x += 256) *(uint32_t *)&sh.win[x & (kXbWin - 1)] = ((const U32U *)(out + x))->v;
     for (uint32_t x = max(lo4, hi4) + (uint32_t)lane; x < outPos; x += 64) sh.win[x & (kXbWin - 1)] = out[x];
-    flushed = outPos;
-    confirmed = outPos;
 }
 
-__device__ __forceinline__ void xb_bulk_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane)
+__device__ __noinline__ void xb_bulk_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane)
 {
     const uint32_t n16 = n >> 4;
     for (uint32_t i = (uint32_t)lane; i < n16; i += 64) *(U128U *)(dst + 16 * i) = *(const U128U *)(src + 16 * i);
     for (uint32_t i = (n16 << 4) + (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
 }
-__device__ __forceinline__ void xb_bulk_fill(uint8_t *dst, uint32_t byte, uint32_t n, int lane)
+__device__ __noinline__ void xb_bulk_fill(uint8_t *dst, uint32_t byte, uint32_t n, int lane)
 {
     const uint32_t v = byte * 0x01010101u;
     const U128U f{v, v, v, v};
@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t xb_owner(uint64_t H, uint32_t sbase, uint32_
     return below - (own ? 0u : 1u);
 }
 
-__global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
+__global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
                                                   int32_t *frame_status, uint64_t *frame_out_len,
@@ -168,11 +168,11 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
     uint32_t confirmed = 0;      // [0, confirmed) has ARRIVED in the slab: a wait on memory came after its stores
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
     if (lane < (int)(kXbStretch / 32)) sh.bits[lane] = 0u;
-    if (lane == 0) sh.special = 0u;
+    if (lane == 0) sh.special = sh.special2 = 0u;
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
-    uint32_t v7ff = kXbWin - 1;
+    uint32_t vwmask = kXbWin - 1;
     uint32_t lblo = lane < 32 ? 1u << lane : 0u, lbhi = lane < 32 ? 0u : 1u << (lane - 32);
-    asm volatile("" : "+v"(v7ff), "+v"(lblo), "+v"(lbhi));
+    asm volatile("" : "+v"(vwmask), "+v"(lblo), "+v"(lbhi));
 #ifdef MZD_XB_STATS
     unsigned long long xbst[16] = {0};
     const unsigned long long xb_t0 = XB_CLOCK();
@@ -186,11 +186,12 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
                 error = MZD_ERR_DST_FULL;
                 break;
             }
-            xb_flush_bytes(sh, out, flushed, outPos, lane);
+            flushed = xb_flush_bytes(sh, out, flushed, outPos, lane);
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
-            xb_reload_window(sh, out, outPos, flushed, confirmed, lane);
+            xb_reload_window(sh, out, outPos, lane);
+            flushed = confirmed = outPos;
             continue;
         }
 
@@ -211,13 +212,14 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
         if (b.n_seq == 0) {
             // no sequences: the block IS its literals (sequence_execution.go:55-59) -- unless the Huffman stage has
             // already put them in place
-            xb_flush_bytes(sh, out, flushed, outPos, lane);
+            flushed = xb_flush_bytes(sh, out, flushed, outPos, lane);
             if (!b.pad[0]) {
                 if (litRle) xb_bulk_fill(out + outPos, lits[0], b.lit_regen, lane);
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
-            xb_reload_window(sh, out, outPos, flushed, confirmed, lane);
+            xb_reload_window(sh, out, outPos, lane);
+            flushed = confirmed = outPos;
             continue;
         }
         if (litRle) {  // RLE literals (literals.go:390-396): every literal of every stretch is this byte
@@ -226,23 +228,38 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
         }
 
         // ---- tiles of 64 sequences; the literals after the last sequence (sequence_execution.go:55-59) ride along as
-        // one more sequence without a match
+        // one more sequence without a match.  The loop is a SOFTWARE PIPELINE over stretches: the loads of the next
+        // stretch (its staged matches, its literals) are issued before the passes of the current one, so that a wavefront
+        // meets its own memory latency once per block instead of once per stretch (SQ_WAIT_ANY was 70 % of the wave cycles).
         const uint32_t rest = b.lit_regen - litTotal;
         const uint32_t nps = b.n_seq + (rest ? 1u : 0u);
         const uint32_t ntiles = (nps + 63) >> 6;
         const uint64_t *brec = recs + b.rec_off;
-        uint32_t tileStart = outPos;  // frame-relative position of the tile's first byte
-        uint32_t litRun = 0;          // literals of the block that earlier tiles consumed
-        uint64_t rec_n = (uint32_t)lane < b.n_seq ? brec[lane] : 0ull;
-        for (uint32_t t = 0; t < ntiles; t++) {
-            const unsigned long long xb_t1 = XB_CLOCK();
-            (void)xb_t1;
-            const uint64_t rec = rec_n;
+
+        // per-lane state of a tile (one sequence per lane)
+        struct Tile {
+            uint32_t LL, ML, lstart, mstart, lsrc, litD;
+            int off;
+            uint2 md;          // a match byte at position p comes from LDS offset (p + md.x) & md.y: the window ring until a stretch stages it
+            uint32_t start, E, lits, litRun;  // wave-uniform: the tile's first byte, the byte after its last, its literals, literals before it
+        };
+        // a stretch whose loads are in flight.  Two of them, used alternately (the loop body below is instantiated for both
+        // orders): a register that a load is still filling is never copied -- a copy would wait for the load on the spot
+        struct Plan {
+            uint32_t P, sEnd, la, lb;
+            uint64_t stg;      // lanes whose match goes through the stage
+            U128U sv, sv2;     // ... and its 32 source bytes
+            uint64_t lv;       // the stretch's literals, 8 per lane
+            uint64_t rec;      // the records of the tile AFTER the stretch's tile
+        };
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        auto load_recs = [&](uint32_t tile) -> uint64_t {
+            const uint32_t si = tile * 64 + (uint32_t)lane;
+            return si < b.n_seq ? brec[si] : 0ull;
+        };
+        // tile t from its records; false: an offset beyond the produced data (ringbuffer.go:206-214)
+        auto load_tile = [&](Tile &T, uint64_t rec, uint32_t t, uint32_t tileStart, uint32_t litRun) -> bool {
             const uint32_t si = t * 64 + (uint32_t)lane;
-            {
-                const uint32_t sn = si + 64;
-                rec_n = sn < b.n_seq ? brec[sn] : 0ull;
-            }
             const bool isSeq = si < b.n_seq;
             uint32_t LL = (uint32_t)rec & kRecLlMask;
             const uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;  // (0 beyond the last sequence: rec == 0)
@@ -254,150 +271,223 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
                 off = sel3(u & 3, H0, H1, H2) - (int)(u >> 2);
             }
             const uint32_t sLL = wave_incl_scan_dpp(LL), sOut = wave_incl_scan_dpp(LL + ML);
-            const uint32_t tileLits = (uint32_t)__builtin_amdgcn_readlane((int)sLL, 63);
-            const uint32_t tileOut = (uint32_t)__builtin_amdgcn_readlane((int)sOut, 63);
-            const uint32_t mstart = tileStart + sOut - ML, lstart = mstart - LL;  // frame-relative
-            const uint32_t lsrc = litRun + sLL - LL;                             // the sequence's first literal (index in the block)
-            const bool bad = isSeq && ML > 0 && (off <= 0 || (uint32_t)off > mstart);  // ringbuffer.go:206-214
-            if (wave_any(bad)) {
-                error = MZD_ERR_OFFSET;
-                break;
-            }
-            const uint32_t E = tileStart + tileOut;
-            // a match byte at position p comes from LDS offset (p + md.x) & md.y: the window ring until a stretch setup stages it
-            uint2 md = make_uint2((uint32_t)(-off), kXbWin - 1);
-            const uint32_t litD = (uint32_t)offsetof(XbLds, lit) + lsrc - lstart;  // literal byte p: LDS offset p + litD - la
-            const bool ringSpecial = off < 64 || off > kXbNear;  // (as long as the match stays a window match)
-            uint32_t la = litRun;  // literal cursor at the stretch's start
-            uint32_t P = tileStart;
-            uint32_t p = P + (uint32_t)lane;
+            T.lits = (uint32_t)__builtin_amdgcn_readlane((int)sLL, 63);
+            T.E = tileStart + (uint32_t)__builtin_amdgcn_readlane((int)sOut, 63);
+            T.start = tileStart;
+            T.litRun = litRun;
+            T.LL = LL;
+            T.ML = ML;
+            T.off = off;
+            T.mstart = tileStart + sOut - ML;  // frame-relative
+            T.lstart = T.mstart - LL;
+            T.lsrc = litRun + sLL - LL;        // the sequence's first literal (index in the block)
+            T.md = make_uint2((uint32_t)(-off), kXbWin - 1);
+            T.litD = (uint32_t)offsetof(XbLds, lit) + T.lsrc - T.lstart;  // literal byte p: LDS offset p + litD - la
             XB_STAT(0, 1);
             XB_STAT(7, __popcll(wave_ballot(isSeq && ML > 0)));
-            XB_STAT(8, XB_CLOCK() - xb_t1);
-
-            while (P < E) {
-                // ---- a stretch: setup for up to 1024 output bytes / 512 literals, then its passes
-                const unsigned long long xb_t2 = XB_CLOCK();
-                (void)xb_t2;
-                uint32_t sEnd = min(E, P + kXbStretch);
-                // literal cursor at the stretch's end: the last sequence that starts at or before it (the lanes' starts ascend;
-                // lane 0 starts at tileStart); a stretch that would need more than 512 literals ends where the 512th does
-                uint32_t lb;
-                {
-                    const int k = 63 - __builtin_clzll(wave_ballot(lstart <= sEnd));
-                    const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)lstart, k), ks = (uint32_t)__builtin_amdgcn_readlane((int)lsrc, k);
-                    const uint32_t kn = (uint32_t)__builtin_amdgcn_readlane((int)LL, k);
-                    lb = ks + min(kn, sEnd - kl);
-                }
-                if (lb - la > kXbLit) {
-                    const int k = 63 - __builtin_clzll(wave_ballot(lsrc <= la + kXbLit));  // the run that holds literal la + 512
-                    const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)lstart, k), ks = (uint32_t)__builtin_amdgcn_readlane((int)lsrc, k);
-                    sEnd = kl + (la + kXbLit - ks);
-                    lb = la + kXbLit;
-                }
-                const uint32_t sLen = sEnd - P;
-                const bool litIn = LL > 0 && lstart - P < sLen;   // the sequence's literal run / match starts in this stretch
-                const bool mIn = ML > 0 && mstart - P < sLen;
-                const bool contL = lstart < P && P < mstart;      // ... or continues from the stretch before (one lane at most)
-                const bool contM = mstart < P && P < mstart + ML;
-                // matches whose source is final in the slab: 16 source bytes into the stage, all of the stretch's loads in
-                // flight together, so that no pass has to wait for memory itself
-                // (a match not farther back than the ring reaches is served by the ring whatever pass it falls into)
-                const uint32_t q0 = mstart - (uint32_t)off;
-                const bool stg = mIn && ML <= 16 && off > kXbNear && q0 + ML <= confirmed;
-                U128U sv{0, 0, 0, 0};
-                if (stg) sv = *(const U128U *)(out + q0);
-                // the stretch's literals: [la, la + 512) of the block's literals
-                uint64_t lv = 0;
-                {
-                    const uint32_t li = la + 8u * (uint32_t)lane;
-                    if (!litRle && li < lb) lv = ((const U64U *)(lits + li))->v;  // (lb <= lit_regen)
-                }
-                // table index of the sequence's heads: 1 + the heads of the lanes below (+ its own literal head)
-                const uint64_t litMask = wave_ballot(litIn), mMask = wave_ballot(mIn);
-                const uint32_t hb = __builtin_amdgcn_mbcnt_hi((uint32_t)(litMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)litMask, 1u)) +
-                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mMask, 0u));
-                if (stg) md = make_uint2((uint32_t)offsetof(XbLds, stage) + 16u * (uint32_t)lane - mstart, 0xFFFFFFFFu);
-                const uint2 ld = make_uint2(litD - la, 0xFFFFFFFFu);
-                if (litIn || contL) sh.table[contL ? 0u : hb] = ld;
-                if (mIn || contM) sh.table[contM ? 0u : hb + (litIn ? 1u : 0u)] = md;
-                if (litIn) atomicOr(&sh.bits[(lstart - P) >> 5], 1u << ((lstart - P) & 31));
-                if (mIn) atomicOr(&sh.bits[(mstart - P) >> 5], 1u << ((mstart - P) & 31));
-                // passes that hold a byte of a window match with a very small or very large offset
-                // (masked stores on purpose: 64 lanes on one LDS word serialise -- unconditional stores with a spare slot
-                // for the lanes without a head made the kernel 12 % slower)
-                const bool spec = (mIn || contM) && md.y == kXbWin - 1 && ringSpecial;
-                if (wave_any(spec)) {
-                    if (spec) {
-                        const uint32_t f0 = (max(mstart, P) - P) >> 6, f1 = (min(mstart + ML, sEnd) - 1 - P) >> 6;
-                        atomicOr(&sh.special, (2u << f1) - (1u << f0));
-                    }
-                }
-#ifndef MZD_ABL_XB_LATE  /* ablation, timing only (wrong bytes): what the passes cost when the stretch's loads travel behind them */
-                xb_wait_vm();  // the staged bytes and the literals are here, and so is every window unit issued before
-                confirmed = flushed;
-                if (stg) *(uint4 *)&sh.stage[16 * lane] = make_uint4(sv.x, sv.y, sv.z, sv.w);
-                if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = lv;
-#else
-                confirmed = flushed;
-#endif
-                while (P - flushed >= kXbFlush) xb_flush_step(sh, out, flushed, lane);
-                uint32_t special = __builtin_amdgcn_readfirstlane((int)sh.special);
-                XB_STAT(1, 1);
-                XB_STAT(6, __popcll(wave_ballot(stg)));
-                XB_STAT(9, XB_CLOCK() - xb_t2);
-                const unsigned long long xb_t3 = XB_CLOCK();
-                (void)xb_t3;
-
-                uint32_t sbase = 1;
-                const uint64_t *hbits = (const uint64_t *)sh.bits;
-                for (uint32_t k = 0; P < sEnd; k++, P += 64, p += 64, special >>= 1) {
-                    const uint64_t H = hbits[k];
-                    const uint32_t own = xb_owner(H, sbase, lblo, lbhi);
-                    sbase = (uint32_t)__builtin_amdgcn_readlane((int)own, 63) + 1u;
-                    const uint2 e = sh.table[own];
-                    const uint32_t s = p + e.x;
-                    uint32_t val = lds[s & e.y];
-                    if (special & 1u) {
-                        // window matches of this pass: made by the pass itself (offset <= lane) or behind the ring
-                        const uint32_t n = sEnd - P;
-                        const bool act = (uint32_t)lane < n && e.y == kXbWin - 1;
-                        const int r = act ? (int)(e.x + (uint32_t)lane) : -1;  // lane - offset
-                        const bool far = act && r < -kXbNear;
-                        XB_STAT(3, 1);
-                        XB_STAT(4, wave_any(r >= 0));
-                        XB_STAT(5, wave_any(far));
-                        if (wave_any(far)) {
-                            xb_wait_vm();  // every window unit issued so far has arrived in the slab
-                            if (far) val = out[s];
-                        }
-                        if (wave_any(r >= 0)) {
-                            // nearly always one level deep: the source lane's byte is there already
-                            const uint32_t srcl = r >= 0 ? (uint32_t)r : (uint32_t)lane;
-                            const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)val);
-                            const int r2 = __builtin_amdgcn_ds_bpermute((int)(srcl << 2), r);
-                            if (!wave_any(r >= 0 && r2 >= 0)) val = r >= 0 ? v2 : val;
-                            else val = xb_resolve_in_pass(val, r, (uint32_t)lane);
-                        }
-                    } else {
-                        XB_STAT(2, 1);
-                    }
-                    sh.win[p & v7ff] = (uint8_t)val;  // (beyond the tile's end: bytes the next tile overwrites before anything reads them)
-                }
-#ifdef MZD_ABL_XB_LATE
-                xb_wait_vm();
-                if (stg) *(uint4 *)&sh.stage[16 * lane] = make_uint4(sv.x, sv.y, sv.z, sv.w);
-                if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = lv;
-#endif
-                P = sEnd;  // (a stretch cut short by its literals ends inside a pass)
-                p = P + (uint32_t)lane;
-                if (lane < (int)(kXbStretch / 64)) ((uint64_t *)sh.bits)[lane] = 0ull;  // every head of the stretch has been used
-                if (lane == 0) sh.special = 0u;
-                la = lb;
-                XB_STAT(10, XB_CLOCK() - xb_t3);
+            return !wave_any(isSeq && ML > 0 && (off <= 0 || (uint32_t)off > T.mstart));
+        };
+        // the stretch of tile T that starts at P with the literal cursor at la: its extent, and its loads on their way
+        auto plan_stretch = [&](const Tile &T, uint32_t P, uint32_t la, Plan &N) {
+            uint32_t sEnd = min(T.E, P + kXbStretch);
+            // literal cursor at the stretch's end: the last sequence that starts at or before it (the lanes' starts ascend;
+            // lane 0 starts at the tile's start); a stretch that would need more than 512 literals ends where the 512th does
+            uint32_t lb;
+            {
+                const int k = 63 - __builtin_clzll(wave_ballot(T.lstart <= sEnd));
+                const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)T.lstart, k), ks = (uint32_t)__builtin_amdgcn_readlane((int)T.lsrc, k);
+                const uint32_t kn = (uint32_t)__builtin_amdgcn_readlane((int)T.LL, k);
+                lb = ks + min(kn, sEnd - kl);
             }
-            tileStart = E;
-            litRun += tileLits;
+            if (lb - la > kXbLit) {
+                const int k = 63 - __builtin_clzll(wave_ballot(T.lsrc <= la + kXbLit));  // the run that holds literal la + 512
+                const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)T.lstart, k), ks = (uint32_t)__builtin_amdgcn_readlane((int)T.lsrc, k);
+                sEnd = kl + (la + kXbLit - ks);
+                lb = la + kXbLit;
+            }
+            N.P = uni(P);
+            N.sEnd = uni(sEnd);
+            N.la = uni(la);
+            N.lb = uni(lb);
+            // matches whose source is final in the slab: 16 source bytes into the stage, all of the stretch's loads in flight
+            // together (a match not farther back than the ring reaches is served by the ring whatever pass it falls into)
+            const bool mIn = T.ML > 0 && T.mstart - N.P < N.sEnd - N.P;
+            const uint32_t q0 = T.mstart - (uint32_t)T.off;
+            const bool stg = mIn && T.ML <= kXbStageMl && T.off > kXbNear && q0 + T.ML <= confirmed;
+            N.stg = wave_ballot(stg);
+            N.sv = N.sv2 = U128U{0, 0, 0, 0};
+#ifndef MZD_ABL_XB_NOSTAGE  /* ablation, timing only (wrong bytes): the kernel without its scattered reads of the slab */
+            if (stg) N.sv = *(const U128U *)(out + q0);
+            if (stg && T.ML > 16) N.sv2 = *(const U128U *)(out + q0 + 16);
+#endif
+            // the stretch's literals: [la, lb) of the block's literals
+            N.lv = 0;
+            const uint32_t li = N.la + 8u * (uint32_t)lane;
+            if (!litRle && li < N.lb) N.lv = ((const U64U *)(lits + li))->v;  // (lb <= lit_regen)
+        };
+
+        Tile T;
+        uint32_t t = 0;
+        // One step of the pipeline: finish the setup of stretch C (its loads were issued a step ago), plan stretch N and issue
+        // its loads, run C's passes.  -> false when C was the block's last stretch (or the block failed).
+        auto step = [&](Plan &C, Plan &N) -> bool {
+            // ---- the current stretch: everything a pass looks up goes to LDS
+            const unsigned long long xb_t2 = XB_CLOCK();
+            (void)xb_t2;
+            const uint32_t P0 = C.P, sEnd = C.sEnd, sLen = sEnd - P0, la = C.la;
+            const bool stg = (C.stg >> lane) & 1;
+            const bool litIn = T.LL > 0 && T.lstart - P0 < sLen;   // the sequence's literal run / match starts in this stretch
+            const bool mIn = T.ML > 0 && T.mstart - P0 < sLen;
+            const bool contL = T.lstart < P0 && P0 < T.mstart;     // ... or continues from the stretch before (one lane at most)
+            const bool contM = T.mstart < P0 && P0 < T.mstart + T.ML;
+            // table index of the sequence's heads: 1 + the heads of the lanes below (+ its own literal head)
+            const uint64_t litMask = wave_ballot(litIn), mMask = wave_ballot(mIn);
+            const uint32_t hb = __builtin_amdgcn_mbcnt_hi((uint32_t)(litMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)litMask, 1u)) +
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(mMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mMask, 0u));
+            if (stg) T.md = make_uint2((uint32_t)offsetof(XbLds, stage) + 32u * (uint32_t)lane - T.mstart, 0xFFFFFFFFu);
+            const uint2 ld = make_uint2(T.litD - la, 0xFFFFFFFFu);
+            if (litIn || contL) sh.table[contL ? 0u : hb] = ld;
+            if (mIn || contM) sh.table[contM ? 0u : hb + (litIn ? 1u : 0u)] = T.md;
+            if (litIn) atomicOr(&sh.bits[(T.lstart - P0) >> 5], 1u << ((T.lstart - P0) & 31));
+            if (mIn) atomicOr(&sh.bits[(T.mstart - P0) >> 5], 1u << ((T.mstart - P0) & 31));
+            // passes in which a window match needs more than the plain pass does: a byte made by the pass itself (offset <= its
+            // lane) or lying behind the ring -> `special`; a byte made by the pass before (the plain passes run in pairs whose
+            // bytes are read together) -> `special2`.  Per match: its first pass holds lanes lo0 .. hi0, the passes in between
+            // all lanes, its last pass lanes 0 .. hiL.  (masked stores on purpose: 64 lanes on one LDS word serialise)
+            const bool spec = (mIn || contM) && T.md.y == kXbWin - 1 && (T.off < 128 || T.off > kXbNear);
+            if (wave_any(spec)) {
+                if (spec) {
+                    const uint32_t a = max(T.mstart, P0) - P0, z = min(T.mstart + T.ML, sEnd) - 1 - P0;  // first and last byte, stretch-relative
+                    const uint32_t f0 = a >> 6, f1 = z >> 6, lo0 = a & 63, hiL = z & 63, hi0 = f1 > f0 ? 63u : hiL;
+                    const uint32_t off = (uint32_t)T.off;
+                    const uint32_t mF = 1u << f0, mL = f1 > f0 ? 1u << f1 : 0u, mM = f1 > f0 + 1 ? (1u << f1) - (2u << f0) : 0u;
+                    const bool far = off > (uint32_t)kXbNear;
+                    uint32_t s1 = 0, s2 = 0;
+                    if (hi0 >= off || (far && off > lo0 + (uint32_t)kXbNear)) s1 |= mF;
+                    if (off <= 63 || far) s1 |= mM;
+                    if (hiL >= off || far) s1 |= mL;
+                    if (off > lo0 && off <= hi0 + 64) s2 |= mF;
+                    if (off <= 127) s2 |= mM;
+                    if (off <= hiL + 64) s2 |= mL;
+                    atomicOr(&sh.special, s1);
+                    atomicOr(&sh.special2, s2 & ~s1);
+                }
+            }
+            xb_wait_vm();  // the staged bytes, the literals and the next tile's records are here; so is every window unit issued before
+            confirmed = uni(flushed);
+            if (stg) {
+                *(uint4 *)&sh.stage[32 * lane] = make_uint4(C.sv.x, C.sv.y, C.sv.z, C.sv.w);
+                *(uint4 *)&sh.stage[32 * lane + 16] = make_uint4(C.sv2.x, C.sv2.y, C.sv2.z, C.sv2.w);
+            }
+            if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = C.lv;
+            uint32_t special = uni(sh.special), special2 = uni(sh.special2);
+            XB_STAT(1, 1);
+            XB_STAT(6, __popcll(C.stg));
+            XB_STAT(9, XB_CLOCK() - xb_t2);
+
+            // ---- the NEXT stretch (of this tile, or the first of the next tile): planned, its loads issued
+            Tile Tn;
+            bool nextTile = false, haveNext = false;
+            if (sEnd < T.E) {
+                plan_stretch(T, sEnd, C.lb, N);
+                N.rec = C.rec;
+                haveNext = true;
+            } else if (t + 1 < ntiles) {
+                nextTile = true;
+                if (!load_tile(Tn, C.rec, t + 1, T.E, T.litRun + T.lits)) {
+                    error = MZD_ERR_OFFSET;
+                } else {
+                    plan_stretch(Tn, Tn.start, Tn.litRun, N);
+                    N.rec = load_recs(t + 2);
+                    haveNext = true;
+                }
+            }
+            // the window units that are complete leave for the slab -- AFTER the next stretch's loads: whatever waits on
+            // memory next (the step after this one) then finds loads and stores a whole stretch old
+            {
+                uint32_t fl = uni(flushed);
+                while (P0 - fl >= kXbFlush) fl = uni(xb_flush_step(sh, out, fl, lane));
+                flushed = fl;
+            }
+
+            // ---- the passes
+            const unsigned long long xb_t3 = XB_CLOCK();
+            (void)xb_t3;
+            uint32_t sbase = 1;
+            const uint64_t *hbits = (const uint64_t *)sh.bits;
+            uint32_t P = P0, p = P0 + (uint32_t)lane;
+            uint32_t k = 0;
+            // two passes at a time while neither is marked: their bitmap words, table entries and bytes are read together, so
+            // that a wavefront meets the LDS latency once per pair (the passes are a chain of three dependent LDS reads)
+            while (P + 128 <= sEnd && ((special & 3u) | (special2 & 2u)) == 0) {
+                const uint64_t Ha = hbits[k], Hb = hbits[k + 1];
+                const uint32_t owna = xb_owner(Ha, sbase, lblo, lbhi);
+                const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)owna, 63) + 1u;
+                const uint32_t ownb = xb_owner(Hb, sb, lblo, lbhi);
+                sbase = (uint32_t)__builtin_amdgcn_readlane((int)ownb, 63) + 1u;
+                const uint2 ea = sh.table[owna], eb = sh.table[ownb];
+                const uint32_t va = lds[(p + ea.x) & ea.y], vb = lds[(p + 64 + eb.x) & eb.y];
+                sh.win[p & vwmask] = (uint8_t)va;
+                sh.win[(p + 64) & vwmask] = (uint8_t)vb;
+                XB_STAT(2, 2);
+                k += 2;
+                P += 128;
+                p += 128;
+                special >>= 2;
+                special2 >>= 2;
+            }
+            for (; P < sEnd; k++, P += 64, p += 64, special >>= 1, special2 >>= 1) {
+                const uint64_t H = hbits[k];
+                const uint32_t own = xb_owner(H, sbase, lblo, lbhi);
+                sbase = (uint32_t)__builtin_amdgcn_readlane((int)own, 63) + 1u;
+                const uint2 e = sh.table[own];
+                const uint32_t s = p + e.x;
+                uint32_t val = lds[s & e.y];
+                if (special & 1u) {
+                    // window matches of this pass: made by the pass itself (offset <= lane) or behind the ring
+                    const uint32_t n = sEnd - P;
+                    const bool act = (uint32_t)lane < n && e.y == kXbWin - 1;
+                    const int r = act ? (int)(e.x + (uint32_t)lane) : -1;  // lane - offset
+                    const bool far = act && r < -kXbNear;
+                    XB_STAT(3, 1);
+                    XB_STAT(4, wave_any(r >= 0));
+                    XB_STAT(5, wave_any(far));
+                    if (wave_any(far)) {
+                        xb_wait_vm();  // every window unit issued so far has arrived in the slab
+                        if (far) val = out[s];
+                    }
+                    if (wave_any(r >= 0)) {
+                        // nearly always one level deep: the source lane's byte is there already
+                        const uint32_t srcl = r >= 0 ? (uint32_t)r : (uint32_t)lane;
+                        const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)val);
+                        const int r2 = __builtin_amdgcn_ds_bpermute((int)(srcl << 2), r);
+                        if (!wave_any(r >= 0 && r2 >= 0)) val = r >= 0 ? v2 : val;
+                        else val = xb_resolve_in_pass(val, r, (uint32_t)lane);
+                    }
+                } else {
+                    XB_STAT(2, 1);
+                }
+                sh.win[p & vwmask] = (uint8_t)val;  // (beyond the stretch's end: bytes the next stretch overwrites before anything reads them)
+            }
+            if (lane < (int)(kXbStretch / 64)) ((uint64_t *)sh.bits)[lane] = 0ull;  // every head of the stretch has been used
+            if (lane == 0) sh.special = sh.special2 = 0u;
+            XB_STAT(10, XB_CLOCK() - xb_t3);
+            if (error != MZD_OK) return false;
+            if (nextTile) {
+                T = Tn;  // (computed values only: nothing here is waiting for memory)
+                t++;
+            }
+            return haveNext;
+        };
+
+        Plan A, B;
+        if (!load_tile(T, load_recs(0), 0, outPos, 0)) {
+            error = MZD_ERR_OFFSET;
+        } else if (ntiles > 0) {
+            plan_stretch(T, T.start, 0, A);
+            A.rec = load_recs(1);
+            while (step(A, B) && step(B, A)) {
+            }
         }
         outPos += blockOut;  // (also for a block that failed on an offset: the length k_exec reports)
         if (error != MZD_OK) break;
@@ -409,7 +499,7 @@ __global__ __launch_bounds__(64, 8) void k_exec_b(const uint8_t *__restrict__ in
             H0 = n0; H1 = n1; H2 = n2;
         }
     }
-    if (error == MZD_OK) xb_flush_bytes(sh, out, flushed, outPos, lane);
+    if (error == MZD_OK) flushed = xb_flush_bytes(sh, out, flushed, outPos, lane);
 #ifdef MZD_XB_STATS
     xbst[11] = XB_CLOCK() - xb_t0;
     xbst[12] = 1;
