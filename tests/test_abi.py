@@ -65,3 +65,16 @@ def test_cpp_mirror_header_compiles():
 def test_product_does_not_link_oracle():
     so = open(_lib.LIB_PATH, "rb").read()
     assert b"orc_decode_frame" not in so and b"sparkzstd_oracle" not in so
+
+
+def test_release_library_reads_no_environment_variable():
+    """The experiment hooks of the kernels' A/B runs (MZD_EXEC_MIN_LDS, MZD_SEQ_NCH, MZD_DEBUG_SEQ_ONLY, ...) exist only in builds
+    made with -DMZD_EXPERIMENTS: the shipped libmzd.so must not change behaviour on ambient environment variables."""
+    import re
+    from sparkzstd_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"MZD_[A-Z0-9_]{3,}", blob))
+    hooks = {n for n in names if n.startswith((b"MZD_EXEC_MIN", b"MZD_EXP_", b"MZD_SEQ_NCH", b"MZD_DEBUG_SEQ", b"MZD_HUF_SEG_LDS"))}
+    assert not hooks, hooks
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparkzstd_amd", "csrc", "mzd_api.hip")).read()
+    assert "getenv(" not in src.replace("inline const char *exp_env(const char *name) { return getenv(name); }", "")

@@ -352,3 +352,18 @@ def test_bench_launches_its_own_ranks(extra):
     assert all(p["frames"] == per for p in line["per_gpu"]) and line["scaling"] == ("weak" if extra else "strong")
     assert line["config"]["rendezvous"] == "gloo" and line["config"]["frames"] == 2 * per
     assert line["value"] > 0 and all(p["algorithmic_GBs"] > 0 for p in line["per_gpu"])
+
+
+def test_bench_real_data_line_small():
+    """`bench.py --workload corpus`: the reference's own decodecorpus frames (real zstd output: every block type, table mode, window
+    size; multi-block frames), replicated at distinct addresses, every frame checked by status and length and a sample by the
+    manifest's sha256.  A heterogeneous batch: its work lists are ordered by size at upload and its frames executed largest first."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "corpus", "--corpus-gib", "0.06", "--steps", "2",
+                        "--warmup", "1", "--cpu-seconds", "0", "--no-ceiling"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["bit_exact"] is True and line["data"].startswith("real") and line["config"]["frames"] >= 500
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
