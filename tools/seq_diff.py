@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Records / tile bases / block sums of two sequence-decode variants on corpus frames, entropy stages only
-(MZD_DEBUG_SEQ_ONLY=1): first difference.  usage: MZD_DEBUG_SEQ_ONLY=1 seq_diff.py name [name...]"""
+(MZD_DEBUG_SEQ_ONLY=1, a library built with -DMZD_EXPERIMENTS selected through MZD_LIB): first difference.
+usage: MZD_LIB=tmp_ab/libmzd_exp.so MZD_DEBUG_SEQ_ONLY=1 seq_diff.py name [name...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
