@@ -112,6 +112,10 @@ struct mzd_dbatch {
     // heterogeneous batches (real data: blocks of 10 and of 40 000 sequences side by side): work lists ordered by size, so
     // that the units a workgroup / wavefront holds at a time are of similar length and the long ones start first
     bool seq_sorted = false;           // d_seq_tasks is in descending n_seq order (not in frame order: no head / tail split)
+    // ... in up to three launches: [0, seq_class_end[0]) chains of >= 2048 sequences, then >= 256, then the rest, each with the
+    // LDS slot of ITS largest tables (short chains come with small tables: less to stage, two workgroups per CU)
+    uint32_t seq_class_end[3] = {0, 0, 0};
+    uint32_t seq_class_cells[3][3] = {{512, 512, 256}, {512, 512, 256}, {512, 512, 256}};
     bool huf_sorted = false;           // d_huf_tasks' quads are grouped by table size class, longest streams first
     uint32_t huf_class_end[3] = {0, 0, 0};  // quads of class 0 (tables <= 32 cells), 1 (<= 256), 2 end here
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
@@ -161,19 +165,31 @@ constexpr const char *exp_env(const char *) { return nullptr; }
 struct ListOrder {
     std::vector<uint32_t> seq_perm, huf_perm, frame_order;  // empty: leave the list in frame order
     uint32_t huf_class_end[3] = {0, 0, 0};
+    uint32_t seq_class_end[3] = {0, 0, 0}, seq_class_logs[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // LL, ML, OF accuracy logs per class
 };
-// seq_nseq[i]: sequences of chain i; huf_key[q]: MaxBits << 24 | longest stream of quad q (capped); frame_cap[f]: output bound
+inline uint32_t seq_key(uint32_t n_seq, uint32_t ll, uint32_t ml, uint32_t of) { return std::min(n_seq, 0xFFFFFu) | (ll << 20) | (ml << 24) | (of << 28); }
+// seq_nseq[i]: seq_key() of chain i; huf_key[q]: MaxBits << 24 | longest stream of quad q (capped); frame_cap[f]: output bound
 void plan_order(const uint32_t *seq_nseq, size_t ns, const uint32_t *huf_key, size_t nq, const uint64_t *frame_cap, size_t nf,
                 uint64_t in_size, ListOrder &o)
 {
     uint64_t sum = 0;
     uint32_t mx = 0;
-    for (size_t i = 0; i < ns; i++) { sum += seq_nseq[i]; mx = std::max(mx, seq_nseq[i]); }
-    // (the sorted list is decoded in ONE launch that addresses the bitstreams with 32-bit offsets from the blob's start)
+    for (size_t i = 0; i < ns; i++) { sum += seq_nseq[i] & 0xFFFFFu; mx = std::max(mx, seq_nseq[i] & 0xFFFFFu); }
+    // (the sorted list is decoded in launches that address the bitstreams with 32-bit offsets from the blob's start)
     if (ns > 64 && (uint64_t)mx * ns >= 2 * sum && in_size < (1ull << 32) - 2 * MZD_IN_PAD - 4096) {
         o.seq_perm.resize(ns);
         for (size_t i = 0; i < ns; i++) o.seq_perm[i] = (uint32_t)i;
-        std::stable_sort(o.seq_perm.begin(), o.seq_perm.end(), [&](uint32_t x, uint32_t y) { return seq_nseq[x] > seq_nseq[y]; });
+        std::stable_sort(o.seq_perm.begin(), o.seq_perm.end(),
+                         [&](uint32_t x, uint32_t y) { return (seq_nseq[x] & 0xFFFFFu) > (seq_nseq[y] & 0xFFFFFu); });
+        for (size_t i = 0; i < ns; i++) {
+            const uint32_t k = seq_nseq[o.seq_perm[i]], n = k & 0xFFFFFu;
+            const int c = n >= 2048 ? 0 : (n >= 256 ? 1 : 2);
+            o.seq_class_end[c] = (uint32_t)i + 1;
+            o.seq_class_logs[c][0] = std::max(o.seq_class_logs[c][0], (k >> 20) & 15u);
+            o.seq_class_logs[c][1] = std::max(o.seq_class_logs[c][1], (k >> 24) & 15u);
+            o.seq_class_logs[c][2] = std::max(o.seq_class_logs[c][2], (k >> 28) & 15u);
+        }
+        for (int c = 1; c < 3; c++) o.seq_class_end[c] = std::max(o.seq_class_end[c], o.seq_class_end[c - 1]);
     }
     uint64_t hsum = 0;
     uint32_t hmx = 0, bits_lo = 99, bits_hi = 0;
@@ -212,7 +228,7 @@ inline uint32_t huf_quad_key(const HufTask *q4)
 __global__ void k_task_keys(const SeqTask *st, uint32_t ns, const HufTask *ht, uint32_t nq, uint32_t *ks, uint32_t *kh)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ns) ks[i] = st[i].n_seq;
+    if (i < ns) ks[i] = min(st[i].n_seq, 0xFFFFFu) | ((uint32_t)st[i].ll_log << 20) | ((uint32_t)st[i].ml_log << 24) | ((uint32_t)st[i].of_log << 28);
     if (i < nq) {
         uint32_t longest = 0, mb = 1;
         for (int k = 0; k < 4; k++) { longest = max(longest, ht[4 * (size_t)i + k].out_size); mb = max(mb, ht[4 * (size_t)i + k].max_bits); }
@@ -612,7 +628,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     {
         std::vector<uint32_t> ks(seq_tasks.size()), kh(huf_tasks.size() / 4);
         std::vector<uint64_t> caps(b->n_frames);
-        for (size_t i = 0; i < ks.size(); i++) ks[i] = seq_tasks[i].n_seq;
+        for (size_t i = 0; i < ks.size(); i++) ks[i] = seq_key(seq_tasks[i].n_seq, seq_tasks[i].ll_log, seq_tasks[i].ml_log, seq_tasks[i].of_log);
         for (size_t q = 0; q < kh.size(); q++) kh[q] = huf_quad_key(&huf_tasks[4 * q]);
         for (uint32_t f = 0; f < b->n_frames; f++) caps[f] = b->frames[f].out_capacity;
         plan_order(ks.data(), ks.size(), kh.data(), kh.size(), caps.data(), caps.size(), b->in_size, order);
@@ -643,6 +659,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     for (int k = 0; k < 3; k++) db->seq_cells[k] = 1u << std::min<uint32_t>(seq_logs[k], k == 2 ? 8u : 9u);
     db->huf_slot_cells = 1u << max_huf_bits;
     db->seq_sorted = seq_sorted;
+    for (int c = 0; c < 3; c++) {
+        db->seq_class_end[c] = order.seq_class_end[c];
+        for (int k = 0; k < 3; k++) db->seq_class_cells[c][k] = 1u << std::min<uint32_t>(order.seq_class_logs[c][k], k == 2 ? 8u : 9u);
+    }
     db->huf_sorted = huf_sorted;
     for (int c = 0; c < 3; c++) db->huf_class_end[c] = huf_class_end[c];
     db->frame_seq_task = std::move(frame_seq_task);
@@ -1052,6 +1072,10 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
             HIP_OR_FAIL(hipMemcpyAsync(db->d_seq_tasks, tp.d_sorted, (size_t)ns * sizeof(SeqTask), hipMemcpyDeviceToDevice, s));
             HIP_OR_FAIL(hipStreamSynchronize(s));  // (the host permutation array is reused below)
             db->seq_sorted = true;
+            for (int c = 0; c < 3; c++) {
+                db->seq_class_end[c] = order.seq_class_end[c];
+                for (int k = 0; k < 3; k++) db->seq_class_cells[c][k] = 1u << std::min<uint32_t>(order.seq_class_logs[c][k], k == 2 ? 8u : 9u);
+            }
         }
         if (!order.huf_perm.empty()) {
             ENSURE(tp.d_sorted, tp.cap_sorted, (size_t)nq * 4 * sizeof(HufTask));
@@ -1379,7 +1403,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // front slack of a WINDOW of the blob: the frames are cut into runs whose bitstreams span < 4 GiB, one launch
     // per run (one run unless the blob is that large); a single frame beyond that takes k_seq.
     auto launch_seq = [&](uint32_t f0, uint32_t f1) {
-        if (db->seq_sorted) {  // the whole list, longest chains first (its bitstreams are within 4 GiB of the blob's start)
+        if (db->seq_sorted) {
+            // the whole list in ONE launch, longest chains first (its bitstreams are within 4 GiB of the blob's start): the
+            // longest chain of real data (42 k sequences = 5.9 ms) is a floor the other workgroups fill in behind.  (A launch per
+            // length class, each with the LDS slot of its own tables -- seq_class_* -- cost 10.2 ms against 7.5: every launch has
+            // its own under-occupied tail, and the class of the long chains is less than one round.)
             launch_seq_tasks(0, db->n_seq_tasks, pipe, 0);
             return;
         }
@@ -1742,7 +1770,7 @@ int mzd_measure_copy(mzd_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, in
 {
     if (!ctx || !ms || iters < 1 || write_bytes < 16) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint64_t n_read = std::min(read_bytes, write_bytes) / 16, n_write = write_bytes / 16;
+    const uint64_t n_read = read_bytes / 16, n_write = write_bytes / 16;  // both streams in full, whichever is longer
     u32x4 *src = nullptr, *dst = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&src, std::max<uint64_t>(n_read, 1) * 16));
     hipError_t e = hipMalloc((void **)&dst, n_write * 16);
@@ -1751,7 +1779,7 @@ int mzd_measure_copy(mzd_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, in
     if (e == hipSuccess) e = hipEventCreate(&t0);
     if (e == hipSuccess) e = hipEventCreate(&t1);
     // grid: 8 workgroups of 256 threads per CU, the rest grid-stride
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_write + 255) / 256, (uint64_t)std::max(ctx->num_cus, 1) * 8);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((std::max(n_read, n_write) + 255) / 256, (uint64_t)std::max(ctx->num_cus, 1) * 8);
     if (e == hipSuccess) {
         k_copy_ceiling<<<grid, 256, 0, ctx->stream>>>(src, dst, n_read, n_write);  // warm-up
         e = hipEventRecord(t0, ctx->stream);

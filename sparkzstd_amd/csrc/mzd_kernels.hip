@@ -3041,15 +3041,16 @@ __global__ __launch_bounds__(64) void k_xxh64(const uint8_t *__restrict__ out_bl
 // ------------------------------------------------------------------------------------------
 // k_copy_ceiling: the achievable-copy ceiling the roofline fractions are quoted against next to the
 // 8 TB/s nominal peak.  Plain streaming kernel, 16 bytes per lane, grid-stride, four
-// independent loads in flight per lane: reads the first n_read 16-byte words of src once and writes
+// independent loads in flight per lane: reads the n_read 16-byte words of src once and writes
 // n_write words of dst once (words past n_read repeat the lane's last loaded value: a write-only
-// stream, like an RLE fill) -- the algorithmic bytes of a pass, C in and D out, and nothing else.
+// stream, like an RLE fill; words past n_write are only read) -- the algorithmic bytes of a pass, C in and D out, and nothing else.
 __global__ __launch_bounds__(256) void k_copy_ceiling(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst,
                                                        uint64_t n_read, uint64_t n_write)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     u32x4 v[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_write; i += 4 * stride) {
+    const uint64_t n_both = n_read > n_write ? n_read : n_write;  // (C > D, e.g. Raw blocks with headers: the extra words are only read)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_both; i += 4 * stride) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint64_t j = i + u * stride;
