@@ -18,6 +18,7 @@
 #include "mzd_kernels.hip"
 #include "mzd_seq_q4.hip"
 #include "mzd_exec_b.hip"
+#include "mzd_exec_blk.hip"
 #include "mzd_parse.hip"
 
 using namespace mzd;
@@ -119,6 +120,13 @@ struct mzd_dbatch {
     bool huf_sorted = false;           // d_huf_tasks' quads are grouped by table size class, longest streams first
     uint32_t huf_class_end[3] = {0, 0, 0};  // quads of class 0 (tables <= 32 cells), 1 (<= 256), 2 end here
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
+    // block mode of the execution stage (few large frames; mzd_exec_blk.hip): allocated by the first run that takes it
+    BJob *d_jobs = nullptr;
+    BFrame *d_bframes = nullptr;
+    uint8_t *d_planes = nullptr;  // (passes - 1) copies of the output layout
+    uint8_t *d_pat = nullptr;     // the passes' patterns, by frame-relative position
+    size_t cap_jobs = 0, cap_bframes = 0, cap_planes = 0, cap_pat = 0;
+    uint32_t pat_n = 0, pat_np = 0;  // what d_pat holds
     uint64_t out_size = 0;
     uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
     uint64_t huf_out_bytes = 0;                        // literals the Huffman stage regenerates (scratch or in place)
@@ -352,6 +360,10 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_status);
     (void)hipFree(db->d_out_len);
     (void)hipFree(db->d_frame_order);
+    (void)hipFree(db->d_jobs);
+    (void)hipFree(db->d_bframes);
+    (void)hipFree(db->d_planes);
+    (void)hipFree(db->d_pat);
     free_parse_temps(db->tmp);
     delete db;
 }
@@ -1323,7 +1335,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
-    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 2) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 3) return MZD_ERR_INVALID_ARG;
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1338,7 +1350,52 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // Heterogeneous batches (work lists ordered by size at upload, frames executed largest first) run their stages one after
     // the other on the caller's stream: the head / tail split and k_huf in the sequence stage's shadow are for batches whose
     // lists are in frame order.
-    const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr;
+    // Which execution kernel: k_exec (a workgroup of two wavefronts per frame, a lane per sequence) for batches of frames of one
+    // size, pure Raw / RLE / literal-only batches (wide copies) and frames of 4 GiB and more (k_exec_b keeps frame positions in
+    // 32 bits); k_exec_b (a wavefront per frame, a lane per output byte) for heterogeneous batches, where a large frame is a
+    // long serial job and twice as many frames are in flight.
+    // measured (round 3): the 65 536 text-like 128 KiB frames k_exec 10.9 ms, k_exec_b 11.7 ms; the reference's corpus
+    // replicated to 4 GiB (frames of 0 to 1 MiB, executed largest first) k_exec 10.1 ms, k_exec_b 9.3 ms
+    // (and batches of small frames: 131 072 frames of 4 KiB k_exec 0.98 ms, k_exec_b 0.71 ms)
+    bool exec_b = ctx->opt.exec_variant >= 2 ||
+                  (ctx->opt.exec_variant == 0 && db->n_seq_tasks > 0 &&
+                   (db->d_frame_order != nullptr || db->out_size < (uint64_t)db->n_frames * 32768));
+    for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
+        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
+    // Block mode (mzd_exec_blk.hip): every block its own job, NP passes and a fix-up walk -- for batches whose largest frame is a
+    // longer serial job than NP passes over everything.  The model: a wavefront alone makes a 128 KiB block in ~0.37 ms, the
+    // chip 5 120 of them in ~0.85 ms; a fix-up step is ~6 us.  (exec_variant 3 forces it: the parity tests.)
+    bool blk = false;
+    uint32_t blk_np = 0;
+    uint64_t blk_maxcap = 0;
+    if (db->n_seq_tasks > 0 && db->n_frames > 0 && (ctx->opt.exec_variant == 0 || ctx->opt.exec_variant == 3)) {
+        for (uint32_t f = 0; f < db->n_frames; f++) blk_maxcap = std::max<uint64_t>(blk_maxcap, db->frame_out_cap[f]);
+        blk_np = blk_maxcap <= (1u << 23) ? 3u : 4u;
+        const double chip = std::max(0.4, (double)db->out_size / kBlockMax / 5120.0 * 0.85);
+        const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.37, chip);
+        const double t_blk = blk_np * chip + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
+        blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant == 3 || t_blk < 0.7 * t_serial);
+        if (blk) exec_b = true;
+    }
+    if (blk) {
+        auto ensure = [&](auto *&ptr, size_t &cap, size_t bytes) -> hipError_t {
+            if (ptr && cap >= bytes) return hipSuccess;
+            if (ptr) (void)hipFree((void *)ptr);
+            ptr = nullptr;
+            cap = 0;
+            const hipError_t e = hipMalloc((void **)&ptr, bytes);
+            if (e == hipSuccess) cap = bytes;
+            return e;
+        };
+        const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
+        const size_t pat_before = db->cap_pat;
+        HIP_TRY(ctx, ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)));
+        HIP_TRY(ctx, ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)));
+        HIP_TRY(ctx, ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256));
+        HIP_TRY(ctx, ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride));
+        if (db->cap_pat != pat_before) db->pat_n = db->pat_np = 0;
+    }
+    const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
     const bool huf_first = serial || ctx->opt.huf_variant == 3 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
                             db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !exp_env("MZD_EXP_HUF_BESIDE"));
@@ -1460,25 +1517,37 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
     };
     const bool no_exec = exp_env("MZD_DEBUG_SEQ_ONLY") != nullptr;  // debugging: entropy stages only (records via mzd_batch_debug_read)
-    // Which execution kernel: k_exec (a workgroup of two wavefronts per frame, a lane per sequence) for batches of frames of one
-    // size, pure Raw / RLE / literal-only batches (wide copies) and frames of 4 GiB and more (k_exec_b keeps frame positions in
-    // 32 bits); k_exec_b (a wavefront per frame, a lane per output byte) for heterogeneous batches, where a large frame is a
-    // long serial job and twice as many frames are in flight.
-    // measured (round 3): the 65 536 text-like 128 KiB frames k_exec 10.9 ms, k_exec_b 11.7 ms; the reference's corpus
-    // replicated to 4 GiB (frames of 0 to 1 MiB, executed largest first) k_exec 10.1 ms, k_exec_b 9.3 ms
-    // (and batches of small frames: 131 072 frames of 4 KiB k_exec 0.98 ms, k_exec_b 0.71 ms)
-    bool exec_b = ctx->opt.exec_variant == 2 ||
-                  (ctx->opt.exec_variant == 0 && db->n_seq_tasks > 0 &&
-                   (db->d_frame_order != nullptr || db->out_size < (uint64_t)db->n_frames * 32768));
-    for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
-        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
     auto launch_exec = [&](hipStream_t st, uint32_t first, uint32_t count) {
         if (!count || no_exec) return;
         // frames in the order of d_frame_order when the batch has one (largest first), else in batch order
+        if (blk) {
+            // (the whole batch: block mode never splits)
+            const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
+            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes);
+            if (db->pat_n != (uint32_t)(blk_maxcap + 64) || db->pat_np != blk_np) {
+                k_blk_pattern<<<(uint32_t)((blk_maxcap + 64 + 1023) / 1024), 256, 0, st>>>(db->d_pat, pstride, (uint32_t)(blk_maxcap + 64), blk_np);
+                db->pat_n = (uint32_t)(blk_maxcap + 64);
+                db->pat_np = blk_np;
+            }
+            for (uint32_t p = 0; p < blk_np; p++)
+                k_exec_b<true><<<db->n_blocks, 64, ctx->opt.exec_chunk, st>>>(
+                    db->d_in, p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                    db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, XbBlk{db->d_jobs, db->d_bframes, db->d_pat + (size_t)p * pstride, p});
+            // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
+            const uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(32u, 1024u / db->n_frames);
+            if (blk_np == 3)
+                k_blk_fixup<3><<<db->n_frames * G, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
+                                                               db->d_bframes, G);
+            else
+                k_blk_fixup<4><<<db->n_frames * G, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
+                                                               db->d_frames, db->d_jobs, db->d_bframes, G);
+            k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
+            return;
+        }
         if (exec_b) {
             // (opt.exec_chunk: extra dynamic LDS per frame = a residency cap; frames in flight vs cache footprint of their slabs)
-            k_exec_b<<<count, 64, ctx->opt.exec_chunk, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
-                                                            db->d_litbuf, db->d_status, db->d_out_len, db->d_frame_order, first);
+            k_exec_b<false><<<count, 64, ctx->opt.exec_chunk, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                                                                   db->d_litbuf, db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
         k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,

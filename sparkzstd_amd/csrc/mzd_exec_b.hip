@@ -148,27 +148,58 @@ __device__ __forceinline__ uint32_t xb_owner(uint64_t H, uint32_t sbase, uint32_
     return below - (own ? 0u : 1u);
 }
 
+// BM (block mode, mzd_exec_blk.hip): the wavefront's job is ONE block (`first + blockIdx.x` of the batch's blocks, `out_blob`
+// the plane of this pass); whatever lies before the block's start S is read from the pass's pattern `bk.pat` instead of the
+// slab -- the ring is preloaded with it, staged and far reads below S go to it.
+struct XbBlk {
+    const BJob *jobs;
+    BFrame *bframes;
+    const uint8_t *pat;  // indexed by the frame-relative position
+    uint32_t pass;
+};
+
+template <bool BM>
 __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
                                                   int32_t *frame_status, uint64_t *frame_out_len,
-                                                  const uint32_t *__restrict__ order, uint32_t first)
+                                                  const uint32_t *__restrict__ order, uint32_t first, XbBlk bk)
 {
     __shared__ __attribute__((aligned(16))) XbLds sh;
     const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
     // this wavefront's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)
-    const uint32_t fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    uint32_t fidx, bi0 = 0;
+    BJob jb{};
+    if (BM) {
+        jb = bk.jobs[first + blockIdx.x];
+        fidx = jb.frame;
+    } else {
+        fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    }
     const DFrame fr = frames[fidx];
     uint8_t *out = out_blob + fr.out_offset;
+    if (BM) {
+        bi0 = first + blockIdx.x - fr.first_block;
+        // the passes after the first are for blocks that can derive bytes from earlier ones
+        if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (jb.flags & kBjDirect)))) return;
+    }
+    const uint32_t S = BM ? jb.start : 0u;  // the block's first byte (block mode)
+    const uint8_t *const pat = bk.pat;
 
-    int error = fr.plan_status;
-    uint32_t outPos = 0;         // bytes of this frame produced so far (frames of 4 GiB and more take k_exec)
-    uint32_t flushed = 0;        // [0, flushed) has left for the slab (the youngest units may still be in flight)
-    uint32_t confirmed = 0;      // [0, confirmed) has ARRIVED in the slab: a wait on memory came after its stores
+    int error = BM ? (int)MZD_OK : fr.plan_status;
+    uint32_t outPos = S;         // bytes of this frame produced so far (frames of 4 GiB and more take k_exec)
+    uint32_t flushed = S;        // [0, flushed) has left for the slab (the youngest units may still be in flight)
+    uint32_t confirmed = S;      // [0, confirmed) has ARRIVED in the slab: a wait on memory came after its stores
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
+    if (BM) {
+        H0 = jb.H0;
+        H1 = jb.H1;
+        H2 = jb.H2;
+    }
     if (lane < (int)(kXbStretch / 32)) sh.bits[lane] = 0u;
     if (lane == 0) sh.special = sh.special2 = 0u;
+    if (BM && S > 0 && !(jb.flags & kBjDirect)) xb_reload_window(sh, pat, S, lane);  // the ring's view of the frame before the block
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
     uint32_t vwmask = kXbWin - 1;
     uint32_t lblo = lane < 32 ? 1u << lane : 0u, lbhi = lane < 32 ? 0u : 1u << (lane - 32);
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     const unsigned long long xb_t0 = XB_CLOCK();
 #endif
 
-    for (uint32_t bi = 0; bi < fr.n_blocks && error == MZD_OK; bi++) {
+    for (uint32_t bi = bi0; bi < (BM ? bi0 + 1 : fr.n_blocks) && error == MZD_OK; bi++) {
         const DBlock b = blocks[fr.first_block + bi];
         if (b.type != MZD_BLOCK_COMPRESSED) {
             // Raw (framedecompressor.go:211-215) / RLE (:229-241): straight copy / fill
@@ -190,7 +221,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
-            xb_reload_window(sh, out, outPos, lane);
+            if (!BM) xb_reload_window(sh, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
-            xb_reload_window(sh, out, outPos, lane);
+            if (!BM) xb_reload_window(sh, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -313,12 +344,14 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
             // together (a match not farther back than the ring reaches is served by the ring whatever pass it falls into)
             const bool mIn = T.ML > 0 && T.mstart - N.P < N.sEnd - N.P;
             const uint32_t q0 = T.mstart - (uint32_t)T.off;
-            const bool stg = mIn && T.ML <= kXbStageMl && T.off > kXbNear && q0 + T.ML <= confirmed;
+            // (block mode: a source that straddles the block's start is left to the pass)
+            const bool stg = mIn && T.ML <= kXbStageMl && T.off > kXbNear && q0 + T.ML <= confirmed && (!BM || q0 >= S || q0 + T.ML <= S);
+            const uint8_t *const rb = BM && q0 < S ? pat : (const uint8_t *)out;
             N.stg = wave_ballot(stg);
             N.sv = N.sv2 = U128U{0, 0, 0, 0};
 #ifndef MZD_ABL_XB_NOSTAGE  /* ablation, timing only (wrong bytes): the kernel without its scattered reads of the slab */
-            if (stg) N.sv = *(const U128U *)(out + q0);
-            if (stg && T.ML > 16) N.sv2 = *(const U128U *)(out + q0 + 16);
+            if (stg) N.sv = *(const U128U *)(rb + q0);
+            if (stg && T.ML > 16) N.sv2 = *(const U128U *)(rb + q0 + 16);
 #endif
             // the stretch's literals: [la, lb) of the block's literals
             N.lv = 0;
@@ -454,7 +487,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
                     XB_STAT(5, wave_any(far));
                     if (wave_any(far)) {
                         xb_wait_vm();  // every window unit issued so far has arrived in the slab
-                        if (far) val = out[s];
+                        if (far) val = (BM && s < S ? pat : (const uint8_t *)out)[s];
                     }
                     if (wave_any(r >= 0)) {
                         // nearly always one level deep: the source lane's byte is there already
@@ -500,6 +533,11 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
         }
     }
     if (error == MZD_OK) flushed = xb_flush_bytes(sh, out, flushed, outPos, lane);
+    if (BM) {
+        // an offset beyond the produced data (the one defect the scan cannot see): the frame ends at its first such block
+        if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi0);
+        return;
+    }
 #ifdef MZD_XB_STATS
     xbst[11] = XB_CLOCK() - xb_t0;
     xbst[12] = 1;

@@ -1,0 +1,303 @@
+// mzd_exec_blk.hip -- the blocks of ONE frame executed side by side (few large frames: framedecompressor.go:246-254 walks a
+// frame's blocks one after the other, and so does k_exec_b's wavefront -- 2.7 us per 64 sequences, 354 MB/s for a frame
+// however large the chip).
+//
+// A block's bytes depend on the blocks before it only through the matches that reach back over its start (ringbuffer.go:242-277
+// RepeatBeforeIndex), directly or through later matches that copy those bytes again.  k_exec_b only ever COPIES bytes, so what
+// it makes of a byte that lay before the block's start is that byte, whatever it was.  Block mode runs every block of every
+// frame as its own wavefront job (k_exec_b<true>), NP times, each time with a different PATTERN in place of the data before
+// the block's start:
+//     pass 0        byte 0 of the position x (frame-relative)                 -> written to the frame's slab itself
+//     pass 1 (, 2)  byte 1 (, 2) of x                                         -> to planes beside the slab
+//     last pass     byte 0 of x  XOR  (1 + the top seven bits of x)           -> to the last plane
+// A byte of the block that does not derive from earlier blocks is the same in all passes (and final in the slab after pass 0).
+// One that does differs between pass 0 and the last pass (the XOR term is never zero), and the passes together spell the
+// position it was copied from: its ORIGIN, below the block's start.  (NP = 3 covers frames below 8 MiB, NP = 4 below 2 GiB.)
+// k_blk_fixup then walks the blocks of a frame in order -- a step is a parallel gather slab[x] = slab[origin(x)] over the
+// block's derived bytes (their origins lie in blocks that are final), a few microseconds instead of the block's execution.
+// The offset history at every block's start (framedecompressor.go:23) and the block's first output byte come from a scan
+// over the blocks' summaries (k_blk_scan), which also applies the per-block checks of the serial walk in its order.
+#pragma once
+
+namespace mzd {
+
+// ---- scan: a wavefront per frame, 64 blocks per round (their summaries loaded side by side, then walked in order)
+__global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
+                                                 const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes)
+{
+    const uint32_t f = blockIdx.x, lane = threadIdx.x;
+    const DFrame fr = frames[f];
+    int error = fr.plan_status;
+    uint64_t outPos = 0;
+    int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
+    uint32_t n_ok = error == MZD_OK ? fr.n_blocks : 0u;
+    for (uint32_t base = 0; base < fr.n_blocks; base += 64) {
+        const uint32_t bi = base + lane;
+        const bool valid = bi < fr.n_blocks;
+        uint32_t bo = 0, flags = 0;
+        int e = MZD_OK, h0 = 0, h1 = 0, h2 = 0;
+        bool hist = false;
+        if (valid) {
+            const DBlock b = blocks[fr.first_block + bi];
+            if (b.type != MZD_BLOCK_COMPRESSED) {
+                bo = b.size;
+                flags = kBjDirect;
+            } else {
+                // the checks of k_exec_b's serial walk, in its order
+                const BlockSum s = sums[fr.first_block + bi];
+                e = s.huf_err != 0xFFFFFFFFu ? (int)(s.huf_err & 0xFF) : s.status;
+                if (e == MZD_OK && s.lit_total > b.lit_regen) e = MZD_ERR_LITERALS;  // sequence_execution.go:27-29
+                bo = s.out_total + (b.lit_regen - min(s.lit_total, b.lit_regen));
+                if (e == MZD_OK && bo > kBlockMax) e = MZD_ERR_CORRUPT_SIZES;
+                if (b.n_seq == 0) flags = kBjDirect;
+                else {
+                    hist = true;
+                    h0 = s.hist[0];
+                    h1 = s.hist[1];
+                    h2 = s.hist[2];
+                }
+            }
+        }
+        uint32_t myStart = 0;
+        int m0 = 1, m1 = 4, m2 = 8;
+        const uint32_t n = min(64u, fr.n_blocks - base);
+        if (error == MZD_OK) {
+            for (uint32_t i = 0; i < n; i++) {
+                int ei = __builtin_amdgcn_readlane(e, (int)i);
+                const uint32_t boi = (uint32_t)__builtin_amdgcn_readlane((int)bo, (int)i);
+                if (ei == MZD_OK && outPos + boi > fr.out_capacity) ei = MZD_ERR_DST_FULL;
+                if (ei != MZD_OK) {
+                    error = ei;
+                    n_ok = base + i;
+                    break;
+                }
+                if (lane == i) {
+                    myStart = (uint32_t)outPos;
+                    m0 = H0;
+                    m1 = H1;
+                    m2 = H2;
+                }
+                outPos += boi;
+                if (__builtin_amdgcn_readlane((int)hist, (int)i)) {
+                    // offset history carried to the next block (framedecompressor.go:23; persists across blocks)
+                    const int n0 = resolve_hist(__builtin_amdgcn_readlane(h0, (int)i), H0, H1, H2);
+                    const int n1 = resolve_hist(__builtin_amdgcn_readlane(h1, (int)i), H0, H1, H2);
+                    const int n2 = resolve_hist(__builtin_amdgcn_readlane(h2, (int)i), H0, H1, H2);
+                    H0 = n0;
+                    H1 = n1;
+                    H2 = n2;
+                }
+            }
+        }
+        if (valid) {
+            BJob j;
+            j.start = myStart;
+            j.len = bo;
+            j.H0 = m0;
+            j.H1 = m1;
+            j.H2 = m2;
+            j.flags = flags | (bi >= n_ok ? kBjSkip : 0u);
+            j.frame = f;
+            j.pad = 0;
+            jobs[fr.first_block + bi] = j;
+        }
+    }
+    if (lane == 0) {
+        BFrame bf;
+        bf.status = error;
+        bf.out_len = (uint32_t)outPos;
+        bf.n_ok = n_ok;
+        bf.first_bad = 0xFFFFFFFFu;
+        bf.cnt = 0;
+        bf.bail = 0;
+        bf.pad[0] = bf.pad[1] = 0;
+        bframes[f] = bf;
+    }
+}
+
+// ---- the patterns: pat[p * stride + x] for x < n
+__global__ void k_blk_pattern(uint8_t *pat, uint64_t stride, uint32_t n, uint32_t np)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // four positions each
+    const uint32_t x = 4 * i;
+    if (x >= n) return;
+    for (uint32_t p = 0; p < np; p++) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t y = x + j;
+            const uint32_t v = p + 1 < np ? (y >> (8 * p)) & 0xFFu : (y & 0xFFu) ^ (((y >> (8 * (np - 1))) & 0x7Fu) + 1u);
+            w |= v << (8 * j);
+        }
+        *(uint32_t *)(pat + p * stride + x) = w;
+    }
+}
+
+// ---- fix-up: G workgroups per frame walk its blocks in order; a block's derived bytes are gathered from their origins.
+// A step's chain is: see the step before finished -> gather -> store -> publish.  Everything that does not depend on the
+// blocks before (the block's own bytes in the planes, which of them are derived, their origins) is loaded BEFORE the wait, and
+// the gathers of a 16-byte chunk are issued together (a byte that is not derived reads itself): one memory latency per step
+// and thread, not one per byte.
+// What one workgroup writes and another gathers a step later crosses the XCDs' L2 caches.  Fences of agent scope would do
+// (write back / invalidate the whole L2, per workgroup and step: 160 us a step with 1 024 workgroups); instead the few
+// accesses concerned go to memory themselves -- the gathers are agent-scope loads (sc1), the chunk stores write through
+// (sc0 sc1); a step is
+// published after a wait for its stores.
+constexpr int kFixK = 2;  // chunks per thread and round
+
+__device__ __forceinline__ void fix_store16(uint8_t *p, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int NP>
+struct FixChunks {
+    U128U a[kFixK], e[kFixK], b1[kFixK], b2[kFixK];
+    uint32_t x[kFixK];
+    bool need[kFixK];
+};
+
+template <int NP>
+__device__ __forceinline__ void fix_load(FixChunks<NP> &C, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, const uint8_t *pE, uint32_t S,
+                                         uint32_t n, uint32_t c0, uint32_t cstep)
+{
+    const uint32_t nfull = n >> 4;  // whole chunks (the last bytes of a block go one by one)
+#pragma unroll
+    for (int k = 0; k < kFixK; k++) {
+        const uint32_t c = c0 + (uint32_t)k * cstep;
+        C.x[k] = S + 16 * c;
+        C.need[k] = c < nfull;
+        C.a[k] = C.e[k] = U128U{0, 0, 0, 0};
+        if (C.need[k]) {
+            C.a[k] = *(const U128U *)(p0 + C.x[k]);
+            C.e[k] = *(const U128U *)(pE + C.x[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFixK; k++) {
+        C.need[k] = ((C.a[k].x ^ C.e[k].x) | (C.a[k].y ^ C.e[k].y) | (C.a[k].z ^ C.e[k].z) | (C.a[k].w ^ C.e[k].w)) != 0;
+        C.b1[k] = C.b2[k] = U128U{0, 0, 0, 0};
+        if (C.need[k]) {
+            C.b1[k] = *(const U128U *)(p1 + C.x[k]);
+            if (NP == 4) C.b2[k] = *(const U128U *)(p2 + C.x[k]);
+        }
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, uint32_t S)
+{
+#pragma unroll
+    for (int k = 0; k < kFixK; k++) {
+        if (!C.need[k]) continue;
+        const uint32_t aw[4] = {C.a[k].x, C.a[k].y, C.a[k].z, C.a[k].w}, ew[4] = {C.e[k].x, C.e[k].y, C.e[k].z, C.e[k].w};
+        const uint32_t w1[4] = {C.b1[k].x, C.b1[k].y, C.b1[k].z, C.b1[k].w}, w2[4] = {C.b2[k].x, C.b2[k].y, C.b2[k].z, C.b2[k].w};
+        uint32_t v[16];
+        bool zero[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int q = j >> 2, sh = 8 * (j & 3);
+            const uint32_t aj = (aw[q] >> sh) & 0xFF, dj = aj ^ ((ew[q] >> sh) & 0xFF);
+            uint32_t org = aj | (((w1[q] >> sh) & 0xFF) << 8);
+            if (NP == 4) org |= ((w2[q] >> sh) & 0xFF) << 16;
+            org |= (dj - 1) << (8 * (NP - 1));
+            const bool ok = dj != 0 && org < S;
+            zero[j] = dj != 0 && !ok;  // (an origin at or beyond the block's start: only in a block whose execution failed)
+            v[j] = __hip_atomic_load(p0 + (ok ? org : C.x[k] + (uint32_t)j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a byte that is not derived reads itself
+        }
+        uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[j >> 2] |= (zero[j] ? 0u : v[j]) << (8 * (j & 3));
+        fix_store16(p0 + C.x[k], u32x4{o[0], o[1], o[2], o[3]});
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
+                                                   const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G)
+{
+    const uint32_t f = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
+    const DFrame fr = frames[f];
+    BFrame *bf = &bframes[f];
+    const uint32_t nb = min(bf->n_ok, bf->first_bad);  // blocks [0, nb) executed without a defect
+    uint8_t *p0 = out_blob + fr.out_offset;
+    const uint8_t *p1 = pl1 + fr.out_offset;
+    const uint8_t *p2 = pl2 + fr.out_offset;                    // (NP == 3: this is the last plane)
+    const uint8_t *pE = (NP == 4 ? pl3 : pl2) + fr.out_offset;
+    const uint32_t cstep = G * 256;
+    __shared__ uint32_t go;
+    for (uint32_t bi = 1; bi < nb; bi++) {
+        const BJob jb = jobs[fr.first_block + bi];
+        if (!(jb.flags & kBjDirect)) {
+            const uint32_t S = jb.start, n = jb.len;
+            const uint32_t nchunks = n >> 4;
+            FixChunks<NP> C;
+            fix_load<NP>(C, p0, p1, p2, pE, S, n, g * 256 + tid, cstep);  // (nothing here was written by this kernel)
+            if (G > 1 && bi > 1) {
+                // every workgroup of the frame is done with the blocks before this one (a bounded wait: all of them are
+                // resident -- the launch is sized for that -- but a hang is not an acceptable failure mode)
+                if (tid == 0) {
+                    uint32_t it = 0, ok = 1;
+                    const uint32_t target = G * (bi - 1);
+                    while (__hip_atomic_load(&bf->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++it > 4000000u || __hip_atomic_load(&bf->bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            ok = 0;
+                            break;
+                        }
+                    }
+                    go = ok;
+                }
+                __syncthreads();
+                if (!go) {
+                    if (tid == 0) __hip_atomic_store(&bf->bail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+            fix_gather<NP>(C, p0, S);
+            for (uint32_t c0 = g * 256 + tid + kFixK * cstep; c0 < nchunks; c0 += kFixK * cstep) {
+                fix_load<NP>(C, p0, p1, p2, pE, S, n, c0, cstep);
+                fix_gather<NP>(C, p0, S);
+            }
+            if (g == 0 && tid < (n & 15)) {  // the block's last bytes
+                const uint32_t x = S + (n & ~15u) + tid;
+                const uint32_t aj = p0[x], dj = aj ^ pE[x];
+                if (dj) {
+                    uint32_t org = aj | ((uint32_t)p1[x] << 8);
+                    if (NP == 4) org |= (uint32_t)p2[x] << 16;
+                    org |= (dj - 1) << (8 * (NP - 1));
+                    *(volatile uint8_t *)(p0 + x) = org < S ? *(const volatile uint8_t *)(p0 + org) : (uint8_t)0;
+                }
+            }
+        }
+        if (G > 1) {
+            xb_wait_vm();  // this thread's stores of the step have reached memory
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&bf->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();  // (one workgroup: its own stores are visible to it)
+        }
+    }
+}
+
+// ---- status and length of every frame, as the serial walk reports them
+__global__ void k_blk_final(const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, const BFrame *__restrict__ bframes,
+                            int32_t *frame_status, uint64_t *frame_out_len, uint32_t n_frames)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const DFrame fr = frames[f];
+    const BFrame bf = bframes[f];
+    int e = bf.status;
+    uint32_t len = bf.out_len;
+    if (bf.first_bad < bf.n_ok) {
+        const BJob jb = jobs[fr.first_block + bf.first_bad];
+        e = MZD_ERR_OFFSET;
+        len = jb.start + jb.len;  // (the length k_exec reports for a block that failed on an offset)
+    }
+    if (bf.bail) e = MZD_ERR_DEVICE;
+    if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && len != fr.content_size) e = MZD_ERR_DST_FULL;
+    frame_status[f] = e;
+    frame_out_len[f] = len;
+}
+
+}  // namespace mzd

@@ -12,9 +12,10 @@ from tests.conftest import check_expected
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["exec_auto", "k_exec", "k_exec_b"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3], ids=["exec_auto", "k_exec", "k_exec_b", "k_exec_b_blocks"])
 def ctx(request):
-    """every test that takes `ctx` runs with both execution kernels (and the default choice between them)"""
+    """every test that takes `ctx` runs with both execution kernels, the default choice between them, and with the blocks of
+    every frame executed side by side (k_exec_b in block mode: what a batch of few large frames takes by default)"""
     return z.Context(0, exec_variant=request.param)
 
 
@@ -25,7 +26,7 @@ def _decode(frames, ctx):
 
 @pytest.mark.parametrize("seq_variant,exec_threads,exec_variant",
                          [(0, 256, 1), (1, 256, 1), (3, 256, 1), (0, 128, 1), (1, 128, 1), (3, 128, 1), (0, 64, 1), (1, 64, 1), (3, 64, 1),
-                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0)])
+                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0), (0, 0, 3), (3, 0, 3)])
 def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads, exec_variant):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
@@ -86,6 +87,32 @@ def test_multi_block_synthetic_frames(ctx):
     outs, sts = _decode(frames, ctx)
     assert sts == [0] * len(frames)
     assert outs == want
+
+
+@pytest.mark.parametrize("exec_variant", [0, 3])
+def test_large_frames_blocks_side_by_side(exec_variant):
+    """Few large frames: the blocks of a frame are executed side by side (mzd_exec_blk.hip) -- three passes for frames below
+    8 MiB, four above.  Text-like frames of 1, 9 and 20 MiB (up to 160 blocks, matches reaching back over many block starts,
+    repeat offsets carried across blocks) against the generator's content; by default (exec_variant 0) such a batch takes
+    block mode by itself, 3 forces it."""
+    from tools import synth_binding as sb
+    frames, want = [], []
+    for kind, n in [(sb.TEXT, 9 << 20), (sb.TEXT, 1 << 20), (sb.TEXT, (20 << 20) + 12345), (sb.EXP, 3 << 20), (sb.RANDOM, 700000)]:
+        d = sb.generate(kind, n ^ 0x5bd1, n)
+        frames.append(sb.compress(d, sb.MODE_FULL)[0])
+        want.append(d)
+    c = z.Context(0, exec_variant=exec_variant)
+    for _ in range(2):
+        outs, sts = _decode(frames, c)
+        assert sts == [0] * len(frames)
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert len(o) == len(w), i
+            if o != w:
+                a = np.frombuffer(o, np.uint8)
+                b = np.frombuffer(w, np.uint8)
+                bad = np.nonzero(a != b)[0]
+                raise AssertionError((i, len(bad), bad[:8].tolist()))
+    c.close()
 
 
 def test_randomized_differential(ctx):
@@ -217,7 +244,7 @@ def test_corrupt_input_reports_status_not_fault(corpus, ctx):
     check_expected(name, outs2[0], length, sha, exp)
 
 
-@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2)])
+@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2), (0, 3)])
 def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant, exec_variant):
     """Every corpus frame, mutated 6 times (random byte flips past the frame header, seeded), all
     in ONE device batch.  The device must not fault; a frame it reports as decoded must be one
