@@ -222,7 +222,9 @@ typedef struct mzd_options {
                                  self-synchronise); 3 = k_huf first with the transposed bulk phase; see DESIGN.md */
     uint32_t exec_variant;    /* execution kernel: 0 = by the batch; 1 = k_exec (a workgroup per frame, a lane per sequence,
                                  dataflow on an 8 KiB LDS chunk); 2 = k_exec_b (a wavefront per frame, a lane per output
-                                 byte, strictly in order; 3 KiB of LDS per frame); see DESIGN.md */
+                                 byte, strictly in order; 7.7 KiB of LDS per frame); 3 = k_exec_b in BLOCK MODE (a wavefront
+                                 per block: the blocks of a frame side by side, 3 or 4 passes + an in-order fix-up walk;
+                                 frames below 2 GiB) -- what 0 picks for batches of few large frames; see DESIGN.md */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

@@ -1362,6 +1362,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                    (db->d_frame_order != nullptr || db->out_size < (uint64_t)db->n_frames * 32768));
     for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
         if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
+    const bool exec_b_serial = exec_b;  // the choice without block mode
     // Block mode (mzd_exec_blk.hip): every block its own job, NP passes and a fix-up walk -- for batches whose largest frame is a
     // longer serial job than NP passes over everything.  The model: a wavefront alone makes a 128 KiB block in ~0.37 ms, the
     // chip 5 120 of them in ~0.85 ms; a fix-up step is ~6 us.  (exec_variant 3 forces it: the parity tests.)
@@ -1389,11 +1390,18 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         };
         const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
         const size_t pat_before = db->cap_pat;
-        HIP_TRY(ctx, ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)));
-        HIP_TRY(ctx, ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)));
-        HIP_TRY(ctx, ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256));
-        HIP_TRY(ctx, ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride));
+        // (passes - 1 copies of the output layout + the patterns: a batch that leaves no room for them walks its frames' blocks
+        // in order instead)
+        const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
+                         ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
+                         ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256) == hipSuccess &&
+                         ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride) == hipSuccess;
         if (db->cap_pat != pat_before) db->pat_n = db->pat_np = 0;
+        if (!got) {
+            (void)hipGetLastError();
+            blk = false;
+            exec_b = exec_b_serial || ctx->opt.exec_variant == 3;
+        }
     }
     const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
     const bool huf_first = serial || ctx->opt.huf_variant == 3 ||
@@ -1536,10 +1544,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
             const uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(32u, 1024u / db->n_frames);
             if (blk_np == 3)
-                k_blk_fixup<3><<<db->n_frames * G, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
+                k_blk_fixup<3><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
                                                                db->d_bframes, G);
             else
-                k_blk_fixup<4><<<db->n_frames * G, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
+                k_blk_fixup<4><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
                                                                db->d_frames, db->d_jobs, db->d_bframes, G);
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;

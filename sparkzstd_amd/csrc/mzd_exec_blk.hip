@@ -215,7 +215,15 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
                                                    const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G)
 {
-    const uint32_t f = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
+    // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised): with several workgroups per
+    // frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a step's hand-off
+    // stays inside one L2
+    uint32_t w = blockIdx.x;
+    if (G > 1) {
+        w = blockIdx.x >> 3;
+        if ((blockIdx.x & 7) != ((w / G) & 7)) return;
+    }
+    const uint32_t f = w / G, g = w % G, tid = threadIdx.x;
     const DFrame fr = frames[f];
     BFrame *bf = &bframes[f];
     const uint32_t nb = min(bf->n_ok, bf->first_bad);  // blocks [0, nb) executed without a defect

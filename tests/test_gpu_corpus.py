@@ -115,6 +115,61 @@ def test_large_frames_blocks_side_by_side(exec_variant):
     c.close()
 
 
+def test_block_mode_many_frames_one_fixup_workgroup_each():
+    """1 100 two-block frames with blocks side by side: with that many frames the fix-up walk runs ONE workgroup per frame
+    (no waiting between workgroups); fewer frames take several per frame (the tests above)."""
+    from tools import synth_binding as sb
+    blob, off, ln, ck, ns = sb.make_batch(4, 23, 1100, frame_bytes=163840, threads=4)
+    frames = [blob[int(o):int(o + l)].tobytes() for o, l in zip(off, ln)]
+    c = z.Context(0, exec_variant=3)
+    outs, sts = _decode(frames, c)
+    assert sts == [0] * len(frames)
+    for o, k in zip(outs, ck):
+        assert len(o) == 163840 and sb.checksum64(o) == int(k)
+    c.close()
+
+
+def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
+    """Damaged multi-block frames: block mode (a scan over the block summaries + per-block execution) names the same status
+    and the same produced length per frame as k_exec_b walking the blocks in order -- the first failing block ends the frame
+    (framedecompressor.go:246-254), whatever later blocks would have reported."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(77)
+    base = []
+    for kind, n in [(sb.TEXT, 700000), (sb.EXP, 500000), (sb.TEXT, 300000)]:
+        base.append(sb.compress(sb.generate(kind, n + 3, n), sb.MODE_FULL)[0])
+    base += [bytes(comp) for _, comp, length, *_ in corpus if length > 200000][:6]
+    frames = list(base)
+    for f in base:
+        for k in range(12):
+            b = bytearray(f)
+            for pos in rng.integers(len(b) // 8, len(b), size=1 + k % 2):
+                b[int(pos)] ^= int(rng.integers(1, 256))
+            frames.append(bytes(b))
+    res = []
+    for variant in (2, 3):
+        c = z.Context(0, exec_variant=variant)
+        plan = z.Plan()
+        for f in frames:
+            plan.add_frame(f)
+        batch = plan.finalize()
+        offs = [int(batch.frames[i].out_offset) for i in range(len(frames))]
+        rb = c.upload(batch)
+        rb.run()
+        out, status, out_len = rb.download()
+        res.append((np.array(status).copy(), np.array(out_len).copy(), np.array(out).copy()))
+        rb.free()
+        plan.close()
+        c.close()
+    (s2, l2, o2), (s3, l3, o3) = res
+    assert (s2 == s3).all(), np.nonzero(s2 != s3)[0][:8]
+    assert (l2 == l3).all(), np.nonzero(l2 != l3)[0][:8]
+    assert (s2 != 0).any() and (s2 == 0).any()
+    for i in np.nonzero(s2 == 0)[0]:
+        a, b = offs[i], offs[i] + int(l2[i])
+        assert (o2[a:b] == o3[a:b]).all(), i
+
+
 def test_randomized_differential(ctx):
     """400 frames of random kind / size / mode in ONE batch (ragged, empty, multi-block, mixed block
     types), checked byte for byte against the content they were made from."""

@@ -26,3 +26,22 @@ assert all(s == 0 for s in sts) and total == sum(len(o) for o in outs)
 print(f"FrameReader, one frame per call: {n / (t1 - t0):.0f} frames/s, {total / (t1 - t0) / 1e6:.0f} MB/s "
       f"({(t1 - t0) / n * 1e3:.2f} ms per frame)")
 print(f"decode_frames, one batch of {n}: {n / (t2 - t1):.0f} frames/s, {total / (t2 - t1) / 1e6:.0f} MB/s (host to host, pageable memory)")
+
+# one LARGE frame through the reader (the reference's own usage: cmd/sparkzstd/main.go:59,126): the frame's blocks are executed
+# side by side on the device (mzd_exec_blk.hip); usage: python tools/reader_bench.py <n_frames> <big_frame_bytes>
+if len(sys.argv) > 2:
+    big = int(sys.argv[2])
+    data = sb.generate(sb.TEXT, 5, big)
+    comp = sb.compress(data, sb.MODE_FULL)[0]
+    z.FrameReader(io.BytesIO(comp)).read()  # warm-up: the allocations of this size
+    t0 = time.time()
+    got = z.FrameReader(io.BytesIO(comp)).read()
+    t1 = time.time()
+    assert got == data
+    print(f"FrameReader, one frame of {big >> 20} MiB ({len(comp) >> 20} MiB compressed): {(t1 - t0) * 1e3:.1f} ms = {big / (t1 - t0) / 1e6:.0f} MB/s "
+          f"host to host (planning on one host thread + upload + device pass + download)")
+    ctx.timing_reset(True)
+    outs, sts = z.decode_frames([comp], ctx)
+    ctx.sync()
+    assert sts == [0] and outs[0] == data
+    print("device pass of that frame, per kernel (ms):", {k: round(v, 3) for k, v in ctx.kernel_ms().items()})
