@@ -1706,8 +1706,8 @@ extern "C" int mzd_debug_q4_stats(unsigned long long *out, int reset)
 #ifdef MZD_HUF_SEG_STATS
 extern "C" int mzd_debug_huf_seg_stats(unsigned long long *out, int reset)
 {
-    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_huf_seg_stats), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_huf_seg_stats), z, sizeof z); }
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_huf_seg_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_huf_seg_stats), z, sizeof z); }
     return 0;
 }
 #endif

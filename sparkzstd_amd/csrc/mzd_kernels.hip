@@ -675,22 +675,39 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
 //                start disagrees takes its neighbour's exit and recounts; repeated until the chain
 //                closes (each round fixes at least the first wrong lane: a code that never
 //                synchronises degrades to the serial time, never to a wrong result);
-//   write pass   an exclusive scan of the counts gives every lane its output offset; it decodes its
-//                c_j symbols again from t_j and stores them (16 or 20 per store group).
+//   write pass   an exclusive scan of the counts gives every lane its output offset.  Codes of seven bits and
+//                more (round 3): the count pass has KEPT its symbols, four to a dword, in the top of the lane's
+//                strip -- the bits up there are dead, the window only moves down -- and the write pass copies
+//                them out, 16 bytes per store (a lane whose symbols caught up with its window, or that has to
+//                recount, fills its strip again and decodes again).  Shorter codes make more symbols than
+//                the bits they free have room for: those streams count only, and every lane decodes its
+//                c_j symbols again from t_j (12 per store).
+// Per round and wavefront (config 3; cycles, -DMZD_HUF_SEG_STATS): strip fill 13 k, approach + count 25 k, write-out
+// 25 k -- the lookups are the smaller part: a lane's loads and stores are 48 to 72 bytes apart from its neighbours',
+// every memory instruction is 64 separate requests to the address unit.  Approach run 128 bits and segment 384 bits
+// (48 bytes: the lanes' 16-byte loads stay aligned to each other) measured best: 0.52 ms against 0.72 ms for two
+// walks with 256 / 512 bits.
 // The status is the one the serial loop gives (huffman.go:248-261, literals.go:320,332,349,366):
 // all R bits decode to N symbols and leave rem = R - e_last <= 0 bits; N < want: rem < 0 ? "bits" :
 // "length"; N == want: rem < 0 ? "bits" : ok; N > want: the serial loop stops at want with bits left:
 // "length".  One workgroup = the (up to) four streams of a literals section = four wavefronts sharing the
-// section's decode table in LDS (<= 4 KiB): the kernel needs no other LDS, so a CU holds 8 workgroups.
+// section's decode table in LDS (<= 4 KiB) + a 140-byte strip per lane: four workgroups per CU.
 
 #ifdef MZD_HUF_SEG_STATS
-__device__ unsigned long long g_huf_seg_stats[8];  // streams, validation rounds, lanes recounted, active lanes, symbols
+// 0 rounds, 1 validation rounds, 2 lanes recounted, 3 active lanes, 5 lanes whose symbols did not fit; wavefront cycles: 8 strip
+// fill, 9 approach + count, 10 validation, 11 scan, 12 write pass, 13 whole stream
+__device__ unsigned long long g_huf_seg_stats[16];
+#define SEG_CLK() __builtin_readcyclecounter()
+#define SEG_ADD(i, v) do { if (lane == 0) atomicAdd(&g_huf_seg_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define SEG_CLK() 0ull
+#define SEG_ADD(i, v) do { } while (0)
 #endif
 #ifndef MZD_SEG_APPROACH
-#define MZD_SEG_APPROACH 256
+#define MZD_SEG_APPROACH 128
 #endif
 #ifndef MZD_SEG_BITS
-#define MZD_SEG_BITS 512
+#define MZD_SEG_BITS 384
 #endif
 constexpr int kSegApproach = MZD_SEG_APPROACH;  // bits a lane decodes ahead of its segment to fall into step
 constexpr int kSegBits = MZD_SEG_BITS;          // a lane's segment; a round of 64 lanes covers 64 times as much
@@ -703,9 +720,16 @@ constexpr int kSegBits = MZD_SEG_BITS;          // a lane's segment; a round of 
 // busy for ~80 cycles, and there were ~60 of them per lane and round: TA_BUSY = the kernel's duration.)
 // The window is 64 bits wide and refilled in whole dwords: C = strip bytes [p, p + 8), p a multiple of 4,
 // k = bits already consumed from its top; a refill shifts in the one or two dwords below once k >= 32.
-constexpr int kSegLaneBytes = 128;   // 256 + 512 bits of approach and segment, lookahead, alignment slack
-constexpr int kSegLaneDwords = 33;   // strip stride: the 64 strips start in different LDS banks
-constexpr int kSegTopByte = 123;     // strip byte that holds the first bit the lane looks at in a round
+// strip byte that holds the first bit the lane looks at in a round: approach run, segment and lookahead (a code of MaxBits,
+// the window's alignment, a refill) lie below it; above it, the dead bits the count pass's symbols overwrite
+constexpr int kSegTopByte = 12 + (kSegApproach + kSegBits + 11 + 7 + 32 + 7) / 8;
+constexpr int kSegLaneBytes = (kSegTopByte + 1 + 15) / 16 * 16;  // stream bytes per strip, in 16-byte loads
+#ifndef MZD_SEG_DWORDS
+#define MZD_SEG_DWORDS 35
+#endif
+constexpr int kSegLaneDwords = MZD_SEG_DWORDS;  // strip stride (odd: the 64 strips start in different LDS banks); what lies above
+                                                // the 32 dwords of stream bytes is room for the count pass's symbols
+static_assert(kSegLaneDwords > kSegLaneBytes / 4 && (kSegLaneDwords & 1), "strip stride");
 static_assert(8 * (kSegTopByte - 8 - 4) >= kSegApproach + kSegBits + 11 + 7 + 32, "a lane's strip covers its approach run, segment and lookahead");
 
 template <int G>  // symbols between two refills: 31 + G * MaxBits <= 64
@@ -771,6 +795,52 @@ struct SegDec {
         if (k >= 32) refill();
         return sym();
     }
+    // count_until that also KEEPS the symbols: they go, four to a dword, into the part of the lane's own strip that the
+    // window has left behind (dwords kSegLaneDwords - 1 downwards; the bits up there are dead: the window only moves down).
+    // The strip's bits are gone afterwards -- whoever needs them again (a lane that recounts, a lane whose symbols did not
+    // fit) fills the strip again.  `ovf`: the symbols caught up with the window (short codes: more than four symbols per
+    // 32 bits for long enough); nothing is stored from then on and the lane decodes again in the write pass.
+    __device__ __forceinline__ uint32_t decode_until(int &pos, int hi, bool &ovf)
+    {
+        uint32_t n = 0;
+        int wd = kSegLaneDwords - 1;  // next dword to take symbols (the stride's spare dword first)
+        while (pos + 4 * mb <= hi) {  // all four symbols start below hi
+            refill();
+            int k0 = k;
+            const uint32_t e0 = sym(), e1 = sym();
+            if (G < 4) {  // MaxBits 9..11: two symbols per refill
+                pos += k - k0;
+                refill();
+                k0 = k;
+            }
+            const uint32_t e2 = sym(), e3 = sym();
+            pos += k - k0;
+            const uint32_t w = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+            if (4 * wd >= p + 8) strip[wd] = w;
+            else ovf = true;
+            wd--;
+            n += 4;
+        }
+        uint32_t w = 0, i = 0;
+        while (pos < hi) {
+            const uint32_t e = one();
+            pos += (int)(e >> 8);
+            w |= (e & 0xFF) << (8 * i);
+            n++;
+            if (++i == 4) {
+                if (4 * wd >= p + 8) strip[wd] = w;
+                else ovf = true;
+                wd--;
+                w = 0;
+                i = 0;
+            }
+        }
+        if (i) {
+            if (4 * wd >= p + 8) strip[wd] = w;
+            else ovf = true;
+        }
+        return n;
+    }
     // decodes up to the first code boundary >= hi; returns the number of symbols that START in [pos, hi)
     __device__ __forceinline__ uint32_t count_until(int &pos, int hi)
     {
@@ -807,6 +877,14 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
     int status = last == 0 ? MZD_ERR_BAD_PADDING : MZD_OK;
     const int a0 = last ? (int)__builtin_clz(last) - 24 + 1 : 8;
     const int R = 8 * len - a0;  // data bits
+    // Codes of seven bits and more: the count pass KEEPS its symbols (in the dead top of the lane's strip) and the write pass
+    // copies them out.  Shorter codes make more symbols than the bits they free have room for: those streams count only, and
+    // every lane decodes its share again (the strip is intact then).
+#ifdef MZD_SEG_TWO_WALKS  /* A/B: the kernel of round 2 */
+    const bool keep = false;
+#else
+    const bool keep = mb >= 7;
+#endif
     SegDec<G> d;
     d.tbl = tbl;
     d.strip = strip;
@@ -815,17 +893,28 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
     // contiguous piece of the literals.
     int p0 = 0;             // exact code boundary where the round starts
     uint32_t out_done = 0;  // symbols written by earlier rounds
+    const unsigned long long c_begin = SEG_CLK();
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};  // (summed per stream: an atomic per round and phase throttles the kernel it measures)
+    unsigned long long acc_rounds = 0, acc_lanes = 0;
+    (void)c_begin;
+    (void)acc;
     while (status == MZD_OK && p0 < R) {
+        const unsigned long long c0 = SEG_CLK();
+        unsigned long long c1 = c0;
+        (void)c1;
         const int lo = p0 + lane * kSegBits;
+        const int fill_pos = max(lo - kSegApproach, p0);  // where the lane's strip starts (p0 moves on before the write pass)
         const bool act = lo < R;
         const int hi = min(R, lo + kSegBits);
         int tpos = 0, epos = 0;
         uint32_t cnt = 0;
+        bool ovf = false;  // the lane's symbols did not fit into its strip: it decodes again in the write pass
         if (act) {
             // ---- the lane's strip, then the count pass: approach, first boundary at or after lo, symbols up to hi
-            int pos = max(lo - kSegApproach, p0);
+            int pos = fill_pos;
             d.fill(s, len, a0 + pos);
             d.seek(a0 + pos);
+            c1 = SEG_CLK();
             while (pos + G * mb <= lo) {
                 d.refill();
                 const int k0 = d.k;
@@ -835,9 +924,17 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
             }
             while (pos < lo) pos += (int)(d.one() >> 8);
             tpos = pos;
-            cnt = d.count_until(pos, hi);
+            if (keep) {
+                ovf = false;
+                cnt = d.decode_until(pos, hi, ovf);
+            } else {
+                ovf = true;
+                cnt = d.count_until(pos, hi);
+            }
             epos = pos;
         }
+        const unsigned long long c2 = SEG_CLK();
+        (void)c2;
         // ---- validation: the chain of boundaries must close (lanes run in lockstep here)
         for (int guard = 0; guard < 66; guard++) {
             const int tnext = __shfl_down(tpos, 1, 64);
@@ -849,17 +946,26 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
 #endif
             const bool fix = (bool)__shfl_up((int)bad, 1, 64) && lane > 0;
             const int newt = __shfl_up(epos, 1, 64);
-            if (fix) {  // newt < lo + MaxBits: inside the lane's strip
+            if (fix) {  // newt < lo + MaxBits: inside the lane's strip (filled again: the symbols have overwritten its top)
                 int pos = newt;
+                if (keep) d.fill(s, len, a0 + fill_pos);
                 d.seek(a0 + pos);
                 tpos = pos;
-                cnt = pos < hi ? d.count_until(pos, hi) : 0u;
+                if (keep) {
+                    ovf = false;
+                    cnt = pos < hi ? d.decode_until(pos, hi, ovf) : 0u;
+                } else {
+                    cnt = pos < hi ? d.count_until(pos, hi) : 0u;
+                }
                 epos = pos;
             }
         }
 #ifdef MZD_HUF_SEG_STATS
-        { const unsigned long long bm = __ballot(act); if (lane == 0) { atomicAdd(&g_huf_seg_stats[0], 1ull); atomicAdd(&g_huf_seg_stats[3], (unsigned long long)__popcll(bm)); } }
+        acc_rounds += 1;
+        acc_lanes += (unsigned long long)__popcll(__ballot(act));
 #endif
+        const unsigned long long c3 = SEG_CLK();
+        (void)c3;
         const uint32_t incl = wave_incl_scan_u32(act ? cnt : 0u, lane);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         const uint64_t am = __ballot(act);
@@ -868,9 +974,45 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
             status = MZD_ERR_HUF_LENGTH;
             break;
         }
-        // ---- write pass: exactly cnt symbols from tpos to out + (symbols of the rounds and lanes below)
-        if (act && cnt) {
+        const unsigned long long c4 = SEG_CLK();
+        (void)c4;
+#ifdef MZD_HUF_SEG_STATS
+        acc[5] += (unsigned long long)__popcll(__ballot(act && ovf));
+#endif
+        // ---- write pass: exactly cnt symbols to out + (symbols of the rounds and lanes below) -- from the lane's strip, where
+        // the count pass left them ...
+        if (act && cnt && !ovf) {
             uint8_t *out = litbuf + t.out_off + out_done + (incl - cnt);
+            int rd = kSegLaneDwords - 1;
+            uint32_t n = 0;
+            for (; n + 16 <= cnt; n += 16, rd -= 4) *(U128U *)(out + n) = U128U{strip[rd], strip[rd - 1], strip[rd - 2], strip[rd - 3]};
+            // the last r < 16 symbols: exactly r bytes leave (the next byte belongs to another lane)
+            const uint32_t r = cnt - n;
+            uint8_t *o = out + n;
+            if (r & 8) {
+                *(U64U *)o = U64U{(uint64_t)strip[rd] | ((uint64_t)strip[rd - 1] << 32)};
+                o += 8;
+                rd -= 2;
+            }
+            if (r & 4) {
+                *(U32U *)o = U32U{strip[rd]};
+                o += 4;
+                rd -= 1;
+            }
+            if (r & 3) {
+                uint32_t acc = strip[rd];
+                if (r & 2) {
+                    *(U16U *)o = U16U{(uint16_t)acc};
+                    o += 2;
+                    acc >>= 16;
+                }
+                if (r & 1) *o = (uint8_t)acc;
+            }
+        }
+        // ... or decoded again from tpos (short codes: the symbols overtook the window)
+        if (act && cnt && ovf) {
+            uint8_t *out = litbuf + t.out_off + out_done + (incl - cnt);
+            if (keep) d.fill(s, len, a0 + fill_pos);
             d.seek(a0 + tpos);
             uint32_t n = 0;
             constexpr int PER = 12;  // symbols per store
@@ -916,7 +1058,21 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
             if (r & 1) *o = (uint8_t)acc;
         }
         out_done += total;
+        {
+            const unsigned long long c5 = SEG_CLK();
+            (void)c5;
+            acc[0] += c1 - c0;
+            acc[1] += c2 - c1;
+            acc[2] += c3 - c2;
+            acc[3] += c4 - c3;
+            acc[4] += c5 - c4;
+        }
     }
+    for (int i = 0; i < 5; i++) SEG_ADD(8 + i, acc[i]);
+    SEG_ADD(5, acc[5]);
+    SEG_ADD(0, acc_rounds);
+    SEG_ADD(3, acc_lanes);
+    SEG_ADD(13, SEG_CLK() - c_begin);
     // ---- status of the whole stream: what the serial loop gives (see the kernel comment)
     if (status == MZD_OK) {
         const int rem = R - p0;

@@ -15,8 +15,11 @@ assert plan.add_frames(blob, off, ln, threads=0) == 0
 ctx = z.Context(0, huf_variant=2)
 rb = ctx.upload(plan.finalize())
 L = _lib.load()
-st = (ctypes.c_ulonglong * 8)()
+st = (ctypes.c_ulonglong * 16)()
 L.mzd_debug_huf_seg_stats(st, 1)
 rb.run(); ctx.sync()
 L.mzd_debug_huf_seg_stats(st, 0)
-print("streams", st[0], "validation rounds", st[1], "lanes recounted", st[2], "active lanes", st[3])
+print("rounds", st[0], "validation rounds", st[1], "lanes recounted", st[2], "active lanes", st[3], "lanes whose symbols did not fit", st[5])
+tot = max(st[13], 1)
+print("wavefront cycles per round: fill %.0f, approach + count %.0f, validation %.0f, scan %.0f, write %.0f; whole stream %.0f per round" %
+      tuple(x / max(st[0], 1) for x in (st[8], st[9], st[10], st[11], st[12], st[13])))
