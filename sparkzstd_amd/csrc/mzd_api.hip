@@ -1404,10 +1404,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
     }
     const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
-    const bool huf_first = serial || ctx->opt.huf_variant == 3 ||
+    // Heterogeneous batches: the Huffman kernel runs on the second stream BESIDE the sequence stage -- that stage is bound by
+    // its longest chain there (real data: 42 k sequences = 5.9 ms of a 7.5 ms kernel with most CUs idle), the Huffman
+    // classes with large tables (up to 64 KiB of LDS per wavefront) fill the CUs it leaves.
+    const bool huf_het_beside = serial && !blk && ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_HET_HUF_FIRST");
+    const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
                             db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !exp_env("MZD_EXP_HUF_BESIDE"));
-    uint32_t nch = q4 ? (uint32_t)(huf_first || db->n_huf_tasks == 0 ? kQ4Chains : kQ4ChainsBeside) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
+    // (heterogeneous batches: the sequence workgroups keep ALL of their CU's LDS, the Huffman wavefronts get the CUs that have
+    // none -- beside a long chain they slowed its step: 7.5 -> 10.4 ms for the kernel)
+    uint32_t nch = q4 ? (uint32_t)(huf_first || huf_het_beside || db->n_huf_tasks == 0 ? kQ4Chains : kQ4ChainsBeside) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
     if (const char *e = exp_env("MZD_SEQ_NCH")) if (pipe) nch = std::min<uint32_t>(nch, std::max(1, atoi(e)));  // experiment: chains per workgroup
     // k_seq_q4 sizes a chain's LDS slot to the batch's largest tables (less to stage, more LDS left for the Huffman
     // workgroups beside it).  With small tables TWO workgroups share a CU: the kernel holds 94 VGPRs (five wavefronts per
@@ -1607,6 +1613,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
+        const hipStream_t hs = huf_first ? s : s2;
         if (db->huf_sorted && !seg) {
             // one launch per table-size class: a wavefront's LDS is 16 tables of the CLASS's size, not of the batch's largest
             // (MaxBits 11 next to MaxBits 5: 64 KiB per wavefront for everybody otherwise), and its 64 streams are of similar length
@@ -1619,10 +1626,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                     const size_t lds = std::max<size_t>((size_t)kHufQuads * cells * 2, ctx->opt.huf_min_lds);
                     if (c == 0 && (hv == 0 || hv == 3) && n >= 64u * (uint32_t)std::max(ctx->num_cus, 1)) {
                         const uint32_t tstage = (uint32_t)((lds + 15) & ~(size_t)15);
-                        k_huf<<<(n + 63) / 64, 64, tstage + kHufTStageBytes, s>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries,
+                        k_huf<<<(n + 63) / 64, 64, tstage + kHufTStageBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries,
                                                                                   db->d_litbuf, db->d_sums, cells, tstage);
                     } else {
-                        k_huf<<<(n + 63) / 64, 64, lds, s>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries, db->d_litbuf,
+                        k_huf<<<(n + 63) / 64, 64, lds, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries, db->d_litbuf,
                                                            db->d_sums, cells, 0u);
                     }
                 }
