@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         if (lane < 36 && seq_code6(0, lane) != kPipeEscape) CTc[seq_code6(0, lane)] = c_ll_base[lane] | ((uint32_t)c_ll_extra[lane] << 24);
         if (lane < 53 && seq_code6(1, lane) != kPipeEscape) CTc[64 + seq_code6(1, lane)] = c_ml_base[lane] | ((uint32_t)c_ml_extra[lane] << 24);
     }
-    // ---- stage the three tables of every chain of this workgroup (as k_seq_pipe: one flat loop, 8 loads in flight)
+    // ---- stage the three tables of every chain of this workgroup
     {
         uint32_t *desc = (uint32_t *)&shs->q1w[0][0];  // [chain][4]: ll_off, ml_off, of_off, logs
         if (lw == 4) {
@@ -185,29 +185,37 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             desc[4 * lane + 3] = has ? ((uint32_t)t.ll_log | ((uint32_t)t.ml_log << 8) | ((uint32_t)t.of_log << 16)) : 0x00FFFFFFu;
         }
         __syncthreads();
-        const uint32_t ncell = min(nch, n_tasks - blockIdx.x * nch) * slot_cells;
+        // A wavefront per chain (round robin), its lanes over the cells the chain's three tables REALLY have: a chain with
+        // predefined or small tables costs what it has, not the batch's largest slot (real data: 40 us of staging per
+        // workgroup for chains of a few hundred steps), and nothing divides by the slot size.
+        const uint32_t nchw = min(nch, n_tasks - blockIdx.x * nch);
         constexpr int UNR = 8;
-        for (uint32_t idx0 = threadIdx.x; idx0 < ncell; idx0 += kQ4Threads * UNR) {
-            uint32_t e[UNR], n[UNR], c6k[UNR];
-            bool ok[UNR];
+        for (uint32_t c = (uint32_t)wave; c < nchw; c += kQ4Threads / 64) {
+            const uint32_t lg3 = desc[4 * c + 3];
+            const uint32_t lgL = lg3 & 0xFF, lgM = (lg3 >> 8) & 0xFF, lgO = (lg3 >> 16) & 0xFF;
+            const uint32_t nL = lgL <= 9 ? 1u << lgL : 0u, nM = lgM <= 9 ? 1u << lgM : 0u, nO = lgO <= 9 ? 1u << lgO : 0u;
+            const uint32_t oL = desc[4 * c + 0], oM = desc[4 * c + 1], oO = desc[4 * c + 2];
+            const uint32_t tot = nL + nM + nO, base = c * slot_cells;
+            for (uint32_t i0 = (uint32_t)lane; i0 < tot; i0 += 64 * UNR) {
+                uint32_t e[UNR], n[UNR], c6k[UNR], dst[UNR];
+                bool ok[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; u++) {
-                const uint32_t idx = idx0 + kQ4Threads * u;
-                const uint32_t c = idx / slot_cells, r = idx - c * slot_cells;
-                const uint32_t kind = r >= off_of ? 2u : (r >= off_ml ? 1u : 0u);
-                const uint32_t i = r - (kind == 2 ? off_of : (kind == 1 ? off_ml : 0u));
-                const uint32_t lg = (desc[4 * min(c, 63u) + 3] >> (8 * kind)) & 0xFF;
-                n[u] = 1u << (lg & 31);
-                ok[u] = idx < ncell && lg <= 9 && i < n[u];
-                c6k[u] = kind;
-                e[u] = ok[u] ? fse_entries[desc[4 * min(c, 63u) + kind] + i] : 0u;  // baseline(16) | nbits(8) | symbol(8)
-            }
+                for (int u = 0; u < UNR; u++) {
+                    const uint32_t i = i0 + 64u * u;
+                    const uint32_t kind = i >= nL + nM ? 2u : (i >= nL ? 1u : 0u);
+                    const uint32_t j = i - (kind == 2 ? nL + nM : (kind == 1 ? nL : 0u));
+                    n[u] = kind == 2 ? nO : (kind == 1 ? nM : nL);
+                    ok[u] = i < tot;
+                    c6k[u] = kind;
+                    dst[u] = base + (kind == 2 ? off_of : (kind == 1 ? off_ml : 0u)) + j;
+                    e[u] = ok[u] ? fse_entries[(kind == 2 ? oO : (kind == 1 ? oM : oL)) + j] : 0u;  // baseline(16) | nbits(8) | symbol(8)
+                }
 #pragma unroll
-            for (int u = 0; u < UNR; u++) {
-                const uint32_t baseline = e[u] & 0xFFFF, nb = (e[u] >> 16) & 0xFF, sym = e[u] >> 24;
-                const uint32_t c6 = c6k[u] == 2 ? sym : seq_code6((int)c6k[u], sym);
-                if (ok[u])
-                    cells[idx0 + kQ4Threads * u] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n[u]) >> (nb & 31)) | (c6 << 10));
+                for (int u = 0; u < UNR; u++) {
+                    const uint32_t baseline = e[u] & 0xFFFF, nb = (e[u] >> 16) & 0xFF, sym = e[u] >> 24;
+                    const uint32_t c6 = c6k[u] == 2 ? sym : seq_code6((int)c6k[u], sym);
+                    if (ok[u]) cells[dst[u]] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n[u]) >> (nb & 31)) | (c6 << 10));
+                }
             }
         }
     }
