@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
                                                   const uint32_t *__restrict__ order, uint32_t first, XbBlk bk)
 {
     __shared__ __attribute__((aligned(16))) XbLds sh;
+#ifdef MZD_SHIFT_XB  /* experiment: the whole instruction stream four bytes later */
+    asm volatile("s_nop 0");
+#endif
     const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
     // this wavefront's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)

@@ -2528,6 +2528,9 @@ __global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uin
                                                const uint32_t *__restrict__ order, uint32_t first)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef MZD_SHIFT_EXEC  /* experiment: the whole instruction stream four bytes later */
+    asm volatile("s_nop 0");
+#endif
     // this workgroup's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)
     const uint32_t fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
     uint8_t *buf = smem;                                        // cap + 32 bytes

@@ -124,6 +124,9 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     // exactly that wide -- 1280 cells when the tables have the format's largest accuracy logs (9 / 9 / 8), 160 when they
     // are the predefined ones -- so batches of small tables leave room for two or three workgroups per CU.
     const uint32_t off_ml = cells_ll, off_of = cells_ll + cells_ml, slot_cells = cells_ll + cells_ml + cells_of;
+#ifdef MZD_SHIFT_Q4  /* experiment: the whole instruction stream four bytes later (code-placement sensitivity of hand-written streams) */
+    asm volatile("s_nop 0");
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef MZD_Q4_PROF
     const long long prof_w0 = wall_clock64(), prof_c0 = clock64();  // 100 MHz / shader clock
