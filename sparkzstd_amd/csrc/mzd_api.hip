@@ -1410,7 +1410,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     const bool huf_het_beside = serial && !blk && ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_HET_HUF_FIRST");
     const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
-                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) && !exp_env("MZD_EXP_HUF_BESIDE"));
+                            db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) &&
+                            // ... and more chains than one round of the sequence stage: with a single round (the 8 192-frame shard
+                            // of configs[4]: 32 chains per CU) LDS is free beside the chains and the Huffman kernel hides in their
+                            // one latency -- 3.81 -> 3.55 ms; 16 384 frames (64 chains per CU) 6.52 -> 6.38-6.53, 32 768 frames
+                            // 11.11 -> 11.18: not there
+                            db->n_seq_tasks > (uint32_t)kQ4Chains * (uint32_t)std::max(ctx->num_cus, 1) && !exp_env("MZD_EXP_HUF_BESIDE"));
     // (heterogeneous batches: the sequence workgroups keep ALL of their CU's LDS, the Huffman wavefronts get the CUs that have
     // none -- beside a long chain they slowed its step: 7.5 -> 10.4 ms for the kernel)
     uint32_t nch = q4 ? (uint32_t)(huf_first || huf_het_beside || db->n_huf_tasks == 0 ? kQ4Chains : kQ4ChainsBeside) : (pipe ? (uint32_t)kPipeMaxChains - 2u : (uint32_t)kSeqChains16);
