@@ -725,9 +725,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         db->own_out = true;
     }
     HIP_OR_FAIL(hipMalloc((void **)&db->d_litbuf, lit_total + 64));
-    // literals that go straight to their place in the output: the kernels address them from the literal scratch's base
-    for (HufTask &t : huf_tasks)
-        if (t.pad) t.out_off = (uint64_t)(uintptr_t)db->d_out + t.out_off - (uint64_t)(uintptr_t)db->d_litbuf;
+    // (literals that go straight to their place in the output -- HufTask.pad -- keep their offset into the output blob: the
+    // Huffman kernels take both bases)
     TRY_OR_FAIL(upload_vec(ctx, frames, &db->d_frames));
     TRY_OR_FAIL(upload_vec(ctx, blocks, &db->d_blocks));
     TRY_OR_FAIL(upload_vec(ctx, huf_tasks, &db->d_huf_tasks));
@@ -1632,10 +1631,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                     if (c == 0 && (hv == 0 || hv == 3) && n >= 64u * (uint32_t)std::max(ctx->num_cus, 1)) {
                         const uint32_t tstage = (uint32_t)((lds + 15) & ~(size_t)15);
                         k_huf<<<(n + 63) / 64, 64, tstage + kHufTStageBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries,
-                                                                                  db->d_litbuf, db->d_sums, cells, tstage);
+                                                                                  db->d_litbuf, db->d_out, db->d_sums, cells, tstage);
                     } else {
                         k_huf<<<(n + 63) / 64, 64, lds, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, n, db->d_huf_entries, db->d_litbuf,
-                                                           db->d_sums, cells, 0u);
+                                                           db->d_out, db->d_sums, cells, 0u);
                     }
                 }
                 q0 = std::max(q0, q1);
@@ -1644,15 +1643,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
         if (seg)
             k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
-                                                               db->d_litbuf, db->d_sums, seg_tbl);
+                                                               db->d_litbuf, db->d_out, db->d_sums, seg_tbl);
         else if (huf_first) {
             const uint32_t tstage = (uint32_t)((huf_lds + 15) & ~(size_t)15);
             k_huf<<<(db->n_huf_tasks + 63) / 64, 64, tstage + kHufTStageBytes, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks,
-                                                                                   db->d_huf_entries, db->d_litbuf, db->d_sums,
+                                                                                   db->d_huf_entries, db->d_litbuf, db->d_out, db->d_sums,
                                                                                    db->huf_slot_cells, tstage);
         } else
             k_huf<<<(db->n_huf_tasks + 63) / 64, 64, huf_lds, s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
-                                                                  db->d_litbuf, db->d_sums, db->huf_slot_cells, 0u);
+                                                                  db->d_litbuf, db->d_out, db->d_sums, db->huf_slot_cells, 0u);
     };
     // k_seq(head) is submitted FIRST so that its workgroups (nearly all of a CU's LDS each) claim the
     // CUs; k_huf's small workgroups then fill what is left instead of delaying them.  (Tried: k_huf beside the LAST,

@@ -302,7 +302,8 @@ constexpr int kHufTStageBytes = 64 * kHufTRow + 64 * kHufTOut + (int)sizeof(HufT
 
 __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, const HufTask *__restrict__ tasks,
                                             uint32_t n_tasks, const uint16_t *__restrict__ huf_entries,
-                                            uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t slot_cells, uint32_t tstage)
+                                            uint8_t *__restrict__ litbuf, uint8_t *out_blob, BlockSum *sums, uint32_t slot_cells,
+                                            uint32_t tstage)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tbl_all = (uint16_t *)smem;
@@ -310,7 +311,10 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     const uint32_t tid = blockIdx.x * 64 + lane;
     HufTask t;
     if (tid < n_tasks) t = tasks[tid];
-    else { t.in_size = 0; t.out_size = 0; t.table_off = 0; t.max_bits = 0; t.in_off = 0; t.out_off = 0; t.block = 0; }
+    else { t.in_size = 0; t.out_size = 0; t.table_off = 0; t.max_bits = 0; t.in_off = 0; t.out_off = 0; t.block = 0; t.pad = 0; }
+    // where the stream's symbols go: the literal scratch, or -- a block without sequences whose place in its frame is known at
+    // upload (HufTask.pad) -- the output blob itself
+    uint8_t *const obase = t.pad ? out_blob : litbuf;
 
     // stage the (up to) 16 tables of this wavefront: all 64 lanes copy each table
     for (int q = 0; q < kHufQuads; q++) {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     int rem = nulltask ? 0 : br.init(in + t.in_off, (int)t.in_size);
     int status = MZD_OK;
     if (rem < 0) status = MZD_ERR_BAD_PADDING;
-    uint8_t *out = litbuf + t.out_off;
+    uint8_t *out = obase + t.out_off;
     uint32_t cnt = 0;
     const uint32_t want = t.out_size;
 
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
         const int badj = (int)((uintptr_t)(in + t.in_off) & 63);
         int clow = ((len - 1 + badj) >> 6) + 1;  // nothing in the ring yet: the two fills below bring chunks ct and ct - 1
         mt->in_off[lane] = t.in_off - (uint64_t)badj;  // (of shifted position 0)
-        mt->out_off[lane] = t.out_off;
+        mt->out_off[lane] = (uint64_t)(uintptr_t)(obase + t.out_off);  // (the address itself: streams of one wavefront may go to either place)
         mt->badj[lane] = badj;
         auto fill = [&](bool need) {  // the streams with `need` get chunk clow - 1 (cooperatively), clow moves down
             mt->need[lane] = need ? 1u : 0u;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
                     }
                     if (mt->bulk[sidx]) {
                         const uint4 v = *(const uint4 *)(ostb + sidx * kHufTOut + 16 * piece);
-                        *(U128U *)(litbuf + mt->out_off[sidx] + 64ull * it + 16 * piece) = U128U{v.x, v.y, v.z, v.w};
+                        *(U128U *)((uint8_t *)(uintptr_t)mt->out_off[sidx] + 64ull * it + 16 * piece) = U128U{v.x, v.y, v.z, v.w};
                     }
                 }
                 it++;
@@ -866,7 +870,7 @@ struct __attribute__((packed, aligned(1))) U16U { uint16_t v; };
 
 template <int G>
 __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, const HufTask &t, const uint16_t *tbl,
-                                               uint32_t *strip, uint8_t *__restrict__ litbuf, BlockSum *sums,
+                                               uint32_t *strip, uint8_t *obase, BlockSum *sums,
                                                uint32_t stream_idx, int lane)
 {
     const uint8_t *s = in + t.in_off;
@@ -898,6 +902,8 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
     unsigned long long acc_rounds = 0, acc_lanes = 0;
     (void)c_begin;
     (void)acc;
+    (void)acc_rounds;
+    (void)acc_lanes;
     while (status == MZD_OK && p0 < R) {
         const unsigned long long c0 = SEG_CLK();
         unsigned long long c1 = c0;
@@ -982,7 +988,7 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
         // ---- write pass: exactly cnt symbols to out + (symbols of the rounds and lanes below) -- from the lane's strip, where
         // the count pass left them ...
         if (act && cnt && !ovf) {
-            uint8_t *out = litbuf + t.out_off + out_done + (incl - cnt);
+            uint8_t *out = obase + t.out_off + out_done + (incl - cnt);
             int rd = kSegLaneDwords - 1;
             uint32_t n = 0;
             for (; n + 16 <= cnt; n += 16, rd -= 4) *(U128U *)(out + n) = U128U{strip[rd], strip[rd - 1], strip[rd - 2], strip[rd - 3]};
@@ -1011,7 +1017,7 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
         }
         // ... or decoded again from tpos (short codes: the symbols overtook the window)
         if (act && cnt && ovf) {
-            uint8_t *out = litbuf + t.out_off + out_done + (incl - cnt);
+            uint8_t *out = obase + t.out_off + out_done + (incl - cnt);
             if (keep) d.fill(s, len, a0 + fill_pos);
             d.seek(a0 + tpos);
             uint32_t n = 0;
@@ -1086,7 +1092,7 @@ constexpr int kHufSegStripBytes = 4 * 64 * kSegLaneDwords * 4;  // four wavefron
 
 __global__ __launch_bounds__(256) void k_huf_seg(const uint8_t *__restrict__ in, const HufTask *__restrict__ tasks,
                                                  uint32_t n_tasks, const uint16_t *__restrict__ huf_entries,
-                                                 uint8_t *__restrict__ litbuf, BlockSum *sums, uint32_t table_bytes)
+                                                 uint8_t *__restrict__ litbuf, uint8_t *out_blob, BlockSum *sums, uint32_t table_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tbl = (uint16_t *)smem;                       // the section's decode table (table_bytes, a multiple of 16)
@@ -1105,9 +1111,10 @@ __global__ __launch_bounds__(256) void k_huf_seg(const uint8_t *__restrict__ in,
     __syncthreads();
     if ((t.in_size | t.out_size) == 0) return;  // null task (sections with one stream use the first wavefront only)
     uint32_t *strip = strips + (wave * 64 + lane) * kSegLaneDwords;
-    if (t.max_bits <= 5) huf_seg_stream<6>(in, t, tbl, strip, litbuf, sums, tid & 3u, lane);
-    else if (t.max_bits <= 8) huf_seg_stream<4>(in, t, tbl, strip, litbuf, sums, tid & 3u, lane);
-    else huf_seg_stream<3>(in, t, tbl, strip, litbuf, sums, tid & 3u, lane);
+    uint8_t *const obase = t.pad ? out_blob : litbuf;  // (see k_huf)
+    if (t.max_bits <= 5) huf_seg_stream<6>(in, t, tbl, strip, obase, sums, tid & 3u, lane);
+    else if (t.max_bits <= 8) huf_seg_stream<4>(in, t, tbl, strip, obase, sums, tid & 3u, lane);
+    else huf_seg_stream<3>(in, t, tbl, strip, obase, sums, tid & 3u, lane);
 }
 
 // ------------------------------------------------------------------------------------------
