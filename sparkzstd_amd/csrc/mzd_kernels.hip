@@ -748,14 +748,26 @@ struct SegDec {
     // byte of the stream) the lane starts at.  The blob has MZD_IN_PAD readable bytes on both sides.
     __device__ __forceinline__ void fill(const uint8_t *s, int stream_len, int a_top)
     {
-        len = stream_len;
-        xb = (len - 1 - (a_top >> 3)) - kSegTopByte;
         U128U q[kSegLaneBytes / 16];
+        fill_load(s, stream_len, a_top, q);
+        fill_store(stream_len, a_top, q);
+    }
+    // the two halves of fill() (issuing the loads of the next round's strip before the stores of this one -- loads and stores
+    // complete through one counter -- cut a wavefront's round from 69 k to 53 k cycles and the kernel's time not at all: with
+    // sixteen wavefronts per CU nobody waits for a single wavefront's latency)
+    static __device__ __forceinline__ void fill_load(const uint8_t *s, int stream_len, int a_top, U128U *q)
+    {
+        const int xb0 = (stream_len - 1 - (a_top >> 3)) - kSegTopByte;
 #pragma unroll
         for (int c = 0; c < kSegLaneBytes / 16; c++) {
-            const int x = min(max(xb + 16 * c, -16), len);  // chunks entirely outside the stream: any readable address
+            const int x = min(max(xb0 + 16 * c, -16), stream_len);  // chunks entirely outside the stream: any readable address
             q[c] = *(const U128U *)(s + x);
         }
+    }
+    __device__ __forceinline__ void fill_store(int stream_len, int a_top, const U128U *q)
+    {
+        len = stream_len;
+        xb = (len - 1 - (a_top >> 3)) - kSegTopByte;
 #pragma unroll
         for (int c = 0; c < kSegLaneBytes / 16; c++) {
             const int x = xb + 16 * c;
@@ -992,8 +1004,20 @@ __device__ __forceinline__ void huf_seg_stream(const uint8_t *__restrict__ in, c
             int rd = kSegLaneDwords - 1;
             uint32_t n = 0;
             for (; n + 16 <= cnt; n += 16, rd -= 4) *(U128U *)(out + n) = U128U{strip[rd], strip[rd - 1], strip[rd - 2], strip[rd - 3]};
-            // the last r < 16 symbols: exactly r bytes leave (the next byte belongs to another lane)
-            const uint32_t r = cnt - n;
+            // the last r < 16 symbols: exactly r bytes leave (the next byte belongs to another lane) -- as ONE more 16-byte store
+            // that ends at the lane's last byte and writes some of the bytes before it again (up to four exact stores for the tail
+            // were a third of the kernel's store instructions; worth 1-2 %)
+            uint32_t r = cnt - n;
+#ifndef MZD_SEG_EXACT_TAILS
+            if (r && cnt >= 16) {
+                const uint32_t s0 = cnt - 16, sh = 8 * (s0 & 3);
+                const int m = kSegLaneDwords - 1 - (int)(s0 >> 2);
+                const uint32_t d0 = strip[m], d1 = strip[m - 1], d2 = strip[m - 2], d3 = strip[m - 3], d4 = strip[m - 4];
+                *(U128U *)(out + s0) = U128U{__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                             __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+                r = 0;
+            }
+#endif
             uint8_t *o = out + n;
             if (r & 8) {
                 *(U64U *)o = U64U{(uint64_t)strip[rd] | ((uint64_t)strip[rd - 1] << 32)};
