@@ -1363,8 +1363,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
     const bool exec_b_serial = exec_b;  // the choice without block mode
     // Block mode (mzd_exec_blk.hip): every block its own job, NP passes and a fix-up walk -- for batches whose largest frame is a
-    // longer serial job than NP passes over everything.  The model: a wavefront alone makes a 128 KiB block in ~0.37 ms, the
-    // chip 5 120 of them in ~0.85 ms; a fix-up step is ~6 us.  (exec_variant 3 forces it: the parity tests.)
+    // longer serial job than NP passes over everything.  The model: a frame's workgroup alone makes a 128 KiB block in ~0.42 ms,
+    // the chip 5 120 of them in ~0.85 ms; a fix-up step is ~6 us.  (exec_variant 3 forces it: the parity tests.)
     bool blk = false;
     uint32_t blk_np = 0;
     uint64_t blk_maxcap = 0;
@@ -1372,9 +1372,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         for (uint32_t f = 0; f < db->n_frames; f++) blk_maxcap = std::max<uint64_t>(blk_maxcap, db->frame_out_cap[f]);
         blk_np = blk_maxcap <= (1u << 23) ? 3u : 4u;
         const double chip = std::max(0.4, (double)db->out_size / kBlockMax / 5120.0 * 0.85);
-        const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.37, chip);
+        // (measured, 8 GiB of output as n frames: 2 048 x 4 MiB serial 31.5 / block mode 46.6 ms per pass; 512 x 16 MiB 65.7 / 58.5;
+        // 256 x 32 MiB 170 / 58.0; 128 x 64 MiB 329 / 58.7 -- a frame's workgroup makes a block in ~0.42 ms)
+        const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.42, chip);
         const double t_blk = blk_np * chip + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
-        blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant == 3 || t_blk < 0.7 * t_serial);
+        blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant == 3 || t_blk < 0.85 * t_serial);
         if (blk) exec_b = true;
     }
     if (blk) {
