@@ -77,7 +77,7 @@ type Context struct {
 // NewContext creates the device context; Close (or the finalizer) destroys it.
 func NewContext(device int) (*Context, error) {
 	var rc C.int
-	var opt C.mzd_options // zero value = defaults
+	var opt C.mzd_options // zero value = defaults: the library picks its kernels per batch (one large frame: its blocks side by side)
 	c := C.mzd_create(C.int(device), &opt, &rc)
 	if c == nil {
 		if rc == C.MZD_ERR_NO_DEVICE {
