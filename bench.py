@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="keep the whole batch PER GPU instead (weak scaling)")
     ap.add_argument("--rendezvous", default=os.environ.get("MZD_BENCH_BACKEND", "gloo"), choices=["gloo", "nccl"],
                     help="how the ranks meet for the barrier and the max-over-ranks time (the data path has no collective)")
-    ap.add_argument("--exec-variant", type=int, default=0, help="0 auto, 1 k_exec (workgroup per frame), 2 k_exec_b (wavefront per frame, lane per byte), 3 k_exec_b with the blocks of a frame side by side")
+    ap.add_argument("--exec-variant", type=int, default=0, help="0 auto, 1 k_exec (workgroup per frame), 2 k_exec_b (wavefront per frame, lane per byte), 3 k_exec_b with the blocks of a frame side by side, 4 the same in jobs of four blocks")
     ap.add_argument("--seq-variant", type=int, default=0)
     ap.add_argument("--verify-checksum", action="store_true", help="frames carry the zstd content checksum and the device verifies it after the pass (k_xxh64; an extension, off by default like in the reference)")
     ap.add_argument("--device-plan", action="store_true", help="parse the frame / block / section headers on the device too (mzd_batch_upload_frames) instead of in the host planner")

@@ -224,7 +224,8 @@ typedef struct mzd_options {
                                  dataflow on an 8 KiB LDS chunk); 2 = k_exec_b (a wavefront per frame, a lane per output
                                  byte, strictly in order; 7.7 KiB of LDS per frame); 3 = k_exec_b in BLOCK MODE (a wavefront
                                  per block: the blocks of a frame side by side, 3 or 4 passes + an in-order fix-up walk;
-                                 frames below 2 GiB) -- what 0 picks for batches of few large frames; see DESIGN.md */
+                                 frames below 2 GiB) -- what 0 picks for batches of few large frames; 4 = the same with jobs
+                                 of four consecutive blocks (fewer fix-up steps; 0 picks the job size by the batch); see DESIGN.md */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

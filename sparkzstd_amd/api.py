@@ -188,7 +188,7 @@ class Context:
         opt.assume_cus = assume_cus
         opt.verify_checksum = 1 if verify_checksum else 0  # extension: the reference never checks it
         opt.huf_variant = huf_variant  # 0 auto, 1 k_huf beside the sequence stage, 2 k_huf_seg, 3 k_huf first with its transposed bulk phase
-        opt.exec_variant = exec_variant  # 0 auto, 1 k_exec (workgroup per frame, lane per sequence), 2 k_exec_b (wavefront per frame, lane per byte), 3 k_exec_b, blocks side by side
+        opt.exec_variant = exec_variant  # 0 auto, 1 k_exec (workgroup per frame, lane per sequence), 2 k_exec_b (wavefront per frame, lane per byte), 3 k_exec_b, blocks side by side, 4 the same in jobs of four blocks
         opt.seq_window_kib = seq_window_kib  # testing: size of the blob window one k_seq_pipe launch covers
         err = ctypes.c_int()
         self._c = self._L.mzd_create(device, ctypes.byref(opt), ctypes.byref(err))

@@ -122,10 +122,11 @@ struct mzd_dbatch {
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
     // block mode of the execution stage (few large frames; mzd_exec_blk.hip): allocated by the first run that takes it
     BJob *d_jobs = nullptr;
+    BSeg *d_segs = nullptr;
     BFrame *d_bframes = nullptr;
     uint8_t *d_planes = nullptr;  // (passes - 1) copies of the output layout
     uint8_t *d_pat = nullptr;     // the passes' patterns, by frame-relative position
-    size_t cap_jobs = 0, cap_bframes = 0, cap_planes = 0, cap_pat = 0;
+    size_t cap_jobs = 0, cap_segs = 0, cap_bframes = 0, cap_planes = 0, cap_pat = 0;
     uint32_t pat_n = 0, pat_np = 0;  // what d_pat holds
     uint64_t out_size = 0;
     uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
@@ -361,6 +362,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_out_len);
     (void)hipFree(db->d_frame_order);
     (void)hipFree(db->d_jobs);
+    (void)hipFree(db->d_segs);
     (void)hipFree(db->d_bframes);
     (void)hipFree(db->d_planes);
     (void)hipFree(db->d_pat);
@@ -1334,7 +1336,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
-    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 3) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 4) return MZD_ERR_INVALID_ARG;
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1368,7 +1370,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     bool blk = false;
     uint32_t blk_np = 0;
     uint64_t blk_maxcap = 0;
-    if (db->n_seq_tasks > 0 && db->n_frames > 0 && (ctx->opt.exec_variant == 0 || ctx->opt.exec_variant == 3)) {
+    // A job is a SEGMENT of blk_gs consecutive blocks, executed in order: a fix-up step per segment instead of per block (one
+    // 1 GiB frame: 8 192 steps of 1.7 us were 14 of its 22.7 ms), as long as there are jobs enough to fill the chip.
+    // (exec_variant 3 forces block mode with segments of one block, 4 with segments of four: the parity tests run both.)
+    uint32_t blk_gs = 1;
+    if (db->n_seq_tasks > 0 && db->n_frames > 0 && (ctx->opt.exec_variant == 0 || ctx->opt.exec_variant >= 3)) {
         for (uint32_t f = 0; f < db->n_frames; f++) blk_maxcap = std::max<uint64_t>(blk_maxcap, db->frame_out_cap[f]);
         blk_np = blk_maxcap <= (1u << 23) ? 3u : 4u;
         const double chip = std::max(0.4, (double)db->out_size / kBlockMax / 5120.0 * 0.85);
@@ -1376,8 +1382,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // 256 x 32 MiB 170 / 58.0; 128 x 64 MiB 329 / 58.7 -- a frame's workgroup makes a block in ~0.42 ms)
         const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.42, chip);
         const double t_blk = blk_np * chip + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
-        blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant == 3 || t_blk < 0.85 * t_serial);
+        blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant >= 3 || t_blk < 0.85 * t_serial);
         if (blk) exec_b = true;
+        if (ctx->opt.exec_variant == 4) blk_gs = 4;
+        else if (ctx->opt.exec_variant == 0) {
+            // (one 1 GiB frame, jobs of 1 / 4 blocks: passes 4 x 1.9 / 2.9 ms, fix-up 12.6 / 5.1 ms; 64 x 128 MiB: 65.4 / 67.3 ms per
+            // pass -- with many frames the fix-up walks are short anyway and larger jobs fill the chip's last round worse)
+            if (const char *e = exp_env("MZD_EXP_BLK_GS")) blk_gs = (uint32_t)std::max(1, atoi(e));
+            else blk_gs = db->n_frames <= 8 && db->n_blocks >= 4096 ? 2u : 1u;
+        }
     }
     if (blk) {
         auto ensure = [&](auto *&ptr, size_t &cap, size_t bytes) -> hipError_t {
@@ -1394,6 +1407,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // (passes - 1 copies of the output layout + the patterns: a batch that leaves no room for them walks its frames' blocks
         // in order instead)
         const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
+                         ensure(db->d_segs, db->cap_segs, ((size_t)db->n_blocks + db->n_frames + 2) * sizeof(BSeg)) == hipSuccess &&
                          ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
                          ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256) == hipSuccess &&
                          ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride) == hipSuccess;
@@ -1543,24 +1557,28 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (blk) {
             // (the whole batch: block mode never splits)
             const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
-            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes);
+            const uint32_t n_slots = db->n_blocks / blk_gs + db->n_frames + 1;  // (see BSeg)
+            (void)hipMemsetAsync(db->d_segs, 0, (size_t)n_slots * sizeof(BSeg), st);
+            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, db->d_segs, blk_gs);
             if (db->pat_n != (uint32_t)(blk_maxcap + 64) || db->pat_np != blk_np) {
                 k_blk_pattern<<<(uint32_t)((blk_maxcap + 64 + 1023) / 1024), 256, 0, st>>>(db->d_pat, pstride, (uint32_t)(blk_maxcap + 64), blk_np);
                 db->pat_n = (uint32_t)(blk_maxcap + 64);
                 db->pat_np = blk_np;
             }
             for (uint32_t p = 0; p < blk_np; p++)
-                k_exec_b<true><<<db->n_blocks, 64, ctx->opt.exec_chunk, st>>>(
+                k_exec_b<true><<<n_slots, 64, ctx->opt.exec_chunk, st>>>(
                     db->d_in, p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
-                    db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, XbBlk{db->d_jobs, db->d_bframes, db->d_pat + (size_t)p * pstride, p});
+                    db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u,
+                    XbBlk{db->d_jobs, db->d_segs, db->d_bframes, db->d_pat + (size_t)p * pstride, db->d_out, p});
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
-            const uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(32u, 1024u / db->n_frames);
+            uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(32u, 1024u / db->n_frames);
+            if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::max(1, atoi(e));  // experiment
             if (blk_np == 3)
                 k_blk_fixup<3><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
-                                                               db->d_bframes, G);
+                                                               db->d_bframes, G, blk_gs);
             else
                 k_blk_fixup<4><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
-                                                               db->d_frames, db->d_jobs, db->d_bframes, G);
+                                                               db->d_frames, db->d_jobs, db->d_bframes, G, blk_gs);
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;
         }

@@ -148,15 +148,25 @@ __device__ __forceinline__ uint32_t xb_owner(uint64_t H, uint32_t sbase, uint32_
     return below - (own ? 0u : 1u);
 }
 
-// BM (block mode, mzd_exec_blk.hip): the wavefront's job is ONE block (`first + blockIdx.x` of the batch's blocks, `out_blob`
-// the plane of this pass); whatever lies before the block's start S is read from the pass's pattern `bk.pat` instead of the
-// slab -- the ring is preloaded with it, staged and far reads below S go to it.
+// BM (block mode, mzd_exec_blk.hip): the wavefront's job is ONE SEGMENT (bk.segs[first + blockIdx.x]: up to a few consecutive
+// blocks of a frame, executed in order; `out_blob` the plane of this pass); whatever lies before the segment's start S is read
+// from the pass's pattern `bk.pat` instead of the slab -- the ring is preloaded with it, staged and far reads below S go to it.
 struct XbBlk {
-    const BJob *jobs;
+    const BJob *jobs;     // per block
+    const BSeg *segs;     // per job
     BFrame *bframes;
-    const uint8_t *pat;  // indexed by the frame-relative position
+    const uint8_t *pat;   // indexed by the frame-relative position
+    const uint8_t *final_blob;  // plane 0 (the output blob): literal-only blocks that the Huffman stage put in place live only there
     uint32_t pass;
 };
+
+// the ring after a bulk write, in block mode: positions below the segment's start come from the pattern
+__device__ __noinline__ void xb_reload_window_bm(XbLds &sh, const uint8_t *out, const uint8_t *pat, uint32_t S, uint32_t outPos, int lane)
+{
+    xb_wait_vm();
+    const uint32_t lo = outPos > kXbWin ? outPos - kXbWin : 0u;
+    for (uint32_t x = lo + (uint32_t)lane; x < outPos; x += 64) sh.win[x & (kXbWin - 1)] = (x < S ? pat : out)[x];
+}
 
 template <bool BM>
 __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
@@ -172,20 +182,24 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
     // this wavefront's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)
-    uint32_t fidx, bi0 = 0;
+    uint32_t fidx, bi0 = 0, seg_n = 0;
     BJob jb{};
     if (BM) {
-        jb = bk.jobs[first + blockIdx.x];
+        const BSeg sg = bk.segs[first + blockIdx.x];
+        if (sg.n == 0) return;  // an unused slot
+        seg_n = sg.n;
+        jb = bk.jobs[sg.first];
         fidx = jb.frame;
+        bi0 = sg.first;  // (global for now)
     } else {
         fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
     }
     const DFrame fr = frames[fidx];
     uint8_t *out = out_blob + fr.out_offset;
     if (BM) {
-        bi0 = first + blockIdx.x - fr.first_block;
-        // the passes after the first are for blocks that can derive bytes from earlier ones
-        if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (jb.flags & kBjDirect)))) return;
+        bi0 -= fr.first_block;
+        // the passes after the first are for segments that can derive bytes from before their start
+        if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (seg_n == 1 && (jb.flags & kBjDirect))))) return;
     }
     const uint32_t S = BM ? jb.start : 0u;  // the block's first byte (block mode)
     const uint8_t *const pat = bk.pat;
@@ -202,7 +216,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     }
     if (lane < (int)(kXbStretch / 32)) sh.bits[lane] = 0u;
     if (lane == 0) sh.special = sh.special2 = 0u;
-    if (BM && S > 0 && !(jb.flags & kBjDirect)) xb_reload_window(sh, pat, S, lane);  // the ring's view of the frame before the block
+    if (BM && S > 0 && !(seg_n == 1 && (jb.flags & kBjDirect))) xb_reload_window(sh, pat, S, lane);  // the ring's view of the frame before the segment
+    uint32_t bi_cur = bi0;  // (block mode: the block an error belongs to)
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
     uint32_t vwmask = kXbWin - 1;
     uint32_t lblo = lane < 32 ? 1u << lane : 0u, lbhi = lane < 32 ? 0u : 1u << (lane - 32);
@@ -212,7 +227,12 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     const unsigned long long xb_t0 = XB_CLOCK();
 #endif
 
-    for (uint32_t bi = bi0; bi < (BM ? bi0 + 1 : fr.n_blocks) && error == MZD_OK; bi++) {
+    for (uint32_t bi = bi0; bi < (BM ? bi0 + seg_n : fr.n_blocks) && error == MZD_OK; bi++) {
+        if (BM) {
+            bi_cur = bi;
+            if (bi > bi0 && (bk.jobs[fr.first_block + bi].flags & kBjSkip)) break;  // the frame ended before this block
+        }
+        const bool more = BM && bi + 1 < bi0 + seg_n;  // (block mode: the segment goes on: the ring must follow a bulk write)
         const DBlock b = blocks[fr.first_block + bi];
         if (b.type != MZD_BLOCK_COMPRESSED) {
             // Raw (framedecompressor.go:211-215) / RLE (:229-241): straight copy / fill
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
             if (!BM) xb_reload_window(sh, out, outPos, lane);
+            else if (more) xb_reload_window_bm(sh, out, pat, S, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -250,9 +271,14 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
             if (!b.pad[0]) {
                 if (litRle) xb_bulk_fill(out + outPos, lits[0], b.lit_regen, lane);
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
+            } else if (BM && bk.pass > 0) {
+                // (in place means in the OUTPUT blob: the planes of the later passes need the bytes too -- blocks after this one
+                // in the segment copy from them)
+                xb_bulk_copy(out + outPos, bk.final_blob + fr.out_offset + outPos, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
             if (!BM) xb_reload_window(sh, out, outPos, lane);
+            else if (more) xb_reload_window_bm(sh, out, pat, S, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     if (error == MZD_OK) flushed = xb_flush_bytes(sh, out, flushed, outPos, lane);
     if (BM) {
         // an offset beyond the produced data (the one defect the scan cannot see): the frame ends at its first such block
-        if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi0);
+        if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi_cur);
         return;
     }
 #ifdef MZD_XB_STATS

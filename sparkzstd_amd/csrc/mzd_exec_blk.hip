@@ -23,7 +23,8 @@ namespace mzd {
 
 // ---- scan: a wavefront per frame, 64 blocks per round (their summaries loaded side by side, then walked in order)
 __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
-                                                 const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes)
+                                                 const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes,
+                                                 BSeg *__restrict__ segs, uint32_t gs)
 {
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
     const DFrame fr = frames[f];
@@ -58,35 +59,72 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
                 }
             }
         }
-        uint32_t myStart = 0;
-        int m0 = 1, m1 = 4, m2 = 8;
+        // ---- the round's 64 blocks at once: where each starts (a prefix sum), which is the first that fails a check (a ballot),
+        // and the offset history at each one's start -- the blocks' history steps are maps "slot k of the history before, minus
+        // d" or constants, and such maps compose: a scan over the lanes (one 1 GiB frame: 8 192 blocks walked one by one were
+        // 1.7 ms of a 20 ms pass)
         const uint32_t n = min(64u, fr.n_blocks - base);
+        const uint32_t incl = wave_incl_scan_dpp(valid ? bo : 0u);
+        uint32_t myStart = (uint32_t)outPos + incl - bo;
+        int m0 = H0, m1 = H1, m2 = H2;
         if (error == MZD_OK) {
-            for (uint32_t i = 0; i < n; i++) {
-                int ei = __builtin_amdgcn_readlane(e, (int)i);
-                const uint32_t boi = (uint32_t)__builtin_amdgcn_readlane((int)bo, (int)i);
-                if (ei == MZD_OK && outPos + boi > fr.out_capacity) ei = MZD_ERR_DST_FULL;
-                if (ei != MZD_OK) {
-                    error = ei;
-                    n_ok = base + i;
-                    break;
+            int ee = e;
+            if (valid && ee == MZD_OK && outPos + incl > fr.out_capacity) ee = MZD_ERR_DST_FULL;
+            const uint64_t bad = wave_ballot(valid && ee != MZD_OK);
+            const uint32_t nok = bad ? (uint32_t)__builtin_ctzll(bad) : n;  // blocks of this round that pass
+            // history maps: conc[i] ? value v[i] : (slot k[i] of the history at the block's start) - v[i]
+            bool c0 = false, c1 = false, c2 = false;
+            uint32_t k0 = 0, k1 = 1, k2 = 2, v0 = 0, v1 = 0, v2 = 0;  // (a block without sequences: the identity)
+            auto dec = [](int h, bool &c, uint32_t &k, uint32_t &v) {
+                if (h > 0) { c = true; k = 0; v = (uint32_t)h; }
+                else { const uint32_t u = (uint32_t)(-h - 1); c = false; k = min(u & 3u, 2u); v = u >> 2; }  // (resolve_hist / sel3)
+            };
+            if (hist) { dec(h0, c0, k0, v0); dec(h1, c1, k1, v1); dec(h2, c2, k2, v2); }
+            // inclusive scan: lane L holds the map of blocks 0..L of the round
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const bool ac0 = (bool)__shfl_up((int)c0, sft, 64), ac1 = (bool)__shfl_up((int)c1, sft, 64), ac2 = (bool)__shfl_up((int)c2, sft, 64);
+                const uint32_t ak0 = (uint32_t)__shfl_up((int)k0, sft, 64), ak1 = (uint32_t)__shfl_up((int)k1, sft, 64), ak2 = (uint32_t)__shfl_up((int)k2, sft, 64);
+                const uint32_t av0 = (uint32_t)__shfl_up((int)v0, sft, 64), av1 = (uint32_t)__shfl_up((int)v1, sft, 64), av2 = (uint32_t)__shfl_up((int)v2, sft, 64);
+                if ((int)lane >= sft) {
+                    auto comp = [&](bool &c, uint32_t &k, uint32_t &v) {  // this lane's component after the earlier lanes' map A
+                        if (c) return;
+                        const bool ac = k == 0 ? ac0 : (k == 1 ? ac1 : ac2);
+                        const uint32_t ak = k == 0 ? ak0 : (k == 1 ? ak1 : ak2), av = k == 0 ? av0 : (k == 1 ? av1 : av2);
+                        if (ac) { c = true; k = 0; v = av - v; }
+                        else { k = ak; v = av + v; }
+                    };
+                    comp(c0, k0, v0);
+                    comp(c1, k1, v1);
+                    comp(c2, k2, v2);
                 }
-                if (lane == i) {
-                    myStart = (uint32_t)outPos;
-                    m0 = H0;
-                    m1 = H1;
-                    m2 = H2;
+            }
+            auto apply = [&](bool c, uint32_t k, uint32_t v) -> int { return c ? (int)v : (int)((uint32_t)(k == 0 ? H0 : (k == 1 ? H1 : H2)) - v); };
+            // the history at this block's start: the map of the lanes before it (lane 0: the history the round starts with)
+            {
+                const bool pc0 = (bool)__shfl_up((int)c0, 1, 64), pc1 = (bool)__shfl_up((int)c1, 1, 64), pc2 = (bool)__shfl_up((int)c2, 1, 64);
+                const uint32_t pk0 = (uint32_t)__shfl_up((int)k0, 1, 64), pk1 = (uint32_t)__shfl_up((int)k1, 1, 64), pk2 = (uint32_t)__shfl_up((int)k2, 1, 64);
+                const uint32_t pv0 = (uint32_t)__shfl_up((int)v0, 1, 64), pv1 = (uint32_t)__shfl_up((int)v1, 1, 64), pv2 = (uint32_t)__shfl_up((int)v2, 1, 64);
+                if (lane > 0) {
+                    m0 = apply(pc0, pk0, pv0);
+                    m1 = apply(pc1, pk1, pv1);
+                    m2 = apply(pc2, pk2, pv2);
                 }
-                outPos += boi;
-                if (__builtin_amdgcn_readlane((int)hist, (int)i)) {
-                    // offset history carried to the next block (framedecompressor.go:23; persists across blocks)
-                    const int n0 = resolve_hist(__builtin_amdgcn_readlane(h0, (int)i), H0, H1, H2);
-                    const int n1 = resolve_hist(__builtin_amdgcn_readlane(h1, (int)i), H0, H1, H2);
-                    const int n2 = resolve_hist(__builtin_amdgcn_readlane(h2, (int)i), H0, H1, H2);
-                    H0 = n0;
-                    H1 = n1;
-                    H2 = n2;
-                }
+            }
+            // what the next round starts with: the map of the round's last good block, and its end
+            if (nok > 0) {
+                const int last = (int)nok - 1;
+                const int n0 = apply((bool)__shfl((int)c0, last, 64), (uint32_t)__shfl((int)k0, last, 64), (uint32_t)__shfl((int)v0, last, 64));
+                const int n1 = apply((bool)__shfl((int)c1, last, 64), (uint32_t)__shfl((int)k1, last, 64), (uint32_t)__shfl((int)v1, last, 64));
+                const int n2 = apply((bool)__shfl((int)c2, last, 64), (uint32_t)__shfl((int)k2, last, 64), (uint32_t)__shfl((int)v2, last, 64));
+                H0 = n0;
+                H1 = n1;
+                H2 = n2;
+                outPos += (uint32_t)__shfl((int)incl, last, 64);
+            }
+            if (nok < n) {
+                error = __shfl(ee, (int)nok, 64);
+                n_ok = base + nok;
             }
         }
         if (valid) {
@@ -100,6 +138,9 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
             j.frame = f;
             j.pad = 0;
             jobs[fr.first_block + bi] = j;
+            // the jobs: segments of up to gs blocks (cut at the multiples of gs of the GLOBAL block index: see BSeg)
+            const uint32_t g = fr.first_block + bi;
+            if (bi == 0 || g % gs == 0) segs[g / gs + f] = BSeg{g, min(gs - g % gs, fr.n_blocks - bi)};
         }
     }
     if (lane == 0) {
@@ -213,7 +254,8 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
 
 template <int NP>
 __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
-                                                   const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G)
+                                                   const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G,
+                                                   uint32_t gs)
 {
     // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised): with several workgroups per
     // frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a step's hand-off
@@ -233,19 +275,24 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
     const uint8_t *pE = (NP == 4 ? pl3 : pl2) + fr.out_offset;
     const uint32_t cstep = G * 256;
     __shared__ uint32_t go;
-    for (uint32_t bi = 1; bi < nb; bi++) {
-        const BJob jb = jobs[fr.first_block + bi];
-        if (!(jb.flags & kBjDirect)) {
-            const uint32_t S = jb.start, n = jb.len;
+    // the frame's segments after its first (which derives nothing: its blocks follow each other inside one job), in order
+    uint32_t steps = 0;  // segments this workgroup is done with
+    uint32_t bi = gs - fr.first_block % gs;  // the first block with a global index that is a multiple of gs
+    for (; bi < nb; bi += gs) {
+        const uint32_t nseg = min(gs, fr.n_blocks - bi);
+        if (bi + nseg > nb) break;  // a segment that did not execute whole: the frame has failed, nothing after it matters
+        const BJob jb = jobs[fr.first_block + bi], je = jobs[fr.first_block + bi + nseg - 1];
+        if (!(nseg == 1 && (jb.flags & kBjDirect))) {
+            const uint32_t S = jb.start, n = je.start + je.len - jb.start;
             const uint32_t nchunks = n >> 4;
             FixChunks<NP> C;
             fix_load<NP>(C, p0, p1, p2, pE, S, n, g * 256 + tid, cstep);  // (nothing here was written by this kernel)
-            if (G > 1 && bi > 1) {
-                // every workgroup of the frame is done with the blocks before this one (a bounded wait: all of them are
+            if (G > 1 && steps > 0) {
+                // every workgroup of the frame is done with the segments before this one (a bounded wait: all of them are
                 // resident -- the launch is sized for that -- but a hang is not an acceptable failure mode)
                 if (tid == 0) {
                     uint32_t it = 0, ok = 1;
-                    const uint32_t target = G * (bi - 1);
+                    const uint32_t target = G * steps;
                     while (__hip_atomic_load(&bf->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                         __builtin_amdgcn_s_sleep(4);
                         if (++it > 4000000u || __hip_atomic_load(&bf->bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -266,7 +313,7 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
                 fix_load<NP>(C, p0, p1, p2, pE, S, n, c0, cstep);
                 fix_gather<NP>(C, p0, S);
             }
-            if (g == 0 && tid < (n & 15)) {  // the block's last bytes
+            if (g == 0 && tid < (n & 15)) {  // the segment's last bytes
                 const uint32_t x = S + (n & ~15u) + tid;
                 const uint32_t aj = p0[x], dj = aj ^ pE[x];
                 if (dj) {
@@ -277,6 +324,7 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
                 }
             }
         }
+        steps++;
         if (G > 1) {
             xb_wait_vm();  // this thread's stores of the step have reached memory
             __syncthreads();

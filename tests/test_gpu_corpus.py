@@ -12,10 +12,11 @@ from tests.conftest import check_expected
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2, 3], ids=["exec_auto", "k_exec", "k_exec_b", "k_exec_b_blocks"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4], ids=["exec_auto", "k_exec", "k_exec_b", "k_exec_b_blocks", "k_exec_b_segments"])
 def ctx(request):
     """every test that takes `ctx` runs with both execution kernels, the default choice between them, and with the blocks of
-    every frame executed side by side (k_exec_b in block mode: what a batch of few large frames takes by default)"""
+    every frame executed side by side (k_exec_b in block mode: what a batch of few large frames takes by default), as jobs of one
+    block and as jobs of four consecutive blocks"""
     return z.Context(0, exec_variant=request.param)
 
 
@@ -26,7 +27,7 @@ def _decode(frames, ctx):
 
 @pytest.mark.parametrize("seq_variant,exec_threads,exec_variant",
                          [(0, 256, 1), (1, 256, 1), (3, 256, 1), (0, 128, 1), (1, 128, 1), (3, 128, 1), (0, 64, 1), (1, 64, 1), (3, 64, 1),
-                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0), (0, 0, 3), (3, 0, 3)])
+                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0), (0, 0, 3), (3, 0, 3), (0, 0, 4)])
 def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads, exec_variant):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
@@ -89,12 +90,12 @@ def test_multi_block_synthetic_frames(ctx):
     assert outs == want
 
 
-@pytest.mark.parametrize("exec_variant", [0, 3])
+@pytest.mark.parametrize("exec_variant", [0, 3, 4])
 def test_large_frames_blocks_side_by_side(exec_variant):
     """Few large frames: the blocks of a frame are executed side by side (mzd_exec_blk.hip) -- three passes for frames below
     8 MiB, four above.  Text-like frames of 1, 9 and 20 MiB (up to 160 blocks, matches reaching back over many block starts,
     repeat offsets carried across blocks) against the generator's content; by default (exec_variant 0) such a batch takes
-    block mode by itself, 3 forces it."""
+    block mode by itself, 3 forces it with jobs of one block, 4 with jobs of four consecutive blocks."""
     from tools import synth_binding as sb
     frames, want = [], []
     for kind, n in [(sb.TEXT, 9 << 20), (sb.TEXT, 1 << 20), (sb.TEXT, (20 << 20) + 12345), (sb.EXP, 3 << 20), (sb.RANDOM, 700000)]:
@@ -147,7 +148,7 @@ def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
                 b[int(pos)] ^= int(rng.integers(1, 256))
             frames.append(bytes(b))
     res = []
-    for variant in (2, 3):
+    for variant in (2, 3, 4):
         c = z.Context(0, exec_variant=variant)
         plan = z.Plan()
         for f in frames:
@@ -161,13 +162,14 @@ def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
         rb.free()
         plan.close()
         c.close()
-    (s2, l2, o2), (s3, l3, o3) = res
-    assert (s2 == s3).all(), np.nonzero(s2 != s3)[0][:8]
-    assert (l2 == l3).all(), np.nonzero(l2 != l3)[0][:8]
+    (s2, l2, o2) = res[0]
     assert (s2 != 0).any() and (s2 == 0).any()
-    for i in np.nonzero(s2 == 0)[0]:
-        a, b = offs[i], offs[i] + int(l2[i])
-        assert (o2[a:b] == o3[a:b]).all(), i
+    for (s3, l3, o3) in res[1:]:
+        assert (s2 == s3).all(), np.nonzero(s2 != s3)[0][:8]
+        assert (l2 == l3).all(), np.nonzero(l2 != l3)[0][:8]
+        for i in np.nonzero(s2 == 0)[0]:
+            a, b = offs[i], offs[i] + int(l2[i])
+            assert (o2[a:b] == o3[a:b]).all(), i
 
 
 def test_randomized_differential(ctx):
@@ -299,7 +301,7 @@ def test_corrupt_input_reports_status_not_fault(corpus, ctx):
     check_expected(name, outs2[0], length, sha, exp)
 
 
-@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2), (0, 3)])
+@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2), (0, 3), (0, 4)])
 def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant, exec_variant):
     """Every corpus frame, mutated 6 times (random byte flips past the frame header, seeded), all
     in ONE device batch.  The device must not fault; a frame it reports as decoded must be one

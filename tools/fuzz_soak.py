@@ -24,7 +24,7 @@ for i in range(40):
 for i in range(12):  # multi-block frames: the scan / pattern passes / fix-up walk of block mode on damaged input
     base.append(sb.compress(sb.generate(int(rng.choice([sb.TEXT, sb.EXP])), 1900 + i, int(rng.integers(300000, 1200000))))[0])
 ctxs = [z.Context(0, seq_variant=0, verify_checksum=True), z.Context(0, seq_variant=1), z.Context(0, seq_variant=3, huf_variant=2), z.Context(0, huf_variant=3),
-        z.Context(0, exec_variant=2), z.Context(0, exec_variant=3), z.Context(0, exec_variant=3, huf_variant=2)]
+        z.Context(0, exec_variant=2), z.Context(0, exec_variant=3), z.Context(0, exec_variant=4, huf_variant=2)]
 bad = done = n_ok = 0
 t0 = time.time()
 while done < n_mut:
