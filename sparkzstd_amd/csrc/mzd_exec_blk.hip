@@ -17,6 +17,9 @@
 // block's derived bytes (their origins lie in blocks that are final), a few microseconds instead of the block's execution.
 // The offset history at every block's start (framedecompressor.go:23) and the block's first output byte come from a scan
 // over the blocks' summaries (k_blk_scan), which also applies the per-block checks of the serial walk in its order.
+// A JOB is a segment of one or more consecutive blocks of a frame (BSeg), executed in order by one wavefront with the
+// pattern in place of whatever lies before the SEGMENT's start; the fix-up walk has a step per segment.  Fewer, longer jobs
+// trade the passes' parallelism for a shorter walk: two blocks per job when the batch has few frames.
 #pragma once
 
 namespace mzd {
