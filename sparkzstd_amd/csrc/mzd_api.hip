@@ -122,11 +122,11 @@ struct mzd_dbatch {
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
     // block mode of the execution stage (few large frames; mzd_exec_blk.hip): allocated by the first run that takes it
     BJob *d_jobs = nullptr;
-    BSeg *d_segs = nullptr;
+    uint32_t *d_heads = nullptr;  // [0] number of jobs, [1 + j] first block of job j
     BFrame *d_bframes = nullptr;
     uint8_t *d_planes = nullptr;  // (passes - 1) copies of the output layout
     uint8_t *d_pat = nullptr;     // the passes' patterns, by frame-relative position
-    size_t cap_jobs = 0, cap_segs = 0, cap_bframes = 0, cap_planes = 0, cap_pat = 0;
+    size_t cap_jobs = 0, cap_heads = 0, cap_bframes = 0, cap_planes = 0, cap_pat = 0;
     uint32_t pat_n = 0, pat_np = 0;  // what d_pat holds
     uint64_t out_size = 0;
     uint64_t n_recs = 0, n_tiles = 0, lit_bytes = 0;  // extent of the scratch arrays (mzd_batch_debug_read)
@@ -362,7 +362,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_out_len);
     (void)hipFree(db->d_frame_order);
     (void)hipFree(db->d_jobs);
-    (void)hipFree(db->d_segs);
+    (void)hipFree(db->d_heads);
     (void)hipFree(db->d_bframes);
     (void)hipFree(db->d_planes);
     (void)hipFree(db->d_pat);
@@ -1407,7 +1407,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // (passes - 1 copies of the output layout + the patterns: a batch that leaves no room for them walks its frames' blocks
         // in order instead)
         const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
-                         ensure(db->d_segs, db->cap_segs, ((size_t)db->n_blocks + db->n_frames + 2) * sizeof(BSeg)) == hipSuccess &&
+                         ensure(db->d_heads, db->cap_heads, ((size_t)db->n_blocks + 2) * 4) == hipSuccess &&
                          ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
                          ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256) == hipSuccess &&
                          ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride) == hipSuccess;
@@ -1557,19 +1557,18 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (blk) {
             // (the whole batch: block mode never splits)
             const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
-            const uint32_t n_slots = db->n_blocks / blk_gs + db->n_frames + 1;  // (see BSeg)
-            (void)hipMemsetAsync(db->d_segs, 0, (size_t)n_slots * sizeof(BSeg), st);
-            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, db->d_segs, blk_gs);
+            (void)hipMemsetAsync(db->d_heads, 0, 4, st);
+            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads);
             if (db->pat_n != (uint32_t)(blk_maxcap + 64) || db->pat_np != blk_np) {
                 k_blk_pattern<<<(uint32_t)((blk_maxcap + 64 + 1023) / 1024), 256, 0, st>>>(db->d_pat, pstride, (uint32_t)(blk_maxcap + 64), blk_np);
                 db->pat_n = (uint32_t)(blk_maxcap + 64);
                 db->pat_np = blk_np;
             }
             for (uint32_t p = 0; p < blk_np; p++)
-                k_exec_b<true><<<n_slots, 64, ctx->opt.exec_chunk, st>>>(
+                k_exec_b<true><<<db->n_blocks, 64, ctx->opt.exec_chunk, st>>>(  // (as many wavefronts as blocks: the ones beyond the job list exit)
                     db->d_in, p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
                     db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u,
-                    XbBlk{db->d_jobs, db->d_segs, db->d_bframes, db->d_pat + (size_t)p * pstride, db->d_out, p});
+                    XbBlk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p});
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
             uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(32u, 1024u / db->n_frames);
             if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::max(1, atoi(e));  // experiment

@@ -148,25 +148,18 @@ __device__ __forceinline__ uint32_t xb_owner(uint64_t H, uint32_t sbase, uint32_
     return below - (own ? 0u : 1u);
 }
 
-// BM (block mode, mzd_exec_blk.hip): the wavefront's job is ONE SEGMENT (bk.segs[first + blockIdx.x]: up to a few consecutive
-// blocks of a frame, executed in order; `out_blob` the plane of this pass); whatever lies before the segment's start S is read
-// from the pass's pattern `bk.pat` instead of the slab -- the ring is preloaded with it, staged and far reads below S go to it.
+// BM (block mode, mzd_exec_blk.hip): the wavefront's job is ONE SEGMENT: block `first + blockIdx.x` of the batch when it is a
+// head (kBjHead) and the blocks after it up to the next head -- a few consecutive blocks WITH sequences of one frame, executed in
+// order (a Raw / RLE / literal-only block is a job of its own); `out_blob` is the plane of this pass.  Whatever lies before the
+// segment's start S is read from the pass's pattern `bk.pat` instead of the slab -- the ring is preloaded with it, staged and
+// far reads below S go to it.
 struct XbBlk {
     const BJob *jobs;     // per block
-    const BSeg *segs;     // per job
+    const uint32_t *heads;  // the jobs: [0] their number, [1 + j] the first block of job j
     BFrame *bframes;
     const uint8_t *pat;   // indexed by the frame-relative position
-    const uint8_t *final_blob;  // plane 0 (the output blob): literal-only blocks that the Huffman stage put in place live only there
     uint32_t pass;
 };
-
-// the ring after a bulk write, in block mode: positions below the segment's start come from the pattern
-__device__ __noinline__ void xb_reload_window_bm(XbLds &sh, const uint8_t *out, const uint8_t *pat, uint32_t S, uint32_t outPos, int lane)
-{
-    xb_wait_vm();
-    const uint32_t lo = outPos > kXbWin ? outPos - kXbWin : 0u;
-    for (uint32_t x = lo + (uint32_t)lane; x < outPos; x += 64) sh.win[x & (kXbWin - 1)] = (x < S ? pat : out)[x];
-}
 
 template <bool BM>
 __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
@@ -182,15 +175,17 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
     // this wavefront's frame: in the batch's execution order when it has one (heterogeneous batches: the largest first)
-    uint32_t fidx, bi0 = 0, seg_n = 0;
+    uint32_t fidx, bi0 = 0;
     BJob jb{};
     if (BM) {
-        const BSeg sg = bk.segs[first + blockIdx.x];
-        if (sg.n == 0) return;  // an unused slot
-        seg_n = sg.n;
-        jb = bk.jobs[sg.first];
+        // the job list k_blk_scan made: heads[0] = number of jobs, heads[1 + j] = the block job j starts at.  (A wavefront per
+        // BLOCK that exits unless its block starts a job put the jobs on every second workgroup -- and so on half of the CUs:
+        // a pass took twice as long.)
+        if (blockIdx.x >= bk.heads[0]) return;
+        const uint32_t g = bk.heads[1 + blockIdx.x];
+        jb = bk.jobs[g];
         fidx = jb.frame;
-        bi0 = sg.first;  // (global for now)
+        bi0 = g;  // (global for now)
     } else {
         fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
     }
@@ -199,7 +194,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     if (BM) {
         bi0 -= fr.first_block;
         // the passes after the first are for segments that can derive bytes from before their start
-        if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (seg_n == 1 && (jb.flags & kBjDirect))))) return;
+        if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (jb.flags & kBjDirect)))) return;
     }
     const uint32_t S = BM ? jb.start : 0u;  // the block's first byte (block mode)
     const uint8_t *const pat = bk.pat;
@@ -216,8 +211,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     }
     if (lane < (int)(kXbStretch / 32)) sh.bits[lane] = 0u;
     if (lane == 0) sh.special = sh.special2 = 0u;
-    if (BM && S > 0 && !(seg_n == 1 && (jb.flags & kBjDirect))) xb_reload_window(sh, pat, S, lane);  // the ring's view of the frame before the segment
-    uint32_t bi_cur = bi0;  // (block mode: the block an error belongs to)
+    if (BM && S > 0 && !(jb.flags & kBjDirect)) xb_reload_window(sh, pat, S, lane);  // the ring's view of the frame before the segment
+    uint32_t bi = bi0;  // (declared out here: block mode reports the block an error belongs to -- every error leaves the loop by `break`)
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
     uint32_t vwmask = kXbWin - 1;
     uint32_t lblo = lane < 32 ? 1u << lane : 0u, lbhi = lane < 32 ? 0u : 1u << (lane - 32);
@@ -227,12 +222,9 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     const unsigned long long xb_t0 = XB_CLOCK();
 #endif
 
-    for (uint32_t bi = bi0; bi < (BM ? bi0 + seg_n : fr.n_blocks) && error == MZD_OK; bi++) {
-        if (BM) {
-            bi_cur = bi;
-            if (bi > bi0 && (bk.jobs[fr.first_block + bi].flags & kBjSkip)) break;  // the frame ended before this block
-        }
-        const bool more = BM && bi + 1 < bi0 + seg_n;  // (block mode: the segment goes on: the ring must follow a bulk write)
+    for (; bi < fr.n_blocks && error == MZD_OK; bi++) {
+        // (block mode: the job ends where the next one starts, or where the frame ended)
+        if (BM && bi > bi0 && (bk.jobs[fr.first_block + bi].flags & (kBjHead | kBjSkip))) break;
         const DBlock b = blocks[fr.first_block + bi];
         if (b.type != MZD_BLOCK_COMPRESSED) {
             // Raw (framedecompressor.go:211-215) / RLE (:229-241): straight copy / fill
@@ -245,7 +237,6 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
             if (!BM) xb_reload_window(sh, out, outPos, lane);
-            else if (more) xb_reload_window_bm(sh, out, pat, S, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -271,14 +262,9 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
             if (!b.pad[0]) {
                 if (litRle) xb_bulk_fill(out + outPos, lits[0], b.lit_regen, lane);
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
-            } else if (BM && bk.pass > 0) {
-                // (in place means in the OUTPUT blob: the planes of the later passes need the bytes too -- blocks after this one
-                // in the segment copy from them)
-                xb_bulk_copy(out + outPos, bk.final_blob + fr.out_offset + outPos, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
             if (!BM) xb_reload_window(sh, out, outPos, lane);
-            else if (more) xb_reload_window_bm(sh, out, pat, S, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -564,7 +550,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
     if (error == MZD_OK) flushed = xb_flush_bytes(sh, out, flushed, outPos, lane);
     if (BM) {
         // an offset beyond the produced data (the one defect the scan cannot see): the frame ends at its first such block
-        if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi_cur);
+        if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi);
         return;
     }
 #ifdef MZD_XB_STATS

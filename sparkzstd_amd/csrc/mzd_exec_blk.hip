@@ -17,7 +17,7 @@
 // block's derived bytes (their origins lie in blocks that are final), a few microseconds instead of the block's execution.
 // The offset history at every block's start (framedecompressor.go:23) and the block's first output byte come from a scan
 // over the blocks' summaries (k_blk_scan), which also applies the per-block checks of the serial walk in its order.
-// A JOB is a segment of one or more consecutive blocks of a frame (BSeg), executed in order by one wavefront with the
+// A JOB is a segment of one or more consecutive blocks of a frame (from a block flagged kBjHead to the next), executed in order by one wavefront with the
 // pattern in place of whatever lies before the SEGMENT's start; the fix-up walk has a step per segment.  Fewer, longer jobs
 // trade the passes' parallelism for a shorter walk: two blocks per job when the batch has few frames.
 #pragma once
@@ -27,14 +27,16 @@ namespace mzd {
 // ---- scan: a wavefront per frame, 64 blocks per round (their summaries loaded side by side, then walked in order)
 __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                  const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes,
-                                                 BSeg *__restrict__ segs, uint32_t gs)
+                                                 uint32_t gs, uint32_t *__restrict__ heads)
 {
+    // heads: [0] a counter (zero at launch), [1 ...] the blocks where a job starts, in no particular order
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
     const DFrame fr = frames[f];
     int error = fr.plan_status;
     uint64_t outPos = 0;
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
     uint32_t n_ok = error == MZD_OK ? fr.n_blocks : 0u;
+    bool prev_direct = true;  // (the block before the frame's first: a job starts there anyway)
     for (uint32_t base = 0; base < fr.n_blocks; base += 64) {
         const uint32_t bi = base + lane;
         const bool valid = bi < fr.n_blocks;
@@ -130,6 +132,8 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
                 n_ok = base + nok;
             }
         }
+        const bool pd_up = (bool)__shfl_up((int)(flags & kBjDirect), 1, 64);  // (all lanes)
+        const bool pd = lane == 0 ? prev_direct : pd_up;
         if (valid) {
             BJob j;
             j.start = myStart;
@@ -140,10 +144,21 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
             j.flags = flags | (bi >= n_ok ? kBjSkip : 0u);
             j.frame = f;
             j.pad = 0;
+            // a job starts at every gs-th block (of the batch's numbering), at a block without sequences and behind one
+            if (bi == 0 || (fr.first_block + bi) % gs == 0 || (flags & kBjDirect) || pd) j.flags |= kBjHead;
             jobs[fr.first_block + bi] = j;
-            // the jobs: segments of up to gs blocks (cut at the multiples of gs of the GLOBAL block index: see BSeg)
-            const uint32_t g = fr.first_block + bi;
-            if (bi == 0 || g % gs == 0) segs[g / gs + f] = BSeg{g, min(gs - g % gs, fr.n_blocks - bi)};
+        }
+        prev_direct = (bool)(__shfl((int)flags, 63, 64) & kBjDirect);
+        {
+            // this round's job starts go on the list (skipped blocks start nothing)
+            const bool head = valid && (bi == 0 || (fr.first_block + bi) % gs == 0 || (flags & kBjDirect) || pd) && bi < n_ok;
+            const uint64_t hm = wave_ballot(head);
+            if (hm) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&heads[0], (uint32_t)__popcll(hm));
+                at = (uint32_t)__shfl((int)at, 0, 64);
+                if (head) heads[1 + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))] = fr.first_block + bi;
+            }
         }
     }
     if (lane == 0) {
@@ -278,20 +293,42 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
     const uint8_t *pE = (NP == 4 ? pl3 : pl2) + fr.out_offset;
     const uint32_t cstep = G * 256;
     __shared__ uint32_t go;
-    // the frame's segments after its first (which derives nothing: its blocks follow each other inside one job), in order
-    uint32_t steps = 0;  // segments this workgroup is done with
-    uint32_t bi = gs - fr.first_block % gs;  // the first block with a global index that is a multiple of gs
-    for (; bi < nb; bi += gs) {
-        const uint32_t nseg = min(gs, fr.n_blocks - bi);
-        if (bi + nseg > nb) break;  // a segment that did not execute whole: the frame has failed, nothing after it matters
-        const BJob jb = jobs[fr.first_block + bi], je = jobs[fr.first_block + bi + nseg - 1];
-        if (!(nseg == 1 && (jb.flags & kBjDirect))) {
+    // the frame's jobs after its first (which derives nothing: its blocks follow each other inside one job), in order.
+    // (Loading the NEXT job's extent and plane bytes while this job's step runs -- a software pipeline over the jobs -- made the
+    // walk slower, 8.1 -> 8.9 ms for 4 095 steps: a step is the hand-off between the workgroups, not the loads before it.)
+    uint32_t steps = 0;  // jobs this workgroup is done with
+    for (uint32_t bi = 1; bi < nb;) {
+        // (this block's entry and the four after it in one go: the job's extent should not cost a latency per block)
+        BJob c[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) c[q] = jobs[fr.first_block + min(bi + (uint32_t)q, fr.n_blocks - 1)];
+        const BJob jb = c[0];
+        if (!(jb.flags & kBjHead)) {  // (a block of the first job)
+            bi++;
+            continue;
+        }
+        uint32_t e = bi + 1;  // the job: blocks [bi, e)
+        BJob je = c[0];
+#pragma unroll
+        for (int q = 1; q < 5; q++)
+            if (e == bi + (uint32_t)q && e < fr.n_blocks && !(c[q].flags & kBjHead)) {
+                je = c[q];
+                e++;
+            }
+        if (e == bi + 5)  // (jobs of more than five blocks: experiments only)
+            while (e < fr.n_blocks && !(jobs[fr.first_block + e].flags & kBjHead)) {
+                je = jobs[fr.first_block + e];
+                e++;
+            }
+        if (e > nb) break;  // a job that did not execute whole: the frame has failed, nothing after it matters
+        bi = e;
+        if (!(jb.flags & kBjDirect)) {
             const uint32_t S = jb.start, n = je.start + je.len - jb.start;
             const uint32_t nchunks = n >> 4;
             FixChunks<NP> C;
             fix_load<NP>(C, p0, p1, p2, pE, S, n, g * 256 + tid, cstep);  // (nothing here was written by this kernel)
             if (G > 1 && steps > 0) {
-                // every workgroup of the frame is done with the segments before this one (a bounded wait: all of them are
+                // every workgroup of the frame is done with the jobs before this one (a bounded wait: all of them are
                 // resident -- the launch is sized for that -- but a hang is not an acceptable failure mode)
                 if (tid == 0) {
                     uint32_t it = 0, ok = 1;
@@ -316,7 +353,7 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
                 fix_load<NP>(C, p0, p1, p2, pE, S, n, c0, cstep);
                 fix_gather<NP>(C, p0, S);
             }
-            if (g == 0 && tid < (n & 15)) {  // the segment's last bytes
+            if (g == 0 && tid < (n & 15)) {  // the job's last bytes
                 const uint32_t x = S + (n & ~15u) + tid;
                 const uint32_t aj = p0[x], dj = aj ^ pE[x];
                 if (dj) {
