@@ -1570,9 +1570,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                     db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u,
                     XbBlk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p});
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
-            // (64 frames of 128 MiB, 2 / 4 / 8 / 16 per frame: 66.9 / 64.4 / 60.9 / 62.7 ms per pass -- every workgroup is a poller of
-            // its frame's counter; one frame of 1 GiB, 16 / 32 / 64 / 128: 21.6 / 18.4 / 18.5 / 20.3 ms)
-            uint32_t G = db->n_frames >= 512 ? 1u : std::min<uint32_t>(32u, 512u / db->n_frames);
+            // (frames whose blocks reach back -- 64 x 128 MiB, 8 / 16 / 32 per frame: 113.8 / 103.7 / 114.8 ms per pass; one frame of
+            // 1 GiB, 32 / 64 with jobs of two blocks: 49.4 / 44.4 ms, 32 / 64 / 128 with jobs of one: 56.0 / 67.4 / 92.2 ms -- every
+            // workgroup is a poller of its frame's counter)
+            uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(64u, 1024u / db->n_frames);
             if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::max(1, atoi(e));  // experiment
             if (blk_np == 3)
                 k_blk_fixup<3><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,

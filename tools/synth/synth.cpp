@@ -698,13 +698,18 @@ inline uint32_t rd32(const uint8_t *p)
 // decoder's repeat-code rules (sequence_execution.go:65-114) applied in reverse.
 // `rep` is the frame's repeat-offset history: it persists across blocks (framedecompressor.go:23) and
 // is updated only by blocks that carry sequences.
-void find_sequences(const uint8_t *src, size_t n, std::vector<Seq> &seqs, std::vector<uint8_t> &lits, int min_match,
-                    uint32_t rep[3])
+// The block is bytes [b0, b0 + bn) of the FRAME `src`; `table` (positions in the frame) lives as long as the frame: a block's
+// matches reach back over its start into the blocks before it (ringbuffer.go:242-277 RepeatBeforeIndex), up to kMaxOffset --
+// single-segment frames, the window is the content.  (A frame of one block starts with an empty table: unchanged.)
+constexpr int kHashLog = 16;
+constexpr size_t kMaxOffset = (size_t)1 << 27;  // (the device path takes offsets below 2^28)
+void find_sequences(const uint8_t *src, size_t b0, size_t bn, std::vector<int32_t> &table, std::vector<Seq> &seqs,
+                    std::vector<uint8_t> &lits, int min_match, uint32_t rep[3])
 {
-    constexpr int HLOG = 16;
-    std::vector<int32_t> table((size_t)1 << HLOG, -1);
-    size_t anchor = 0, ip = 0;
-    const size_t limit = n >= 8 ? n - 8 : 0;
+    constexpr int HLOG = kHashLog;
+    const size_t n = b0 + bn;  // the block's end
+    size_t anchor = b0, ip = b0;
+    const size_t limit = bn >= 8 ? n - 8 : b0;
     auto hash = [&](const uint8_t *p) { return (rd32(p) * 2654435761u) >> (32 - HLOG); };
     while (ip < limit) {
         size_t mlen = 0, mpos = ip;
@@ -718,7 +723,7 @@ void find_sequences(const uint8_t *src, size_t n, std::vector<Seq> &seqs, std::v
             uint32_t h = hash(src + ip);
             int32_t cand = table[h];
             table[h] = (int32_t)ip;
-            if (cand >= 0 && (size_t)cand < ip && rd32(src + cand) == rd32(src + ip)) {
+            if (cand >= 0 && (size_t)cand < ip && ip - (size_t)cand <= kMaxOffset && rd32(src + cand) == rd32(src + ip)) {
                 off = (uint32_t)(ip - (size_t)cand);
                 mlen = 4;
             }
@@ -828,6 +833,8 @@ void encode_frame_body(const uint8_t *src, size_t n, int mode, std::vector<uint8
         return;
     }
     uint32_t rep[3] = {1, 4, 8};  // framedecompressor.go:48
+    std::vector<int32_t> table;  // the matcher's positions: one table per frame
+    if (mode == 0) table.assign((size_t)1 << kHashLog, -1);
     while (p < n) {
         const size_t bn = std::min<size_t>(n - p, 128 * 1024);
         const bool last = p + bn == n;
@@ -842,7 +849,7 @@ void encode_frame_body(const uint8_t *src, size_t n, int mode, std::vector<uint8
             std::vector<Seq> seqs;
             std::vector<uint8_t> lits;
             uint32_t rep_new[3] = {rep[0], rep[1], rep[2]};
-            if (mode == 0) find_sequences(src + p, bn, seqs, lits, min_match, rep_new);
+            if (mode == 0) find_sequences(src, p, bn, table, seqs, lits, min_match, rep_new);
             else lits.assign(src + p, src + p + bn);
             write_literals(lits.data(), lits.size(), body);
             write_sequences(seqs, body);
