@@ -1378,10 +1378,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         for (uint32_t f = 0; f < db->n_frames; f++) blk_maxcap = std::max<uint64_t>(blk_maxcap, db->frame_out_cap[f]);
         blk_np = blk_maxcap <= (1u << 23) ? 3u : 4u;
         const double chip = std::max(0.4, (double)db->out_size / kBlockMax / 5120.0 * 0.85);
-        // (measured, 8 GiB of output as n frames: 2 048 x 4 MiB serial 31.5 / block mode 46.6 ms per pass; 512 x 16 MiB 65.7 / 58.5;
-        // 256 x 32 MiB 170 / 58.0; 128 x 64 MiB 329 / 58.7 -- a frame's workgroup makes a block in ~0.42 ms)
+        // (measured, 8 GiB of output as n frames whose blocks reach back, serial / block mode per pass: 2 048 x 4 MiB 30.2 / 82.1 ms;
+        // 512 x 16 MiB 91.8 / 117.0; 256 x 32 MiB 168 / 98.6; 128 x 64 MiB 325 / 97.2 -- a frame's workgroup makes a block in
+        // ~0.42 ms; the passes cost ~12 % more than the plain kernel, the fix-up walk ~5 ms per GiB + 6 us per block)
         const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.42, chip);
-        const double t_blk = blk_np * chip + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
+        const double t_blk = blk_np * chip * 1.12 + (double)db->out_size / (1u << 30) * 5.0 + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
         blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant >= 3 || t_blk < 0.85 * t_serial);
         if (blk) exec_b = true;
         if (ctx->opt.exec_variant == 4) blk_gs = 4;
