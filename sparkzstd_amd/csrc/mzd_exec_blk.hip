@@ -250,45 +250,74 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
         if (!C.need[k]) continue;
         const uint32_t aw[4] = {C.a[k].x, C.a[k].y, C.a[k].z, C.a[k].w}, ew[4] = {C.e[k].x, C.e[k].y, C.e[k].z, C.e[k].w};
         const uint32_t w1[4] = {C.b1[k].x, C.b1[k].y, C.b1[k].z, C.b1[k].w}, w2[4] = {C.b2[k].x, C.b2[k].y, C.b2[k].z, C.b2[k].w};
-        // A derived byte is fetched from its origin.  Derived bytes come in RUNS (a match copied them together): four bytes of
-        // one aligned dword of the chunk whose origins follow each other are ONE four-byte load; the others go byte by byte,
-        // and a byte that is not derived is not fetched at all.  (With a load per byte, derived or not, the walk was bound by
-        // the number of requests: 73 ms for 64 frames of 128 MiB whose blocks do reach back, 45 ms for one 1 GiB frame; now 58 /
-        // 37 ms.  One 16-byte load per run of equal distance, four per chunk behind one wait: slower, 48 ms for the one frame.)
-        uint32_t r32[4], b8[16], org0[4];
-        bool run[4], get[16];
+        // A derived byte is fetched from its origin.  (A load per byte, derived or not: the walk was 73 ms for 64 frames of
+        // 128 MiB whose blocks do reach back; one load for four bytes whose origins follow each other, byte loads otherwise:
+        // 58 ms at first, 43.6 ms with sixteen workgroups per frame; grouped by distance as below: 27 ms.  One 16-byte load per
+        // distance, four per chunk behind one wait: slower.)
+        // per aligned dword of the chunk: the derived bytes that are the same DISTANCE from their origins (a match copied them
+        // together) come with one four-byte load at (dword position - distance); a dword touches two matches at most in the
+        // common case, so two such loads, and single bytes for what is left
+        uint32_t o[4];
+        uint32_t ldA[4], ldB[4], mA[4], mB[4], b8[16];
+        bool hasA[4], hasB[4], get[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            bool isrun = true;
+            uint32_t dlt[4], keep = 0, okq = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int j = 4 * q + i, sh = 8 * i;
+                const int sh = 8 * i;
                 const uint32_t aj = (aw[q] >> sh) & 0xFF, dj = aj ^ ((ew[q] >> sh) & 0xFF);
                 uint32_t org = aj | (((w1[q] >> sh) & 0xFF) << 8);
                 if (NP == 4) org |= ((w2[q] >> sh) & 0xFF) << 16;
                 org |= (dj - 1) << (8 * (NP - 1));
-                const bool ok = dj != 0 && org < S;  // (an origin at or beyond the job's start: only in a job whose execution failed: reads as 0)
-                if (i == 0) org0[q] = org;
-                isrun = isrun && ok && org == org0[q] + (uint32_t)i;
-                get[j] = ok;
-                b8[j] = dj != 0 ? 0u : aj;  // not derived: the byte itself; derived: what the load below brings
-                if (!ok) continue;
-                b8[j] = org;  // (the address for now)
+                const bool ok = dj != 0 && org < S && org >= (uint32_t)i;  // (beyond the job's start: only in a failed job; reads as 0)
+                dlt[i] = org - (uint32_t)i;
+                okq |= ok ? 1u << i : 0u;
+                if (dj == 0) keep |= aj << sh;                  // not derived: the byte itself
+                get[4 * q + i] = dj != 0 && org < S && !ok;     // (an origin in the frame's first three bytes: a byte load)
+                b8[4 * q + i] = org;
             }
-            run[q] = isrun;
+            o[q] = keep;
+            // group A: the bytes at the distance of the first derived byte; group B: of the first one not in A
+            uint32_t rem = okq;
+            hasA[q] = rem != 0;
+            const uint32_t iA = rem ? (uint32_t)__builtin_ctz(rem) : 0u;
+            const uint32_t dA = iA == 0 ? dlt[0] : (iA == 1 ? dlt[1] : (iA == 2 ? dlt[2] : dlt[3]));
+            uint32_t ma = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) ma |= ((rem >> i) & 1u) && dlt[i] == dA ? 1u << i : 0u;
+            rem &= ~ma;
+            hasB[q] = rem != 0;
+            const uint32_t iB = rem ? (uint32_t)__builtin_ctz(rem) : 0u;
+            const uint32_t dB = iB == 0 ? dlt[0] : (iB == 1 ? dlt[1] : (iB == 2 ? dlt[2] : dlt[3]));
+            uint32_t mb = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) mb |= ((rem >> i) & 1u) && dlt[i] == dB ? 1u << i : 0u;
+            rem &= ~mb;
+#pragma unroll
+            for (int i = 0; i < 4; i++) get[4 * q + i] = get[4 * q + i] || ((rem >> i) & 1u);
+            ldA[q] = dA;
+            ldB[q] = dB;
+            mA[q] = ((ma & 1u) * 0xFFu) | ((ma & 2u) * 0x7F80u) | ((ma & 4u) * 0x3FC000u) | ((ma & 8u) * 0x1FE00000u);  // bit i -> byte i
+            mB[q] = ((mb & 1u) * 0xFFu) | ((mb & 2u) * 0x7F80u) | ((mb & 4u) * 0x3FC000u) | ((mb & 8u) * 0x1FE00000u);
         }
+        uint32_t vA[4], vB[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            r32[q] = 0;
-            if (run[q]) r32[q] = __hip_atomic_load((const uint32_t *)(p0 + org0[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (byte-aligned)
+            vA[q] = vB[q] = 0;
+            if (hasA[q]) vA[q] = __hip_atomic_load((const uint32_t *)(p0 + ldA[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (byte-aligned)
+            if (hasB[q]) vB[q] = __hip_atomic_load((const uint32_t *)(p0 + ldB[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            if (get[j] && !run[j >> 2]) b8[j] = __hip_atomic_load(p0 + b8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t o[4];
+            if (get[j]) b8[j] = __hip_atomic_load(p0 + b8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            o[q] = run[q] ? r32[q] : ((b8[4 * q] & 0xFF) | ((b8[4 * q + 1] & 0xFF) << 8) | ((b8[4 * q + 2] & 0xFF) << 16) | (b8[4 * q + 3] << 24));
+        for (int q = 0; q < 4; q++) {
+            o[q] |= (vA[q] & mA[q]) | (vB[q] & mB[q]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (get[4 * q + i]) o[q] |= (b8[4 * q + i] & 0xFF) << (8 * i);
+        }
         fix_store16(p0 + C.x[k], u32x4{o[0], o[1], o[2], o[3]});
     }
 }
