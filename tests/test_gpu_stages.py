@@ -276,7 +276,15 @@ def _run_full_config(config, n_frames, ctx, frame_bytes=131072):
     rb = ctx.upload(batch)
     try:
         rb.run()
-        rb.run()  # a resident batch is re-runnable: the second pass must leave the same bytes
+        # a resident batch is re-runnable: the second pass must leave the same bytes -- by itself.  The output blob is
+        # POISONED between the two (0xA5 everywhere), so a second pass that wrote nothing would be caught.
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        hip.hipDeviceSynchronize.argtypes = []
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemset(rb.device_out_ptr(), 0xA5, n_frames * frame_bytes) == 0
+        assert hip.hipDeviceSynchronize() == 0
+        rb.run()
         _, status, out_len = rb.download(want_out=False)
         assert (status == 0).all(), np.unique(status, return_counts=True)
         assert (out_len == frame_bytes).all()
@@ -285,7 +293,6 @@ def _run_full_config(config, n_frames, ctx, frame_bytes=131072):
         n = n_frames * frame_bytes
         dptr = rb.device_out_ptr()
         out = torch.empty(n, dtype=torch.uint8, device="cuda")
-        hip = ctypes.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         assert hip.hipMemcpy(out.data_ptr(), dptr, n, 3) == 0  # device to device; frames are laid out back to back
         words = frame_bytes // 8
