@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("sparkzstd_amd/csrc/mzd_kernels.hip", "sparkzstd_amd/csrc/mzd_seq_q4.hip", "sparkzstd_amd/csrc/mzd_exec_b.hip", "sparkzstd_amd/csrc/mzd_exec_blk.hip", "sparkzstd_amd/csrc/mzd_api.hip",
+KERNEL_SOURCES = ("sparkzstd_amd/csrc/mzd_kernels.hip", "sparkzstd_amd/csrc/mzd_seq_q4.hip", "sparkzstd_amd/csrc/mzd_exec_b.hip", "sparkzstd_amd/csrc/mzd_exec_c.hip", "sparkzstd_amd/csrc/mzd_exec_blk.hip", "sparkzstd_amd/csrc/mzd_api.hip",
                   "sparkzstd_amd/csrc/mzd_device.h")
 
 

@@ -205,8 +205,9 @@ typedef struct mzd_options {
                                  (four lanes per chain, five-stage pipeline); 3: k_seq_pipe (one lane per chain, three
                                  stages); see DESIGN.md */
     uint32_t exec_threads;    /* threads per frame in the execution kernel (multiple of 64) */
-    uint32_t exec_chunk;      /* LDS window chunk of the execution kernel in bytes (multiple of 1024) */
-    uint32_t huf_min_lds;     /* minimum LDS bytes requested per Huffman workgroup (residency cap) */
+    uint32_t exec_chunk;      /* k_exec: LDS window chunk in bytes (multiple of 1024, clamped to 4 KiB..128 KiB; 0 = 8 KiB).
+                                 k_exec_b: EXTRA LDS per frame on top of its own (a residency cap; clamped to what 64 KiB leaves) */
+    uint32_t huf_min_lds;     /* minimum LDS bytes requested per Huffman workgroup (residency cap; 0 = none, the default) */
     uint32_t no_split;        /* 1: never overlap k_seq(tail) with k_exec(head) on a second stream */
     uint32_t assume_cus;      /* testing: pretend the device has this many CUs when choosing the split */
     uint32_t verify_checksum; /* 1: frames that carry a content checksum are verified on the device after the

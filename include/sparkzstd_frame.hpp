@@ -13,9 +13,13 @@
 #include <cstring>
 #include <istream>
 #include <iterator>
+#include <map>
+#include <mutex>
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "mzd.h"
@@ -107,6 +111,123 @@ inline std::vector<std::vector<uint8_t>> DecodeFrames(const std::vector<std::vec
         }
     }
     mzd_plan_destroy(plan);
+    if (status) *status = st;
+    return res;
+}
+
+// ---- one batch over several GPUs of a node.  Frames share nothing (tables, offset history and window are per frame:
+// framedecompressor.go:42-52), so device r takes a contiguous range of them -- equal counts when the frames cost the same,
+// equal C + D (compressed + declared decompressed bytes, frame.go:23-61) otherwise -- on its own context and host thread,
+// and the results are stitched in frame order.  No collective, no RCCL.
+
+// context k of `device` (a device listed twice gets two contexts: two independent streams on one GPU)
+inline mzd_ctx *device_context(int device, int k = 0)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, mzd_ctx *> pool;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = pool.find({device, k});
+    if (it != pool.end()) return it->second;
+    int err = 0;
+    mzd_ctx *c = mzd_create(device, nullptr, &err);
+    if (!c) throw Error(err, "mzd_create");
+    pool[{device, k}] = c;
+    return c;
+}
+
+// C + D of one frame from its header alone; a frame without a declared content size counts with its window
+inline uint64_t DeclaredFrameCost(const std::vector<uint8_t> &f)
+{
+    const uint64_t n = f.size();
+    static const unsigned char magic[4] = {0x28, 0xB5, 0x2F, 0xFD};
+    if (n < 6 || std::memcmp(f.data(), magic, 4) != 0) return n;
+    const unsigned fhd = f[4], fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    size_t pos = 5;
+    uint64_t window = 128 * 1024;
+    if (!single) {
+        const unsigned wd = f[pos++];
+        const uint64_t base = 1ull << (10 + (wd >> 3));
+        window = base + (base >> 3) * (wd & 7);
+    }
+    static const unsigned did_bytes[4] = {0, 1, 2, 4};
+    pos += did_bytes[did];
+    const unsigned fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+    if (fcs_bytes == 0 || pos + fcs_bytes > n) return n + window;
+    uint64_t d = 0;
+    for (unsigned i = 0; i < fcs_bytes; i++) d |= (uint64_t)f[pos + i] << (8 * i);
+    return n + d + (fcs_bytes == 2 ? 256 : 0);
+}
+
+// the frame range [lo, hi) of each of `world` devices
+inline std::vector<std::pair<size_t, size_t>> ShardFrames(const std::vector<std::vector<uint8_t>> &frames, size_t world)
+{
+    std::vector<std::pair<size_t, size_t>> r(world);
+    const size_t n = frames.size();
+    std::vector<uint64_t> cost(n);
+    bool same = true;
+    double total = 0;
+    for (size_t i = 0; i < n; i++) {
+        cost[i] = DeclaredFrameCost(frames[i]);
+        same = same && cost[i] == cost[0];
+        total += (double)cost[i];
+    }
+    if (same) {
+        const size_t base = world ? n / world : 0, extra = world ? n % world : 0;
+        for (size_t k = 0, lo = 0; k < world; k++) {
+            const size_t hi = lo + base + (k < extra ? 1 : 0);
+            r[k] = {lo, hi};
+            lo = hi;
+        }
+        return r;
+    }
+    double acc = 0, target = 0;
+    size_t lo = 0;
+    for (size_t k = 0; k < world; k++) {
+        target += total / (double)world;
+        size_t hi = lo;
+        while (hi < n && (acc + (double)cost[hi] <= target || hi == lo) && (n - hi) > (world - k - 1)) acc += (double)cost[hi++];
+        if (k == world - 1) hi = n;
+        r[k] = {lo, hi};
+        lo = hi;
+    }
+    return r;
+}
+
+// DecodeFramesOn(devices []int, frames [][]byte) ([][]byte, []error)
+inline std::vector<std::vector<uint8_t>> DecodeFramesOn(const std::vector<int> &devices, const std::vector<std::vector<uint8_t>> &frames,
+                                                        std::vector<int> *status = nullptr)
+{
+    if (devices.empty()) return DecodeFrames(frames, status, nullptr);
+    std::vector<mzd_ctx *> ctxs;
+    std::map<int, int> seen;
+    for (int d : devices) ctxs.push_back(device_context(d, seen[d]++));
+    const auto ranges = ShardFrames(frames, devices.size());
+    std::vector<std::vector<uint8_t>> res(frames.size());
+    std::vector<int> st(frames.size(), MZD_OK);
+    std::vector<std::string> fail(devices.size());
+    std::vector<int> failcode(devices.size(), MZD_OK);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < devices.size(); k++) {
+        const size_t lo = ranges[k].first, hi = ranges[k].second;
+        if (hi <= lo) continue;
+        th.emplace_back([&, k, lo, hi] {
+            try {
+                std::vector<std::vector<uint8_t>> part(frames.begin() + (long)lo, frames.begin() + (long)hi);
+                std::vector<int> pst;
+                auto out = DecodeFrames(part, &pst, ctxs[k]);
+                for (size_t i = lo; i < hi; i++) {
+                    res[i] = std::move(out[i - lo]);
+                    st[i] = pst[i - lo];
+                }
+            } catch (const Error &e) {
+                failcode[k] = e.code();
+                fail[k] = e.what();
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < devices.size(); k++)
+        if (failcode[k] != MZD_OK) throw Error(failcode[k], "DecodeFramesOn device " + std::to_string(devices[k]) + ": " + fail[k]);
     if (status) *status = st;
     return res;
 }
@@ -213,6 +334,119 @@ class FrameReader {
     size_t pos_ = 0;
     uint64_t readTotal_ = 0;
     bool decoded_ = false;
+};
+
+// A FrameReader that BATCHES.  The reference's harness feeds many frames through ONE reader, Reset per frame
+// (framereader.go:35, cmd/sparkzstd/main.go:59,126); one frame at a time that is one device batch per frame.  Here the
+// sources of the frames to come are known to the reader (Enqueue), it reads `lookahead` of them ahead, decodes them as ONE
+// device batch -- on a background thread, the batch after the one being served -- and serves them in order:
+//     BatchFrameReader r(256);  for (auto &s : streams) r.Enqueue(&s);
+//     while (r.Reset()) { while (size_t n = r.Read(buf, sizeof buf)) consume(buf, n); }
+// Errors surface where FrameReader's do: a wrong magic number at Reset, a damaged block at the frame's first Read; the
+// frames behind a damaged one are unaffected.
+class BatchFrameReader {
+  public:
+    explicit BatchFrameReader(size_t lookahead = 256, std::vector<int> devices = {}, mzd_ctx *ctx = nullptr)
+        : lookahead_(lookahead ? lookahead : 1), devices_(std::move(devices)), ctx_(ctx)
+    {
+    }
+    ~BatchFrameReader()
+    {
+        if (worker_.joinable()) worker_.join();
+    }
+    void Enqueue(std::istream *source) { pending_.push_back({source, {}}); }
+    void Enqueue(std::vector<uint8_t> frame) { pending_.push_back({nullptr, std::move(frame)}); }
+    // the next frame becomes the current one; false when there is none left
+    bool Reset()
+    {
+        buffer_.clear();
+        pos_ = 0;
+        have_ = false;
+        status_ = MZD_OK;
+        if (ready_pos_ == ready_.size()) {
+            if (!worker_.joinable()) StartBatch();
+            if (!worker_.joinable()) return false;
+            CollectBatch();
+        }
+        Decoded &d = ready_[ready_pos_++];
+        if (ready_.size() - ready_pos_ <= lookahead_ / 2 && !worker_.joinable()) StartBatch();  // decode ahead while this batch is served
+        have_ = true;
+        FramesServed++;
+        if (d.status == MZD_ERR_MAGIC || (d.status == MZD_ERR_TRUNCATED && d.frame_len < 4)) throw Error(d.status, "Reset");
+        status_ = d.status;
+        buffer_ = std::move(d.bytes);
+        return true;
+    }
+    size_t Read(uint8_t *p, size_t n)
+    {
+        if (!have_ && !Reset()) return 0;
+        if (status_ != MZD_OK) throw Error(status_, "Read");
+        const size_t k = std::min(n, buffer_.size() - pos_);
+        std::memcpy(p, buffer_.data() + pos_, k);
+        pos_ += k;
+        return k;
+    }
+    size_t FramesServed = 0;
+
+  private:
+    struct Source {
+        std::istream *stream;
+        std::vector<uint8_t> bytes;
+    };
+    struct Decoded {
+        std::vector<uint8_t> bytes;
+        int status;
+        size_t frame_len;
+    };
+    void StartBatch()
+    {
+        std::vector<std::vector<uint8_t>> frames;
+        while (frames.size() < lookahead_ && pending_head_ < pending_.size()) {
+            Source &s = pending_[pending_head_++];
+            if (s.stream) frames.emplace_back(std::istreambuf_iterator<char>(*s.stream), std::istreambuf_iterator<char>());
+            else frames.push_back(std::move(s.bytes));
+        }
+        if (pending_head_ == pending_.size()) {
+            pending_.clear();
+            pending_head_ = 0;
+        }
+        if (frames.empty()) return;
+        inflight_.clear();
+        inflight_error_ = MZD_OK;
+        worker_ = std::thread([this, frames = std::move(frames)]() {
+            try {
+                std::vector<int> st;
+                auto out = devices_.empty() ? DecodeFrames(frames, &st, ctx_) : DecodeFramesOn(devices_, frames, &st);
+                for (size_t i = 0; i < frames.size(); i++) inflight_.push_back({std::move(out[i]), st[i], frames[i].size()});
+            } catch (const Error &e) {
+                inflight_error_ = e.code();
+                inflight_what_ = e.what();
+            }
+        });
+    }
+    void CollectBatch()
+    {
+        worker_.join();
+        if (inflight_error_ != MZD_OK) throw Error(inflight_error_, "BatchFrameReader: " + inflight_what_);
+        ready_.erase(ready_.begin(), ready_.begin() + (long)ready_pos_);
+        ready_pos_ = 0;
+        for (auto &d : inflight_) ready_.push_back(std::move(d));
+        inflight_.clear();
+    }
+    size_t lookahead_;
+    std::vector<int> devices_;
+    mzd_ctx *ctx_;
+    std::vector<Source> pending_;
+    size_t pending_head_ = 0;
+    std::vector<Decoded> ready_, inflight_;
+    size_t ready_pos_ = 0;
+    std::thread worker_;
+    int inflight_error_ = MZD_OK;
+    std::string inflight_what_;
+    std::vector<uint8_t> buffer_;
+    size_t pos_ = 0;
+    bool have_ = false;
+    int status_ = MZD_OK;
 };
 
 }  // namespace sparkzstd

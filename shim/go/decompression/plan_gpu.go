@@ -22,26 +22,46 @@ import (
 // (framedecompressor.go:283-294: Repeat mode / Treeless literals mean "the table used last", including an RLE one).
 type gpuPlan struct {
 	b                   *gpu.Batch
+	bp                  *batchPlan
 	prevHuf             uint32
 	prevLL, prevOF, prevML uint32
+}
+
+// batchPlan is the per-BATCH planning state: the indices of the three predefined tables in THIS batch (added on first
+// use; a package-level map would hand a second batch the first one's indices) -- one per gpu.Batch, used by one goroutine.
+type batchPlan struct {
+	b          *gpu.Batch
+	predefined [3]uint32 // by kind (gpu.KindLL / KindOF / KindML); noTable until the batch has the table
+}
+
+func newBatchPlan(b *gpu.Batch) *batchPlan {
+	return &batchPlan{b: b, predefined: [3]uint32{noTable, noTable, noTable}}
 }
 
 const noTable = 0xFFFFFFFF
 
 // PlanFrame replaces decodeAllBlocks (framedecompressor.go:246-254) for one frame: after CheckMagicnum and
 // DecodeFrameHeader it walks the blocks like DecodeNextBlock (:198-244) but records descriptors instead of decoding.
-func (fd *FrameDecompressor) PlanFrame(b *gpu.Batch) error {
+// It returns the index of the frame IN THE BATCH (what status / outLen / OutOffset are looked up with).  A frame that
+// fails half-way is taken back out: the batch is truncated to the mark taken before BeginFrame, so that the frames after
+// it keep consecutive slots and nothing unfinished reaches the device.
+func (fd *FrameDecompressor) PlanFrame(bp *batchPlan) (int, error) {
 	h := fd.frame.Header
-	b.BeginFrame(uint64(h.WindowSize), uint64(h.FrameContentSize), h.FrameContentSize > 0 || h.Descriptor.GetSingleSegmentFlag())
-	p := &gpuPlan{b: b, prevHuf: noTable, prevLL: noTable, prevOF: noTable, prevML: noTable}
+	b := bp.b
+	mark := b.Mark()
+	predefinedBefore := bp.predefined
+	slot := b.BeginFrame(uint64(h.WindowSize), uint64(h.FrameContentSize), h.FrameContentSize > 0 || h.Descriptor.GetSingleSegmentFlag())
+	p := &gpuPlan{b: b, bp: bp, prevHuf: noTable, prevLL: noTable, prevOF: noTable, prevML: noTable}
 	for !fd.CurrentBlock.Header.LastBlock {
 		if err := fd.PlanNextBlock(p); err != nil {
-			return err
+			b.Truncate(mark) // frames, blocks, tables, cells and payload bytes this frame added
+			bp.predefined = predefinedBefore
+			return -1, err
 		}
 		fd.BlockCounter++
 	}
 	b.FinishFrame()
-	return nil
+	return slot, nil
 }
 
 // PlanNextBlock is DecodeNextBlock (framedecompressor.go:198-244) up to and including the table descriptions.
@@ -142,17 +162,16 @@ func (fd *FrameDecompressor) planCompressed(p *gpuPlan, src *bufio.Reader, block
 }
 
 // predefined tables are tables 0..2 of every batch in the device planner's layout; the Go side adds them once per
-// batch on first use (predefined.go:22,52,70 as normalised counts).
-var predefinedIndex = map[int]uint32{}
+// batch on first use (predefined.go:22,52,70 as normalised counts) and keeps their indices in the batch's batchPlan.
 
 // table resolves one of the three sequence tables to an index in the batch (sequences.go:275-370).
 func (p *gpuPlan) table(mode structure.SymbolCompressionMode, d structure.TableDescription, kind int, prev *uint32) (uint32, error) {
 	switch mode {
 	case structure.SymbolCompressionModePredefined:
-		idx, ok := predefinedIndex[kind]
-		if !ok {
+		idx := p.bp.predefined[kind]
+		if idx == noTable {
 			idx = p.b.AddFSECounts(d.AccuracyLog, d.Counts, kind) // the predefined distribution, as counts
-			predefinedIndex[kind] = idx
+			p.bp.predefined[kind] = idx
 		}
 		*prev = idx
 	case structure.SymbolCompressionModeRLE:
@@ -170,9 +189,11 @@ func (p *gpuPlan) table(mode structure.SymbolCompressionMode, d structure.TableD
 // DecodeFramesPlanned: DecodeFrames over the host-planned route.
 func DecodeFramesPlanned(ctx *gpu.Context, frames []io.Reader) ([][]byte, []error, error) {
 	var b gpu.Batch
+	bp := newBatchPlan(&b)
 	errs := make([]error, len(frames))
-	planned := make([]int, 0, len(frames)) // frame index in the batch -> index in frames
+	slotOf := make([]int, len(frames)) // index in frames -> frame index in the batch (-1: not planned)
 	for i, r := range frames {
+		slotOf[i] = -1
 		fd := NewFrameDecompressor(r, nil)
 		if errs[i] = fd.CheckMagicnum(); errs[i] != nil {
 			continue
@@ -180,16 +201,17 @@ func DecodeFramesPlanned(ctx *gpu.Context, frames []io.Reader) ([][]byte, []erro
 		if errs[i] = fd.DecodeFrameHeader(); errs[i] != nil {
 			continue
 		}
-		if errs[i] = fd.PlanFrame(&b); errs[i] == nil {
-			planned = append(planned, i)
-		} // (a frame that fails half-way leaves its blocks in the batch: a production shim truncates the batch back)
+		slotOf[i], errs[i] = fd.PlanFrame(bp) // (a frame that fails half-way has been truncated out of the batch again)
 	}
 	out, status, outLen, err := b.Decode(ctx)
 	if err != nil {
 		return nil, nil, err
 	}
 	res := make([][]byte, len(frames))
-	for k, i := range planned {
+	for i, k := range slotOf {
+		if k < 0 {
+			continue
+		}
 		if errs[i] = gpu.SentinelFor(status[k]); errs[i] == nil {
 			o := b.OutOffset(k)
 			res[i] = out[o : o+outLen[k]]

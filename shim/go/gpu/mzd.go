@@ -198,6 +198,145 @@ func DecodeFrames(frames [][]byte) ([][]byte, []error) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// One batch over several GPUs of a node.  Frames share nothing (tables, offset history and window are per frame:
+// framedecompressor.go:42-52), so device r takes a contiguous range of them -- equal counts when the frames cost the
+// same, equal C + D otherwise -- on its own Context and goroutine; results are stitched in frame order.  No collective.
+
+var (
+	poolMu sync.Mutex
+	pool   = map[[2]int]*Context{} // (device, k-th context on it) -> context
+)
+
+func poolContext(device, k int) (*Context, error) {
+	poolMu.Lock()
+	defer poolMu.Unlock()
+	if x, ok := pool[[2]int{device, k}]; ok {
+		return x, nil
+	}
+	x, err := NewContext(device)
+	if err == nil {
+		pool[[2]int{device, k}] = x
+	}
+	return x, err
+}
+
+// DeclaredFrameCost is C + D of one frame from its header alone (frame.go:23-61); a frame that declares no content size
+// counts with its window, anything that is not a frame with its length.
+func DeclaredFrameCost(f []byte) uint64 {
+	n := uint64(len(f))
+	if n < 6 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD {
+		return n
+	}
+	fhd := f[4]
+	fcsFlag, single, did := fhd>>6, (fhd>>5)&1, fhd&3
+	pos := 5
+	window := uint64(128 * 1024)
+	if single == 0 {
+		wd := f[pos]
+		base := uint64(1) << (10 + (wd >> 3))
+		window = base + (base>>3)*uint64(wd&7)
+		pos++
+	}
+	pos += []int{0, 1, 2, 4}[did]
+	fcsBytes := []int{0, 2, 4, 8}[fcsFlag]
+	if fcsFlag == 0 && single == 1 {
+		fcsBytes = 1
+	}
+	if fcsBytes == 0 || pos+fcsBytes > len(f) {
+		return n + window
+	}
+	var d uint64
+	for i := 0; i < fcsBytes; i++ {
+		d |= uint64(f[pos+i]) << (8 * uint(i))
+	}
+	if fcsBytes == 2 {
+		d += 256
+	}
+	return n + d
+}
+
+// ShardFrames returns the frame range [lo, hi) of each of `world` devices.
+func ShardFrames(frames [][]byte, world int) [][2]int {
+	n := len(frames)
+	r := make([][2]int, world)
+	cost := make([]uint64, n)
+	same := true
+	total := 0.0
+	for i, f := range frames {
+		cost[i] = DeclaredFrameCost(f)
+		same = same && cost[i] == cost[0]
+		total += float64(cost[i])
+	}
+	if same {
+		base, extra, lo := n/world, n%world, 0
+		for k := 0; k < world; k++ {
+			hi := lo + base
+			if k < extra {
+				hi++
+			}
+			r[k] = [2]int{lo, hi}
+			lo = hi
+		}
+		return r
+	}
+	acc, target, lo := 0.0, 0.0, 0
+	for k := 0; k < world; k++ {
+		target += total / float64(world)
+		hi := lo
+		for hi < n && (acc+float64(cost[hi]) <= target || hi == lo) && n-hi > world-k-1 {
+			acc += float64(cost[hi])
+			hi++
+		}
+		if k == world-1 {
+			hi = n
+		}
+		r[k] = [2]int{lo, hi}
+		lo = hi
+	}
+	return r
+}
+
+// DecodeFramesOn decodes ONE batch of independent frames on the listed devices (a device listed twice gets two
+// contexts).  out[i] is nil where errs[i] != nil; a device that fails as a whole fails the frames of its range.
+func DecodeFramesOn(devices []int, frames [][]byte) ([][]byte, []error) {
+	if len(devices) == 0 {
+		return DecodeFrames(frames)
+	}
+	out, errs := make([][]byte, len(frames)), make([]error, len(frames))
+	ranges := ShardFrames(frames, len(devices))
+	seen := map[int]int{}
+	var wg sync.WaitGroup
+	for k, d := range devices {
+		lo, hi := ranges[k][0], ranges[k][1]
+		x, err := poolContext(d, seen[d])
+		seen[d]++
+		if hi <= lo {
+			continue
+		}
+		if err != nil {
+			for i := lo; i < hi; i++ {
+				errs[i] = err
+			}
+			continue
+		}
+		wg.Add(1)
+		go func(x *Context, lo, hi int) {
+			defer wg.Done()
+			o, e, err := x.DecodeFrames(frames[lo:hi])
+			for i := lo; i < hi; i++ {
+				if err != nil {
+					errs[i] = err
+				} else {
+					out[i], errs[i] = o[i-lo], e[i-lo]
+				}
+			}
+		}(x, lo, hi)
+	}
+	wg.Wait()
+	return out, errs
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The host-planned route: Go parses headers and table descriptions (north_star), the device runs the three loops.
 
 // Table kinds of mzd_fse_table_desc.kind.
@@ -419,6 +558,25 @@ func (b *Batch) Decode(x *Context) (out []byte, status []int32, outLen []uint64,
 		return nil, nil, nil, errors.New(C.GoString(C.mzd_strerror(rc)) + ": " + x.lastError())
 	}
 	return out, status[:n], outLen[:n], nil // per-frame errors are in status[] (SentinelFor)
+}
+
+// BatchMark is a position in a Batch that Truncate can return to (every slice length and the output size).
+type BatchMark struct {
+	in, frames, blocks, fseTables, fseEntries, hufTables, hufEntries int
+	outSize                                                         uint64
+}
+
+// Mark remembers the batch as it is now; Truncate(mark) drops everything appended since (a frame whose planning failed
+// half-way: its frame slot, blocks, tables, cells and payload bytes), so that the slots of the frames planned afterwards
+// stay consecutive and no unfinished frame reaches the device.
+func (b *Batch) Mark() BatchMark {
+	return BatchMark{len(b.In), len(b.frames), len(b.blocks), len(b.fseTables), len(b.fseEntries), len(b.hufTables), len(b.hufEntries), b.outSize}
+}
+func (b *Batch) Truncate(m BatchMark) {
+	b.In, b.frames, b.blocks = b.In[:m.in], b.frames[:m.frames], b.blocks[:m.blocks]
+	b.fseTables, b.fseEntries = b.fseTables[:m.fseTables], b.fseEntries[:m.fseEntries]
+	b.hufTables, b.hufEntries = b.hufTables[:m.hufTables], b.hufEntries[:m.hufEntries]
+	b.outSize = m.outSize
 }
 
 // OutOffset is where frame i's slab starts in the blob Decode returns.

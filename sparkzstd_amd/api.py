@@ -385,12 +385,99 @@ class Stream:
             pass
 
 
-def decode_frames(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):
+def declared_frame_cost(frame) -> int:
+    """Compressed + declared decompressed bytes of one frame (the C + D a device pass moves for it), from the frame
+    header alone (frame.go:23-61: descriptor byte, window descriptor, dictionary id, Frame_Content_Size).  A frame that
+    declares no content size counts with its window (or 128 KiB); anything that is not a frame with its length."""
+    n = len(frame)
+    if n < 6 or bytes(frame[:4]) != b"\x28\xb5\x2f\xfd":
+        return n
+    fhd = frame[4]
+    fcs_flag, single, did = fhd >> 6, (fhd >> 5) & 1, fhd & 3
+    pos = 5
+    window = 128 * 1024
+    if not single:
+        wd = frame[pos]
+        base = 1 << (10 + (wd >> 3))
+        window = base + (base >> 3) * (wd & 7)
+        pos += 1
+    pos += (0, 1, 2, 4)[did]
+    fcs_bytes = (1 if single else 0, 2, 4, 8)[fcs_flag]
+    if fcs_bytes == 0 or pos + fcs_bytes > n:
+        return n + window
+    d = int.from_bytes(bytes(frame[pos:pos + fcs_bytes]), "little") + (256 if fcs_bytes == 2 else 0)
+    return n + d
+
+
+def shard_frames(frames, world: int):
+    """The contiguous frame range of every one of `world` devices: equal counts when the frames cost the same
+    (sharding.frame_range), equal C + D otherwise (sharding.balanced_ranges).  -> list of (lo, hi)."""
+    from .sharding import frame_range, balanced_ranges
+    costs = [declared_frame_cost(f) for f in frames]
+    if not costs or min(costs) == max(costs):
+        return [frame_range(len(frames), r, world) for r in range(world)]
+    return balanced_ranges(costs, world)
+
+
+_device_pool = {}
+
+
+def device_contexts(devices):
+    """One Context per entry of `devices` (device ids, or Context objects that are taken as they are); a device id that
+    appears twice gets two contexts (two independent streams on one GPU)."""
+    seen, out = {}, []
+    for d in devices:
+        if isinstance(d, Context):
+            out.append(d)
+            continue
+        k = (int(d), seen.get(int(d), 0))
+        seen[int(d)] = k[1] + 1
+        if k not in _device_pool:
+            _device_pool[k] = Context(int(d))
+        out.append(_device_pool[k])
+    return out
+
+
+def decode_frames_multi(frames, devices, device_tables: bool = True, device_plan: bool = False):
+    """One batch of independent frames over several GPUs of one node: frames share nothing (tables, offset history and
+    window are per frame: framedecompressor.go:42-52), so every device takes a contiguous range of them, one host
+    thread and one context per device, and the results are stitched in frame order.  No collective, no RCCL."""
+    import threading
+    ctxs = device_contexts(devices)
+    ranges = shard_frames(frames, len(ctxs))
+    outs, sts = [None] * len(frames), [0] * len(frames)
+    errors = []
+
+    def work(ctx, lo, hi):
+        try:
+            o, s = decode_frames(frames[lo:hi], ctx, device_tables=device_tables, device_plan=device_plan)
+            outs[lo:hi] = o
+            sts[lo:hi] = s
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(c, lo, hi)) for c, (lo, hi) in zip(ctxs, ranges) if hi > lo]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return outs, sts
+
+
+def decode_frames(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False, devices=None):
     """Decodes independent zstd frames (list of bytes) in ONE device batch.
     -> (outputs: list of bytes-or-None, statuses: list of int).  The batched analogue of calling
     sparkzstd's FrameDecompressor.Decompress() (framedecompressor.go:153) once per frame.
     device_tables: FSE tables are shipped as normalised counts and built on the device.
-    device_plan: no host planner at all -- headers are parsed on the device too (Context.upload_frames)."""
+    device_plan: no host planner at all -- headers are parsed on the device too (Context.upload_frames).
+    devices: a list of device ids (or Contexts): the batch is split over them (decode_frames_multi)."""
+    if devices is not None and len(devices) > 0:
+        if len(devices) == 1:
+            ctx = device_contexts(devices)[0]
+        else:
+            return decode_frames_multi(frames, devices, device_tables=device_tables, device_plan=device_plan)
     ctx = ctx or default_context()
     if device_plan:
         frames = [bytes(f) for f in frames]

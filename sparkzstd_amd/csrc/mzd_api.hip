@@ -18,6 +18,7 @@
 #include "mzd_kernels.hip"
 #include "mzd_seq_q4.hip"
 #include "mzd_exec_b.hip"
+#include "mzd_exec_c.hip"
 #include "mzd_exec_blk.hip"
 #include "mzd_parse.hip"
 
@@ -1306,7 +1307,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
     const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 128;
-    if (exec_threads % 64 || exec_threads > 256) return MZD_ERR_INVALID_ARG;
+    if (exec_threads % 64 || exec_threads > MZD_EXEC_MAX_THREADS) return MZD_ERR_INVALID_ARG;
     // LDS chunk of the execution kernel: default 8 KiB (up to 16 workgroups per CU); multiple of 1024
     uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 8192;
     exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
@@ -1315,7 +1316,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (const char *e = exp_env("MZD_EXEC_MIN_LDS")) exec_lds = std::max<size_t>(exec_lds, (size_t)atoi(e));  // experiment: residency cap
     // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
     // overflow L2 and every refill goes to MALL/HBM; a minimum LDS request per workgroup limits the
-    // number of resident wavefronts (opt.huf_min_lds bytes, default 48 KiB -> 3 wavefronts per CU)
+    // number of resident wavefronts (opt.huf_min_lds bytes; 0, the default, = no cap: the same value on the sorted class launches below)
     const size_t huf_lds = std::max<size_t>((size_t)kHufQuads * db->huf_slot_cells * 2, ctx->opt.huf_min_lds);
     if (!ctx->attr_set) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1336,7 +1337,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
-    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 4) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 5) return MZD_ERR_INVALID_ARG;
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1358,12 +1359,17 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // measured (round 3): the 65 536 text-like 128 KiB frames k_exec 10.9 ms, k_exec_b 11.7 ms; the reference's corpus
     // replicated to 4 GiB (frames of 0 to 1 MiB, executed largest first) k_exec 10.1 ms, k_exec_b 9.3 ms
     // (and batches of small frames: 131 072 frames of 4 KiB k_exec 0.98 ms, k_exec_b 0.71 ms)
-    bool exec_b = ctx->opt.exec_variant >= 2 ||
+    // exec_variant 5: k_exec_c (mzd_exec_c.hip: k_exec_b's method, two bytes per lane and pass, fixed-point passes, a lean setup)
+    const bool exec_c = ctx->opt.exec_variant == 5;
+    bool exec_b = (ctx->opt.exec_variant >= 2 && ctx->opt.exec_variant <= 4) ||
                   (ctx->opt.exec_variant == 0 && db->n_seq_tasks > 0 &&
                    (db->d_frame_order != nullptr || db->out_size < (uint64_t)db->n_frames * 32768));
     for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
         if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
     const bool exec_b_serial = exec_b;  // the choice without block mode
+    // k_exec_b takes opt.exec_chunk as EXTRA dynamic LDS on top of its 7.7 KiB (a residency cap), k_exec as its LDS chunk: a value that
+    // suits k_exec (up to 128 KiB) must not make the k_exec_b launch fail -- clamped to what the default 64 KiB limit leaves
+    const uint32_t xb_extra_lds = std::min<uint32_t>(ctx->opt.exec_chunk, 64u * 1024u - (uint32_t)sizeof(XbLds) - 256u);
     // Block mode (mzd_exec_blk.hip): every block its own job, NP passes and a fix-up walk -- for batches whose largest frame is a
     // longer serial job than NP passes over everything.  The model: a frame's workgroup alone makes a 128 KiB block in ~0.42 ms,
     // the chip 5 120 of them in ~0.85 ms; a fix-up step is ~6 us.  (exec_variant 3 forces it: the parity tests.)
@@ -1374,7 +1380,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // 1 GiB frame: 8 192 steps of 1.7 us were 14 of its 22.7 ms), as long as there are jobs enough to fill the chip.
     // (exec_variant 3 forces block mode with segments of one block, 4 with segments of four: the parity tests run both.)
     uint32_t blk_gs = 1;
-    if (db->n_seq_tasks > 0 && db->n_frames > 0 && (ctx->opt.exec_variant == 0 || ctx->opt.exec_variant >= 3)) {
+    if (db->n_seq_tasks > 0 && db->n_frames > 0 && (ctx->opt.exec_variant == 0 || ctx->opt.exec_variant == 3 || ctx->opt.exec_variant == 4)) {
         for (uint32_t f = 0; f < db->n_frames; f++) blk_maxcap = std::max<uint64_t>(blk_maxcap, db->frame_out_cap[f]);
         blk_np = blk_maxcap <= (1u << 23) ? 3u : 4u;
         const double chip = std::max(0.4, (double)db->out_size / kBlockMax / 5120.0 * 0.85);
@@ -1566,7 +1572,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 db->pat_np = blk_np;
             }
             for (uint32_t p = 0; p < blk_np; p++)
-                k_exec_b<true><<<db->n_blocks, 64, ctx->opt.exec_chunk, st>>>(  // (as many wavefronts as blocks: the ones beyond the job list exit)
+                k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(  // (as many wavefronts as blocks: the ones beyond the job list exit)
                     db->d_in, p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
                     db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u,
                     XbBlk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p});
@@ -1585,9 +1591,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;
         }
+        if (exec_c) {
+            k_exec_c<<<count, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf, db->d_status,
+                                           db->d_out_len, db->d_frame_order, first);
+            return;
+        }
         if (exec_b) {
             // (opt.exec_chunk: extra dynamic LDS per frame = a residency cap; frames in flight vs cache footprint of their slabs)
-            k_exec_b<false><<<count, 64, ctx->opt.exec_chunk, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+            k_exec_b<false><<<count, 64, xb_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
                                                                    db->d_litbuf, db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
@@ -1750,6 +1761,14 @@ extern "C" int mzd_debug_xb_stats(unsigned long long *out, int reset)
 {
     if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_xb_stats), sizeof(unsigned long long) * 16);
     if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_xb_stats), z, sizeof z); }
+    return 0;
+}
+#endif
+#ifdef MZD_XC_STATS
+extern "C" int mzd_debug_xc_stats(unsigned long long *out, int reset)
+{
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_xc_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_xc_stats), z, sizeof z); }
     return 0;
 }
 #endif

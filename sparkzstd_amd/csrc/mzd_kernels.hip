@@ -2551,7 +2551,10 @@ __device__ void exec_tile_in_hbm(uint8_t *out, uint64_t outPos, const uint8_t *l
 #ifndef MZD_EXEC_IDLE_SLEEP
 #define MZD_EXEC_IDLE_SLEEP 1  // units of 64 cycles between two polls of a wavefront that found nothing to do
 #endif
-__global__ __launch_bounds__(256, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
+#ifndef MZD_EXEC_MAX_THREADS
+#define MZD_EXEC_MAX_THREADS 256  // experiment builds: up to 1024 (sixteen wavefronts on ONE frame, the whole block in LDS) with MZD_EXEC_WAVES_PER_SIMD=4
+#endif
+__global__ __launch_bounds__(MZD_EXEC_MAX_THREADS, MZD_EXEC_WAVES_PER_SIMD) void k_exec(const uint8_t *__restrict__ in, uint8_t *out_blob,
                                                const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                const BlockSum *__restrict__ sums, const uint64_t *__restrict__ recs,
                                                const TileBase *__restrict__ tiles, const uint8_t *__restrict__ litbuf,

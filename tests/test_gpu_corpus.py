@@ -12,7 +12,7 @@ from tests.conftest import check_expected
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4], ids=["exec_auto", "k_exec", "k_exec_b", "k_exec_b_blocks", "k_exec_b_segments"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4, 5], ids=["exec_auto", "k_exec", "k_exec_b", "k_exec_b_blocks", "k_exec_b_segments", "k_exec_c"])
 def ctx(request):
     """every test that takes `ctx` runs with both execution kernels, the default choice between them, and with the blocks of
     every frame executed side by side (k_exec_b in block mode: what a batch of few large frames takes by default), as jobs of one
@@ -27,7 +27,7 @@ def _decode(frames, ctx):
 
 @pytest.mark.parametrize("seq_variant,exec_threads,exec_variant",
                          [(0, 256, 1), (1, 256, 1), (3, 256, 1), (0, 128, 1), (1, 128, 1), (3, 128, 1), (0, 64, 1), (1, 64, 1), (3, 64, 1),
-                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0), (0, 0, 3), (3, 0, 3), (0, 0, 4)])
+                          (0, 0, 2), (1, 0, 2), (3, 0, 2), (0, 0, 0), (0, 0, 3), (3, 0, 3), (0, 0, 4), (0, 0, 5), (1, 0, 5), (3, 0, 5)])
 def test_decodecorpus_bit_exact_on_gpu(corpus, seq_variant, exec_threads, exec_variant):
     """All 100 golden frames in ONE device batch: multi-block frames, cross-block matches,
     Repeat/Treeless tables, RLE modes, 1-stream literals, windows < 128 KiB."""
@@ -148,7 +148,7 @@ def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
                 b[int(pos)] ^= int(rng.integers(1, 256))
             frames.append(bytes(b))
     res = []
-    for variant in (2, 3, 4):
+    for variant in (2, 3, 4, 5):
         c = z.Context(0, exec_variant=variant)
         plan = z.Plan()
         for f in frames:
@@ -244,7 +244,7 @@ def test_frame_reader_mirror(corpus, ctx):
     check_expected(name, sink.getvalue(), length, sha, exp)
 
 
-@pytest.mark.parametrize("flags", [[], ["--device-plan"]])
+@pytest.mark.parametrize("flags", [[], ["--device-plan"], ["--devices", "0,0"], ["--device-plan", "--devices", "0,0,0"], ["--batch-reader", "7"]])
 def test_cpp_frame_reader_verify_cli(corpus, flags):
     """The C++ mirror of FrameReader (include/sparkzstd_frame.hpp) driven like the reference's own
     harness cmd/sparkzstd/main.go: decode x.zst, compare byte for byte with x."""
@@ -260,6 +260,48 @@ def test_cpp_frame_reader_verify_cli(corpus, flags):
     r = subprocess.run([exe] + flags + files, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Found no diffs in any files" in r.stdout and "Found no unexpected errors" in r.stdout
+
+
+def test_batch_frame_reader_serves_frames_in_order(corpus):
+    """BatchFrameReader: the reference harness's pattern (ONE reader, Reset per frame: framereader.go:35,
+    cmd/sparkzstd/main.go:59,126) with the frames to come known to the reader -- it reads ahead, decodes `lookahead` frames per
+    device batch and serves them in order.  Ragged batches (lookahead 7 over 100 frames), sources as file objects and as
+    bytes, a damaged frame in the middle (its error surfaces at ITS read; the frames behind it are unaffected), an
+    explicit Reset(source), and EOF."""
+    frames = [comp for _, comp, *_ in corpus]
+    srcs = [io.BytesIO(f) if i % 2 else f for i, f in enumerate(frames)]
+    bad_at = 13
+    srcs[bad_at] = io.BytesIO(frames[bad_at][:len(frames[bad_at]) // 2])
+    r = z.BatchFrameReader(iter(srcs), lookahead=7)
+    n = 0
+    while r.Reset():
+        if n == bad_at:
+            with pytest.raises(z.ZstdError):
+                r.Read(10)
+        else:
+            name, comp, length, sha, exp = corpus[n]
+            got = bytearray()
+            while True:
+                d = r.Read(50000)  # short reads, like a caller with a fixed buffer
+                if not d:
+                    break
+                got += d
+            check_expected(name, bytes(got), length, sha, exp)
+        n += 1
+    assert n == len(frames) and r.frames_served == len(frames) and r.Read(1) == b""
+    # Enqueue as the frames become known; Reset(source) puts a frame in front; a wrong magic number is Reset's error
+    r = z.NewBatchFrameReader(lookahead=4)
+    for f in frames[:6]:
+        r.Enqueue(f)
+    assert r.Reset(io.BytesIO(frames[50]))
+    check_expected(corpus[50][0], r.read(), corpus[50][2], corpus[50][3], corpus[50][4])
+    r.Enqueue(b"\x00\x01\x02\x03 not a frame")
+    for k in range(6):
+        assert r.Reset()
+        check_expected(corpus[k][0], r.read(), corpus[k][2], corpus[k][3], corpus[k][4])
+    with pytest.raises(z.ZstdError):
+        r.Reset()
+    assert not r.Reset()
 
 
 def test_raw_rle_frames(ctx):
@@ -301,7 +343,7 @@ def test_corrupt_input_reports_status_not_fault(corpus, ctx):
     check_expected(name, outs2[0], length, sha, exp)
 
 
-@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2), (0, 3), (0, 4)])
+@pytest.mark.parametrize("seq_variant,exec_variant", [(0, 1), (1, 1), (3, 1), (0, 2), (1, 2), (0, 3), (0, 4), (0, 5), (1, 5)])
 def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_variant, exec_variant):
     """Every corpus frame, mutated 6 times (random byte flips past the frame header, seeded), all
     in ONE device batch.  The device must not fault; a frame it reports as decoded must be one

@@ -326,6 +326,44 @@ def test_config4_full_frames_65536_full_size(ctx):
     assert st.n_huf_streams == 4 * 65536 and st.n_sequences > 65536 * 10000
 
 
+def test_config4_shard_of_eight_gpus_8192_frames_full_size(ctx):
+    """BASELINE configs[4]: what ONE of eight GPUs runs -- the 8 192-frame shard of the 65 536-frame batch, at full size
+    (a single round of the sequence stage: 32 chains per CU, the Huffman kernel beside it)."""
+    st = _run_full_config(4, 8192, ctx)
+    assert st.n_huf_streams == 4 * 8192 and st.n_sequences > 8192 * 10000
+
+
+def test_decode_frames_over_two_contexts_splits_and_stitches(corpus):
+    """The multi-GPU entry of the product (decode_frames(devices=[...]) / DecodeFrames): one host thread and one context per
+    listed device, contiguous frame ranges, results in frame order.  On a one-GPU box both contexts sit on device 0.
+    Heterogeneous frames (the corpus: balanced by C + D) and frames of one size (equal counts), against the goldens /
+    the generator's checksums."""
+    import torch
+    from tests.conftest import check_expected
+    from tools import synth_binding as sb
+    devs = [0, 1] if torch.cuda.device_count() >= 2 else [0, 0]
+    frames = [comp for _, comp, *_ in corpus]
+    ranges = z.shard_frames(frames, 2)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == len(frames) and 0 < ranges[0][1] < len(frames)
+    for kw in ({}, {"device_plan": True}):
+        outs, sts = z.decode_frames(frames, devices=devs, **kw)
+        assert sts == [0] * len(frames)
+        for (name, comp, length, sha, exp), got in zip(corpus, outs):
+            check_expected(name, got, length, sha, exp)
+    blob, off, ln, ck, ns = sb.make_batch(4, 5, 257, frame_bytes=16384, threads=4)
+    fr = [blob[int(o):int(o + l)].tobytes() for o, l in zip(off, ln)]
+    assert z.shard_frames(fr, 3) == [(0, 86), (86, 172), (172, 257)]
+    outs, errs = z.DecodeFrames(fr, devices=devs + [0])  # three contexts
+    assert errs == [None] * len(fr)
+    for o, k in zip(outs, ck):
+        assert len(o) == 16384 and sb.checksum64(o) == int(k)
+    # a damaged frame keeps its place and its status
+    bad = list(fr[:9])
+    bad[7] = bad[7][:100]
+    outs, sts = z.decode_frames(bad, devices=devs)
+    assert [s == 0 for s in sts] == [True] * 7 + [False] + [True] and outs[7] is None and outs[8] is not None
+
+
 def test_small_frames_small_sequence_tables_two_workgroups_per_cu(ctx):
     """131072 frames of 4 KiB: ~400 sequences each, so the batch's largest LL / ML / OF tables are small, k_seq_q4 sizes
     its chains' LDS slots to them and two of its workgroups share a CU (and every chain's last step, the loop variant

@@ -204,3 +204,29 @@ def test_split_frames_multi_frame_stream_with_skippable_frames(corpus):
     many = frames[1] * 1500
     rc, off, ln, _, _ = z.split_frames(many)
     assert rc == 0 and len(off) == 1500 and int(off[-1]) == 1499 * len(frames[1])
+
+
+def test_declared_frame_cost_and_shard_ranges(corpus):
+    """Host side of the multi-GPU entry (decode_frames(devices=...)): the cost of a frame is its compressed length plus
+    the content size its header declares (frame.go:23-61); equal costs -> equal counts, else contiguous ranges of
+    roughly equal C + D.  Every frame lands in exactly one range, in order."""
+    from sparkzstd_amd.api import declared_frame_cost, shard_frames
+    declared = 0
+    for name, comp, length, sha, exp in corpus:
+        c = declared_frame_cost(comp)
+        assert c >= len(comp)
+        if c == len(comp) + length:
+            declared += 1
+    assert declared >= 40  # about half of the decodecorpus frames declare their content size; the others count with their window
+    assert declared_frame_cost(b"") == 0 and declared_frame_cost(b"\x28\xb5\x2f\xfd\x20") == 5 and declared_frame_cost(b"junkjunk") == 8
+    frames = [comp for _, comp, *_ in corpus]
+    for world in (1, 2, 3, 8, 128):
+        r = shard_frames(frames, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == len(frames)
+        assert all(r[k][1] == r[k + 1][0] for k in range(world - 1)) and all(lo <= hi for lo, hi in r)
+    r = shard_frames(frames, 4)
+    costs = [declared_frame_cost(f) for f in frames]
+    per = [sum(costs[lo:hi]) for lo, hi in r]
+    assert max(per) <= 2.5 * (sum(costs) / 4) + max(costs)
+    assert shard_frames([b"x" * 10] * 10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_frames([], 2) == [(0, 0), (0, 0)]

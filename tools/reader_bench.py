@@ -26,6 +26,20 @@ assert all(s == 0 for s in sts) and total == sum(len(o) for o in outs)
 print(f"FrameReader, one frame per call: {n / (t1 - t0):.0f} frames/s, {total / (t1 - t0) / 1e6:.0f} MB/s "
       f"({(t1 - t0) / n * 1e3:.2f} ms per frame)")
 print(f"decode_frames, one batch of {n}: {n / (t2 - t1):.0f} frames/s, {total / (t2 - t1) / 1e6:.0f} MB/s (host to host, pageable memory)")
+# the reader that batches: the same reader-shaped consumer (Reset per frame, Read until EOF), the frames to come known to it
+for look in (64, 256):
+    r = z.BatchFrameReader((io.BytesIO(f) for f in frames), lookahead=look)
+    t3 = time.time()
+    tot = 0
+    while r.Reset():
+        while True:
+            d = r.Read(1 << 20)
+            if not d:
+                break
+            tot += len(d)
+    t4 = time.time()
+    assert tot == total
+    print(f"BatchFrameReader, lookahead {look}: {n / (t4 - t3):.0f} frames/s, {tot / (t4 - t3) / 1e6:.0f} MB/s (Reset + Read per frame, host to host)")
 
 # one LARGE frame through the reader (the reference's own usage: cmd/sparkzstd/main.go:59,126): the frame's blocks are executed
 # side by side on the device (mzd_exec_blk.hip); usage: python tools/reader_bench.py <n_frames> <big_frame_bytes>

@@ -4,6 +4,8 @@
 // A first argument --device-plan parses the headers on the device too (k_parse) instead of in the host planner.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <iterator>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -20,6 +22,86 @@ int main(int argc, char **argv)
     if (argc > 1 && std::string(argv[1]) == "--device-plan") {
         sparkzstd::DevicePlanning() = true;
         first = 2;
+    }
+    if (argc > first + 1 && std::string(argv[first]) == "--devices") {
+        // --devices 0,1,...: every file is one frame of ONE batch, split over the listed devices (DecodeFramesOn; a device
+        // listed twice = two contexts on it), results compared in frame order
+        std::vector<int> devices;
+        for (const char *p = argv[first + 1]; *p;) {
+            devices.push_back(atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        std::vector<std::vector<uint8_t>> frames, originals;
+        std::vector<std::string> names;
+        for (int i = first + 2; i < argc; i++) {
+            const std::string path = argv[i];
+            std::ifstream z(path, std::ios::binary), o(path.substr(0, path.size() - 4), std::ios::binary);
+            if (!z || !o) {
+                errs.push_back(path + ": cannot open");
+                continue;
+            }
+            frames.emplace_back(std::istreambuf_iterator<char>(z), std::istreambuf_iterator<char>());
+            originals.emplace_back(std::istreambuf_iterator<char>(o), std::istreambuf_iterator<char>());
+            names.push_back(path);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            std::vector<int> st;
+            const auto out = sparkzstd::DecodeFramesOn(devices, frames, &st);
+            for (size_t i = 0; i < frames.size(); i++) {
+                if (st[i] != MZD_OK) errs.push_back(names[i] + " status " + mzd_strerror(st[i]));
+                else if (out[i] != originals[i]) diffs.push_back(names[i]);
+                bytes += out[i].size();
+            }
+        } catch (const sparkzstd::Error &e) {
+            errs.push_back(std::string("DecodeFramesOn: ") + e.what());
+        }
+        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        first = argc;
+    }
+    if (argc > first + 1 && std::string(argv[first]) == "--batch-reader") {
+        // --batch-reader N: the harness's own loop (one reader, Reset per file, Read until EOF) over a reader that decodes N
+        // frames per device batch and reads ahead
+        const size_t look = (size_t)atoi(argv[first + 1]);
+        sparkzstd::BatchFrameReader br(look);
+        std::vector<std::ifstream> zs;
+        std::vector<std::string> names;
+        for (int i = first + 2; i < argc; i++) {
+            zs.emplace_back(argv[i], std::ios::binary);
+            names.push_back(argv[i]);
+        }
+        for (auto &z : zs) br.Enqueue(&z);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < names.size(); i++) {
+            const std::string original = names[i].substr(0, names[i].size() - 4);
+            std::ifstream o(original, std::ios::binary);
+            try {
+                if (!br.Reset()) {
+                    errs.push_back(names[i] + ": reader ran out of frames");
+                    break;
+                }
+                std::vector<uint8_t> got(1 << 16), want(1 << 16);
+                bool differ = !o;
+                for (;;) {
+                    const size_t n = br.Read(got.data(), got.size());
+                    o.read(reinterpret_cast<char *>(want.data()), (std::streamsize)std::max<size_t>(n, 1));
+                    const size_t m = (size_t)o.gcount();
+                    if (n == 0) {
+                        differ = differ || m != 0;
+                        break;
+                    }
+                    if (m != n || std::memcmp(got.data(), want.data(), n) != 0) differ = true;
+                    bytes += n;
+                }
+                if (differ) diffs.push_back(original);
+            } catch (const sparkzstd::Error &e) {
+                errs.push_back(original + " Decompress-Read Err: " + e.what());
+            }
+        }
+        if (br.Reset()) errs.push_back("reader served more frames than it was given");
+        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        first = argc;
     }
     for (int i = first; i < argc; i++) {
         const std::string path = argv[i];

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Debug helper (GPU box, library built with -DMZD_XC_STATS, selected with MZD_LIB): what k_exec_c's stretches and passes do."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sparkzstd_amd as z
+from sparkzstd_amd import _lib
+from tools import synth_binding as sb
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+blob, off, ln, ck, ns = sb.make_batch(4, 0, n, threads=8)
+frames = [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+ctx = z.Context(0, exec_variant=5)
+L = _lib.load()
+buf = (ctypes.c_ulonglong * 16)()
+outs, sts = z.decode_frames(frames, ctx)  # warm
+L.mzd_debug_xc_stats(buf, 1)
+outs, sts = z.decode_frames(frames, ctx)
+assert all(s == 0 for s in sts)
+L.mzd_debug_xc_stats(buf, 0)
+names = ["tiles", "stretches", "passes (128 B)", "extra fixed-point rounds", "passes resolved by pointer jumping", "passes that went to memory",
+         "staged matches", "matches", "cycles setup", "cycles plan + flush", "cycles passes", "cycles total", "frames", "stretches on the general path"]
+t = max(buf[0], 1)
+for i, nm in enumerate(names):
+    print(f"{nm:36s} {buf[i]:14d}  per tile {buf[i] / t:10.3f}")
+print("cycles per pass", buf[10] / max(buf[2], 1), " other per tile", (buf[11] - buf[8] - buf[9] - buf[10]) / t)
