@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 4
+#define MZD_ABI_VERSION 5
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -92,6 +92,8 @@ typedef struct mzd_frame_desc {
     uint32_t flags;         /* MZD_FRAME_* */
 } mzd_frame_desc;
 #define MZD_FRAME_HAS_CHECKSUM 1u /* Content_Checksum_flag set (frame.go:106-108) and the 4 bytes were there */
+#define MZD_FRAME_PLAN_STATUS_SHIFT 8 /* bits 8..15: the MZD_ERR_* with which the planner gave the frame up (it then has no
+                                        blocks); 0 = planned.  The device reports it as the frame's status. */
 
 /* One block (block.go:22-26 BlockHeader + the slices the reference's section
  * parsers produce: literals.go:30-41,283-361, sequences.go:371-433). Offsets are
@@ -226,7 +228,8 @@ typedef struct mzd_options {
                                  byte, strictly in order; 7.7 KiB of LDS per frame); 3 = k_exec_b in BLOCK MODE (a wavefront
                                  per block: the blocks of a frame side by side, 3 or 4 passes + an in-order fix-up walk;
                                  frames below 2 GiB) -- what 0 picks for batches of few large frames; 4 = the same with jobs
-                                 of four consecutive blocks (fewer fix-up steps; 0 picks the job size by the batch); see DESIGN.md */
+                                 of four consecutive blocks (fewer fix-up steps; 0 picks the job size by the batch); 5 = k_exec_c
+                                 (k_exec_b's method, two bytes per lane and pass, fixed-point passes) */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);
@@ -377,6 +380,11 @@ int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset
  * (reversebitstream.go:13-15: -1 == exactly empty, below: over-read, which reads zeros :23-27,67-75). */
 int mzd_debug_backbits(mzd_ctx *ctx, const uint8_t *stream, uint32_t len, const uint8_t *nbits, uint32_t n_reads,
                        uint64_t *values, int64_t *bits_still);
+
+/* Test hook of block mode's fix-up walk (mzd_exec_blk.hip): with step > 0, workgroup 1 of every frame gives up waiting at that
+ * step of the walk, as it would if its siblings were not resident; the rescue launch then has to finish the frame.  0 (the
+ * default) = off.  For the parity tests only: a decoded frame never depends on it. */
+int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step);
 
 /* ------------------------------------------------------------------ host planner
  * C++ restatement of the reference's host side, exposed in C so that tests, the

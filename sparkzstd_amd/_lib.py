@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 4
+MZD_ABI_VERSION = 5
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -24,7 +24,7 @@ EXPORTS = [
     "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table", "mzd_batch_read_huf_table",
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
-    "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits",
+    "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
 ]
 
 MZD_DEBUG_LITERALS, MZD_DEBUG_RECORDS, MZD_DEBUG_TILES, MZD_DEBUG_BLOCKS = 0, 1, 2, 3
@@ -164,6 +164,7 @@ def load():
         "mzd_measure_copy": (i32, [vp, u64, u64, i32, ctypes.POINTER(ctypes.c_float)]),
         "mzd_batch_debug_read": (i32, [vp, vp, i32, u64, vp, u64]),
         "mzd_debug_backbits": (i32, [vp, vp, u32, vp, u32, vp, vp]),
+        "mzd_debug_force_fixup_bail": (i32, [vp, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -479,46 +479,52 @@ def decode_frames(frames, ctx: Context = None, device_tables: bool = True, devic
         else:
             return decode_frames_multi(frames, devices, device_tables=device_tables, device_plan=device_plan)
     ctx = ctx or default_context()
+    out, lay, out_len, sts = decode_frames_blob(frames, ctx, device_tables=device_tables, device_plan=device_plan)
+    outs = []
+    for i in range(len(sts)):
+        o = int(lay[i])
+        outs.append(out[o:o + int(out_len[i])].tobytes() if sts[i] == 0 else None)
+    return outs, sts
+
+
+def decode_frames_blob(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):
+    """decode_frames without the per-frame copies: -> (output blob np.uint8[], slab offset of every frame, out_len of every
+    frame, statuses).  Frame i is blob[offset[i] : offset[i] + out_len[i]] when its status is 0.  The input is laid out
+    ONCE (a single frame is not copied at all) and the host planner adopts it in place (mzd_plan_add_frames): for one
+    large frame -- the reference's own usage, one frame per reader -- the copies used to be most of the host side."""
+    ctx = ctx or default_context()
+    n = len(frames)
+    if n == 1:
+        blob = np.frombuffer(frames[0], dtype=np.uint8)
+    else:
+        blob = np.frombuffer(b"".join(bytes(f) if not isinstance(f, (bytes, bytearray)) else f for f in frames), dtype=np.uint8)
+    ln = np.array([len(f) for f in frames], dtype=np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        off[1:] = np.cumsum(ln)[:-1]
     if device_plan:
-        frames = [bytes(f) for f in frames]
-        ln = np.array([len(f) for f in frames], dtype=np.uint64)
-        off = np.zeros(len(frames), dtype=np.uint64)
-        if len(frames) > 1:
-            off[1:] = np.cumsum(ln)[:-1]
-        rb = ctx.upload_frames(b"".join(frames), off, ln)
+        rb = ctx.upload_frames(blob, off, ln)
         try:
             rb.run()
             out, status, out_len = rb.download()
             lay = rb.frame_out_offset
         finally:
             rb.free()
-        outs, sts = [], [int(x) for x in status]
-        for i in range(len(frames)):
-            o = int(lay[i])
-            outs.append(out[o:o + int(out_len[i])].tobytes() if sts[i] == 0 else None)
-        return outs, sts
+        return out, np.asarray(lay, dtype=np.uint64), out_len, [int(x) for x in status]
     plan = Plan(device_tables=device_tables)
     try:
-        plan_status = []
-        for f in frames:
-            rc, _ = plan.add_frame(bytes(f))
-            plan_status.append(rc)
+        if blob.size == 0:
+            blob = np.zeros(1, dtype=np.uint8)
+        plan.add_frames(blob, off, ln, threads=0)
         batch = plan.finalize()
+        plan_status = [plan.frame_status(i) for i in range(n)]
+        lay = np.array([int(batch.frames[i].out_offset) for i in range(n)], dtype=np.uint64)
         rb = ctx.upload(batch)
         try:
             rb.run()
             out, status, out_len = rb.download()
         finally:
             rb.free()
-        outs, sts = [], []
-        for i in range(len(frames)):
-            st = plan_status[i] or int(status[i])
-            sts.append(st)
-            if st == 0:
-                o = int(batch.frames[i].out_offset)
-                outs.append(out[o:o + int(out_len[i])].tobytes())
-            else:
-                outs.append(None)
-        return outs, sts
+        return out, lay, out_len, [plan_status[i] or int(status[i]) for i in range(n)]
     finally:
         plan.close()

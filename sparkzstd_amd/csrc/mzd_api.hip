@@ -38,6 +38,7 @@ struct mzd_ctx {
     size_t runs = 0;
     bool timing = true;
     bool attr_set = false;
+    uint32_t test_fixup_bail = 0;  // mzd_debug_force_fixup_bail: workgroup 1 of every frame gives up at this step of the fix-up walk
 };
 
 // temporaries of the device-side planning pass (kept by a streaming slot, freed at once otherwise)
@@ -125,6 +126,8 @@ struct mzd_dbatch {
     BJob *d_jobs = nullptr;
     uint32_t *d_heads = nullptr;  // [0] number of jobs, [1 + j] first block of job j
     BFrame *d_bframes = nullptr;
+    uint32_t *d_fixdone = nullptr;  // block mode: steps each fix-up workgroup of a frame finished (64 per frame)
+    size_t cap_fixdone = 0;
     uint8_t *d_planes = nullptr;  // (passes - 1) copies of the output layout
     uint8_t *d_pat = nullptr;     // the passes' patterns, by frame-relative position
     size_t cap_jobs = 0, cap_heads = 0, cap_bframes = 0, cap_planes = 0, cap_pat = 0;
@@ -365,6 +368,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_jobs);
     (void)hipFree(db->d_heads);
     (void)hipFree(db->d_bframes);
+    (void)hipFree(db->d_fixdone);
     (void)hipFree(db->d_planes);
     (void)hipFree(db->d_pat);
     free_parse_temps(db->tmp);
@@ -511,6 +515,11 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         if ((uint64_t)fd.first_block + fd.n_blocks > b->n_blocks || (fd.out_offset & 15) ||
             fd.out_offset > b->out_size || fd.out_capacity > b->out_size - fd.out_offset) {
             df.plan_status = MZD_ERR_INVALID_ARG;
+            df.n_blocks = 0;
+            continue;
+        }
+        if (const uint32_t ps = (fd.flags >> MZD_FRAME_PLAN_STATUS_SHIFT) & 0xFFu) {  // the planner gave this frame up
+            df.plan_status = (int32_t)ps;
             df.n_blocks = 0;
             continue;
         }
@@ -1138,6 +1147,44 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
         (flags & ~(uint32_t)(MZD_BATCH_IN_ON_DEVICE | MZD_BATCH_OUT_ON_DEVICE)) || ((flags & MZD_BATCH_OUT_ON_DEVICE) && !out_dev))
         return MZD_ERR_INVALID_ARG;
     *out = nullptr;
+    // k_parse gives a FRAME one lane: right for batches of many frames (65 536 frames in 1 ms), hopeless for one large frame -- its
+    // blocks are walked one by one, 0.29 ms each (a 256 MiB frame: 599 ms), where the host planner goes through 64 MiB of frame
+    // per millisecond on one thread (frames in parallel on all of them).  A batch with a frame of kHostPlanFrameBytes or more is
+    // therefore planned by the host planner here too (a blob that is resident on the device is copied back once for it): same
+    // descriptors, same statuses (the two planners agree frame for frame: tests/test_gpu_corpus.py::test_device_planner_*),
+    // same layout calls afterwards.
+    constexpr uint64_t kHostPlanFrameBytes = 4ull << 20;
+    uint64_t longest = 0;
+    for (uint32_t i = 0; i < n_frames; i++) longest = std::max(longest, frame_len[i]);
+    if (longest >= kHostPlanFrameBytes) {
+        for (uint32_t i = 0; i < n_frames; i++)
+            if (frame_off[i] > in_size || frame_len[i] > in_size - frame_off[i]) return MZD_ERR_INVALID_ARG;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        std::vector<uint8_t> back;
+        const uint8_t *host = in;
+        if (flags & MZD_BATCH_IN_ON_DEVICE) {
+            back.resize(in_size);
+            HIP_TRY(ctx, hipMemcpy(back.data(), in, in_size, hipMemcpyDeviceToHost));
+            host = back.data();
+        }
+        mzd_plan *plan = mzd_plan_create();
+        mzd_plan_set_device_tables(plan, 1);
+        (void)mzd_plan_add_frames(plan, host, frame_off, frame_len, n_frames, 0);  // (per-frame statuses travel in the descriptors)
+        mzd_batch run = *mzd_plan_finalize(plan);
+        if (flags & MZD_BATCH_IN_ON_DEVICE) {
+            run.in = in;
+            run.flags |= MZD_BATCH_IN_ON_DEVICE;
+        }
+        int rc = MZD_OK;
+        if (flags & MZD_BATCH_OUT_ON_DEVICE) {
+            if (out_dev_size < run.out_size) rc = MZD_ERR_DST_FULL;
+            run.out = out_dev;
+            run.flags |= MZD_BATCH_OUT_ON_DEVICE;
+        }
+        if (rc == MZD_OK) rc = mzd_batch_upload(ctx, &run, out);
+        mzd_plan_destroy(plan);
+        return rc;
+    }
     return upload_frames_impl(ctx, in, in_size, flags, frame_off, frame_len, n_frames, out_dev, out_dev_size, nullptr, ctx->stream, out);
 }
 
@@ -1359,13 +1406,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // measured (round 3): the 65 536 text-like 128 KiB frames k_exec 10.9 ms, k_exec_b 11.7 ms; the reference's corpus
     // replicated to 4 GiB (frames of 0 to 1 MiB, executed largest first) k_exec 10.1 ms, k_exec_b 9.3 ms
     // (and batches of small frames: 131 072 frames of 4 KiB k_exec 0.98 ms, k_exec_b 0.71 ms)
-    // exec_variant 5: k_exec_c (mzd_exec_c.hip: k_exec_b's method, two bytes per lane and pass, fixed-point passes, a lean setup)
-    const bool exec_c = ctx->opt.exec_variant == 5;
-    bool exec_b = (ctx->opt.exec_variant >= 2 && ctx->opt.exec_variant <= 4) ||
-                  (ctx->opt.exec_variant == 0 && db->n_seq_tasks > 0 &&
-                   (db->d_frame_order != nullptr || db->out_size < (uint64_t)db->n_frames * 32768));
-    for (uint32_t f = 0; exec_b && f < db->n_frames; f++)
-        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_b = false;
+    // Round 4: k_exec_c (mzd_exec_c.hip: k_exec_b's method, two bytes per lane and pass, fixed-point passes, a lean setup) is what
+    // exec_variant 0 takes for every batch with sequences whose frames are below 4 GiB (k_exec_b and k_exec_c keep frame
+    // positions in 32 bits) -- measured against k_exec / k_exec_b, whole pass (profiles/r4_exec_matrix.txt): 65 536 x 128 KiB
+    // 20.0 against 21.05 / 21.3 ms; 32 768 / 16 384 / 8 192 frames 10.76 / 6.26 / 3.25 against 11.14 / 6.52 / 3.58 and 11.38 / 6.75 /
+    // 3.60; 8 192 x 1 MiB 25.7 against 27.8 / 28.0; 131 072 x 4 KiB 1.92 against 2.38 / 2.06; the corpus 17.3 against 18.6 / 17.2.
+    // k_exec stays for frames of 4 GiB and more and (variant 1) for the parity tests; k_exec_b for block mode and (2) the tests.
+    bool exec_c = ctx->opt.exec_variant == 5 || (ctx->opt.exec_variant == 0 && db->n_seq_tasks > 0);
+    for (uint32_t f = 0; exec_c && f < db->n_frames; f++)
+        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_c = false;
+    bool exec_b = ctx->opt.exec_variant >= 2 && ctx->opt.exec_variant <= 4;
     const bool exec_b_serial = exec_b;  // the choice without block mode
     // k_exec_b takes opt.exec_chunk as EXTRA dynamic LDS on top of its 7.7 KiB (a residency cap), k_exec as its LDS chunk: a value that
     // suits k_exec (up to 128 KiB) must not make the k_exec_b launch fail -- clamped to what the default 64 KiB limit leaves
@@ -1390,7 +1440,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.42, chip);
         const double t_blk = blk_np * chip * 1.12 + (double)db->out_size / (1u << 30) * 5.0 + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
         blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant >= 3 || t_blk < 0.85 * t_serial);
-        if (blk) exec_b = true;
+        if (blk) {
+            exec_b = true;
+            exec_c = false;
+        }
         if (ctx->opt.exec_variant == 4) blk_gs = 4;
         else if (ctx->opt.exec_variant == 0) {
             // (one 1 GiB frame, jobs of 1 / 4 blocks: passes 4 x 1.9 / 2.9 ms, fix-up 12.6 / 5.1 ms; 64 x 128 MiB: 65.4 / 67.3 ms per
@@ -1416,13 +1469,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
                          ensure(db->d_heads, db->cap_heads, ((size_t)db->n_blocks + 2) * 4) == hipSuccess &&
                          ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
+                         ensure(db->d_fixdone, db->cap_fixdone, (size_t)std::min<uint32_t>(db->n_frames, 1024u) * 64 * sizeof(uint32_t)) == hipSuccess &&
                          ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256) == hipSuccess &&
                          ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride) == hipSuccess;
         if (db->cap_pat != pat_before) db->pat_n = db->pat_np = 0;
         if (!got) {
             (void)hipGetLastError();
             blk = false;
-            exec_b = exec_b_serial || ctx->opt.exec_variant == 3;
+            exec_b = exec_b_serial || ctx->opt.exec_variant >= 3;
+            exec_c = ctx->opt.exec_variant == 0;
         }
     }
     const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
@@ -1582,12 +1637,25 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // workgroup is a poller of its frame's counter)
             uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(64u, 1024u / db->n_frames);
             if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::max(1, atoi(e));  // experiment
-            if (blk_np == 3)
-                k_blk_fixup<3><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
-                                                               db->d_bframes, G, blk_gs);
-            else
-                k_blk_fixup<4><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
-                                                               db->d_frames, db->d_jobs, db->d_bframes, G, blk_gs);
+            // (G > 1: the workgroups of a frame wait for each other.  Should some of them not be resident -- another stream or
+            // process on the GPU --, the waiters give up after a bounded wait and a second launch, one workgroup per such frame,
+            // finishes the frame's walk from what `d_fixdone` says each workgroup got done: slower, never wrong, never a hang)
+            if (G > 1) (void)hipMemsetAsync(db->d_fixdone, 0, (size_t)db->n_frames * 64 * sizeof(uint32_t), st);
+            const uint32_t tb = ctx->test_fixup_bail;
+            if (blk_np == 3) {
+                k_blk_fixup<3, false><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames,
+                                                                      db->d_jobs, db->d_bframes, G, blk_gs, db->d_fixdone, tb);
+                if (G > 1)
+                    k_blk_fixup<3, true><<<db->n_frames, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
+                                                                       db->d_bframes, G, blk_gs, db->d_fixdone, 0u);
+            } else {
+                k_blk_fixup<4, false><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride,
+                                                                      db->d_planes + 2 * stride, db->d_frames, db->d_jobs, db->d_bframes, G, blk_gs,
+                                                                      db->d_fixdone, tb);
+                if (G > 1)
+                    k_blk_fixup<4, true><<<db->n_frames, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
+                                                                       db->d_frames, db->d_jobs, db->d_bframes, G, blk_gs, db->d_fixdone, 0u);
+            }
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;
         }
@@ -1620,16 +1688,21 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (db->n_huf_tasks == 0 && db->n_seq_tasks == 0 && db->stats.n_blocks[2] == 0) {
         // Nothing but Raw / RLE blocks (BASELINE configs[1]): the pass IS the copy kernel -- no summaries to reset,
         // no second stream, no cross-stream events in front of it (they cost more than the 0.2 ms copy itself).
+        // (two events, not nine: an event record costs the stream 3-5 us, and this pass is 0.2 ms)
         if (ev) {
-            for (int i : {0, 1, 3, 9, 2, 4}) HIP_TRY(ctx, hipEventRecord(ev[i], s));
-            ctx->run_split[ctx->runs] = false;
+            HIP_TRY(ctx, hipEventRecord(ev[4], s));
+            ctx->run_split[ctx->runs] = 4;  // bit 2: a copy-only pass -- only ev[4], ev[5] (and ev[11] with checksums) were recorded
         }
-        launch_exec(s, 0, db->n_frames);
+        // (exec_variant 0: the chunked copy kernel; a forced variant: that kernel's own copy arms, as the parity tests want them)
+        if (ctx->opt.exec_variant == 0 && !no_exec && db->n_frames > 0)
+            k_copy_blocks<<<(uint32_t)std::min<uint64_t>((uint64_t)db->n_frames * kCopyChunksPerBlock, (uint64_t)std::max(ctx->num_cus, 1) * 8), 256, 0, s>>>(
+                db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_status, db->d_out_len, db->d_frame_order, 0u, db->n_frames);
+        else
+            launch_exec(s, 0, db->n_frames);
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
         launch_verify(s, 0, db->n_frames);
         if (ev) {
-            HIP_TRY(ctx, hipEventRecord(ev[11], s));
-            HIP_TRY(ctx, hipEventRecord(ev[8], s));
+            if (ctx->opt.verify_checksum) HIP_TRY(ctx, hipEventRecord(ev[11], s));
             ctx->runs++;
         }
         HIP_TRY(ctx, hipGetLastError());
@@ -1872,6 +1945,13 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
     for (size_t r = 0; r < ctx->runs; r++) {
         hipEvent_t *e = ctx->ev.data() + r * kEvPerRun;
         const bool split = ctx->run_split[r] & 1, huf_first = ctx->run_split[r] & 2;
+        if (ctx->run_split[r] & 4) {  // a copy-only pass (Raw / RLE blocks only)
+            acc[3] += el(e[4], e[5]);
+            acc[4] += el(e[4], ctx->opt.verify_checksum ? e[11] : e[5]);
+            if (ctx->opt.verify_checksum) acc[5] += el(e[5], e[11]);
+            cnt++;
+            continue;
+        }
         acc[0] += el(e[0], e[1]);
         acc[1] += el(e[9], e[2]);                                           // k_huf (second stream, or first on the caller's)
         // k_seq head (+ tail, incl. its wait for k_huf); with k_huf first on the same stream the head starts at ITS end
@@ -1947,6 +2027,13 @@ int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (bytes) HIP_TRY(ctx, hipMemcpy(dst, (const uint8_t *)base + offset, bytes, hipMemcpyDeviceToHost));
+    return MZD_OK;
+}
+
+int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step)
+{
+    if (!ctx) return MZD_ERR_INVALID_ARG;
+    ctx->test_fixup_bail = step;
     return MZD_OK;
 }
 

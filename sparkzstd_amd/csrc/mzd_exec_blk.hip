@@ -301,16 +301,34 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
             mA[q] = ((ma & 1u) * 0xFFu) | ((ma & 2u) * 0x7F80u) | ((ma & 4u) * 0x3FC000u) | ((ma & 8u) * 0x1FE00000u);  // bit i -> byte i
             mB[q] = ((mb & 1u) * 0xFFu) | ((mb & 2u) * 0x7F80u) | ((mb & 4u) * 0x3FC000u) | ((mb & 8u) * 0x1FE00000u);
         }
-        uint32_t vA[4], vB[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            vA[q] = vB[q] = 0;
-            if (hasA[q]) vA[q] = __hip_atomic_load((const uint32_t *)(p0 + ldA[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (byte-aligned)
-            if (hasB[q]) vB[q] = __hip_atomic_load((const uint32_t *)(p0 + ldB[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // the single bytes first (the compiler's own loads), the eight dwords behind them: one wait for all of them
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if (get[j]) b8[j] = __hip_atomic_load(p0 + b8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (Four-byte agent-scope loads at BYTE-aligned addresses: the hardware takes them, C++ has no name for them -- an atomic
+        // load through a misaligned uint32_t pointer is undefined behaviour for the compiler -- so the eight of a chunk are
+        // written out, issued together, one wait behind them.  A dword without a group reads the chunk's own position.)
+        uint32_t vA[4], vB[4];
+        {
+            const uint8_t *aA[4], *aB[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                aA[q] = p0 + (hasA[q] ? ldA[q] : C.x[k] + 4u * (uint32_t)q);
+                aB[q] = p0 + (hasB[q] ? ldB[q] : C.x[k] + 4u * (uint32_t)q);
+            }
+            asm volatile("global_load_dword %0, %8, off sc1\n\t"
+                         "global_load_dword %1, %9, off sc1\n\t"
+                         "global_load_dword %2, %10, off sc1\n\t"
+                         "global_load_dword %3, %11, off sc1\n\t"
+                         "global_load_dword %4, %12, off sc1\n\t"
+                         "global_load_dword %5, %13, off sc1\n\t"
+                         "global_load_dword %6, %14, off sc1\n\t"
+                         "global_load_dword %7, %15, off sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(vA[0]), "=&v"(vA[1]), "=&v"(vA[2]), "=&v"(vA[3]), "=&v"(vB[0]), "=&v"(vB[1]), "=&v"(vB[2]), "=&v"(vB[3])
+                         : "v"(aA[0]), "v"(aA[1]), "v"(aA[2]), "v"(aA[3]), "v"(aB[0]), "v"(aB[1]), "v"(aB[2]), "v"(aB[3])
+                         : "memory");
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             o[q] |= (vA[q] & mA[q]) | (vB[q] & mB[q]);
@@ -322,28 +340,37 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
     }
 }
 
-template <int NP>
+// RESCUE = false: the walk proper.  RESCUE = true: ONE workgroup per frame finishes the walk of a frame whose workgroups gave up
+// waiting for each other (`bail`: siblings that were not resident -- the launch is sized so that they are, but nothing promises it
+// when another stream or process shares the GPU).  A step's gathers are all-or-nothing per workgroup (a workgroup gives up only
+// at the wait in front of them) and `done[g]` says how many steps workgroup g finished, so the rescue redoes exactly the chunk
+// sets that were not gathered, step by step, without waiting for anybody: the frame is decoded instead of failing with
+// MZD_ERR_DEVICE.  (A chunk that WAS gathered must not be looked at again: which bytes are derived is read from the slab's own
+// pass-0 bytes.)
+template <int NP, bool RESCUE>
 __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
                                                    const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G,
-                                                   uint32_t gs)
+                                                   uint32_t gs, uint32_t *done, uint32_t test_bail_step)
 {
     // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised): with several workgroups per
     // frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a step's hand-off
     // stays inside one L2
     uint32_t w = blockIdx.x;
-    if (G > 1) {
+    if (!RESCUE && G > 1) {
         w = blockIdx.x >> 3;
         if ((blockIdx.x & 7) != ((w / G) & 7)) return;
     }
-    const uint32_t f = w / G, g = w % G, tid = threadIdx.x;
+    const uint32_t f = RESCUE ? w : w / G, g0 = RESCUE ? 0u : w % G, tid = threadIdx.x;
     const DFrame fr = frames[f];
     BFrame *bf = &bframes[f];
+    if (RESCUE && !bf->bail) return;
     const uint32_t nb = min(bf->n_ok, bf->first_bad);  // blocks [0, nb) executed without a defect
     uint8_t *p0 = out_blob + fr.out_offset;
     const uint8_t *p1 = pl1 + fr.out_offset;
     const uint8_t *p2 = pl2 + fr.out_offset;                    // (NP == 3: this is the last plane)
     const uint8_t *pE = (NP == 4 ? pl3 : pl2) + fr.out_offset;
     const uint32_t cstep = G * 256;
+    uint32_t *fdone = done + (size_t)f * 64;
     __shared__ uint32_t go;
     // the frame's jobs after its first (which derives nothing: its blocks follow each other inside one job), in order.
     // (Loading the NEXT job's extent and plane bytes while this job's step runs -- a software pipeline over the jobs -- made the
@@ -359,72 +386,85 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
             bi++;
             continue;
         }
-        uint32_t e = bi + 1;  // the job: blocks [bi, e)
+        // the job: blocks [bi, e) -- up to the next head, and not beyond the blocks that executed (k_exec_b<true> stops at a
+        // skipped block and at the first block that failed: the blocks of the job before that one ran and are fixed up, as the
+        // serial walk would have left them)
+        uint32_t e = bi + 1;
         BJob je = c[0];
 #pragma unroll
         for (int q = 1; q < 5; q++)
-            if (e == bi + (uint32_t)q && e < fr.n_blocks && !(c[q].flags & kBjHead)) {
+            if (e == bi + (uint32_t)q && e < nb && !(c[q].flags & (kBjHead | kBjSkip))) {
                 je = c[q];
                 e++;
             }
         if (e == bi + 5)  // (jobs of more than five blocks: experiments only)
-            while (e < fr.n_blocks && !(jobs[fr.first_block + e].flags & kBjHead)) {
+            while (e < nb && !(jobs[fr.first_block + e].flags & (kBjHead | kBjSkip))) {
                 je = jobs[fr.first_block + e];
                 e++;
             }
-        if (e > nb) break;  // a job that did not execute whole: the frame has failed, nothing after it matters
         bi = e;
         if (!(jb.flags & kBjDirect)) {
             const uint32_t S = jb.start, n = je.start + je.len - jb.start;
             const uint32_t nchunks = n >> 4;
-            FixChunks<NP> C;
-            fix_load<NP>(C, p0, p1, p2, pE, S, n, g * 256 + tid, cstep);  // (nothing here was written by this kernel)
-            if (G > 1 && steps > 0) {
-                // every workgroup of the frame is done with the jobs before this one (a bounded wait: all of them are
-                // resident -- the launch is sized for that -- but a hang is not an acceptable failure mode)
-                if (tid == 0) {
-                    uint32_t it = 0, ok = 1;
-                    const uint32_t target = G * steps;
-                    while (__hip_atomic_load(&bf->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++it > 4000000u || __hip_atomic_load(&bf->bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            ok = 0;
-                            break;
+            for (uint32_t g = g0; g < (RESCUE ? G : g0 + 1); g++) {
+                if (RESCUE && fdone[g] > steps) continue;  // workgroup g gathered its chunks of this step
+                FixChunks<NP> C;
+                fix_load<NP>(C, p0, p1, p2, pE, S, n, g * 256 + tid, cstep);  // (nothing here was written by this kernel)
+                if (!RESCUE && G > 1 && steps > 0) {
+                    // every workgroup of the frame is done with the jobs before this one (a bounded wait: all of them are
+                    // resident -- the launch is sized for that -- but a hang is not an acceptable failure mode)
+                    if (tid == 0) {
+                        uint32_t it = 0, ok = 1;
+                        const uint32_t target = G * steps;
+                        while (__hip_atomic_load(&bf->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                            __builtin_amdgcn_s_sleep(4);
+                            if (++it > 4000000u || __hip_atomic_load(&bf->bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                ok = 0;
+                                break;
+                            }
                         }
+                        if (test_bail_step && steps >= test_bail_step && g == 1) ok = 0;  // (mzd_debug_force_fixup_bail: the tests' way into the rescue)
+                        go = ok;
                     }
-                    go = ok;
+                    __syncthreads();
+                    if (!go) {
+                        if (tid == 0) __hip_atomic_store(&bf->bail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
                 }
-                __syncthreads();
-                if (!go) {
-                    if (tid == 0) __hip_atomic_store(&bf->bail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-            }
-            fix_gather<NP>(C, p0, S);
-            for (uint32_t c0 = g * 256 + tid + kFixK * cstep; c0 < nchunks; c0 += kFixK * cstep) {
-                fix_load<NP>(C, p0, p1, p2, pE, S, n, c0, cstep);
                 fix_gather<NP>(C, p0, S);
-            }
-            if (g == 0 && tid < (n & 15)) {  // the job's last bytes
-                const uint32_t x = S + (n & ~15u) + tid;
-                const uint32_t aj = p0[x], dj = aj ^ pE[x];
-                if (dj) {
-                    uint32_t org = aj | ((uint32_t)p1[x] << 8);
-                    if (NP == 4) org |= (uint32_t)p2[x] << 16;
-                    org |= (dj - 1) << (8 * (NP - 1));
-                    *(volatile uint8_t *)(p0 + x) = org < S ? *(const volatile uint8_t *)(p0 + org) : (uint8_t)0;
+                for (uint32_t c0 = g * 256 + tid + kFixK * cstep; c0 < nchunks; c0 += kFixK * cstep) {
+                    fix_load<NP>(C, p0, p1, p2, pE, S, n, c0, cstep);
+                    fix_gather<NP>(C, p0, S);
+                }
+                if (g == 0 && tid < (n & 15)) {  // the job's last bytes
+                    const uint32_t x = S + (n & ~15u) + tid;
+                    const uint32_t aj = p0[x], dj = aj ^ pE[x];
+                    if (dj) {
+                        uint32_t org = aj | ((uint32_t)p1[x] << 8);
+                        if (NP == 4) org |= (uint32_t)p2[x] << 16;
+                        org |= (dj - 1) << (8 * (NP - 1));
+                        *(volatile uint8_t *)(p0 + x) = org < S ? *(const volatile uint8_t *)(p0 + org) : (uint8_t)0;
+                    }
                 }
             }
         }
         steps++;
-        if (G > 1) {
+        if (RESCUE) {
+            xb_wait_vm();
+            __syncthreads();  // (one workgroup; its stores write through and its gathers are agent-scope loads)
+        } else if (G > 1) {
             xb_wait_vm();  // this thread's stores of the step have reached memory
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&bf->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                fdone[g0] = steps;
+                __hip_atomic_fetch_add(&bf->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             __syncthreads();  // (one workgroup: its own stores are visible to it)
         }
     }
+    if (RESCUE && tid == 0) bf->bail = 0u;  // the frame is whole: k_blk_final reports what the walk found
 }
 
 // ---- status and length of every frame, as the serial walk reports them

@@ -30,7 +30,10 @@
 
 namespace mzd {
 
-constexpr uint32_t kXcWin = 4096;      // window ring at LDS offset 0 of the frame's block
+#ifndef MZD_XC_WIN
+#define MZD_XC_WIN 4096
+#endif
+constexpr uint32_t kXcWin = MZD_XC_WIN;  // window ring at LDS offset 0 of the frame's block (a power of two, 4 KiB at least)
 constexpr uint32_t kXcLit = 512;       // literals of the current stretch
 constexpr uint32_t kXcStageMl = 32;    // longest match that is staged: 32 source bytes per sequence lane
 constexpr uint32_t kXcStage = 64 * kXcStageMl;
@@ -42,7 +45,7 @@ constexpr int kXcNear = (int)kXcWin - (int)kXcPass;  // a window match this clos
 #define MZD_XC_OOR 0x00FF0000u
 #endif
 constexpr uint32_t kXcOor = MZD_XC_OOR;   // an LDS address no workgroup has: stores to it are dropped (tools/ubench k_pred<2>)
-constexpr uint32_t kXcFarMark = 0x2000u;   // table entry of a window match that is neither in the ring nor staged: | lane of its sequence
+constexpr uint32_t kXcFarMark = 2 * kXcWin;   // table entry of a window match that is neither in the ring nor staged: | lane of its sequence
 
 struct XcLds {
     uint8_t win[kXcWin];
@@ -68,6 +71,35 @@ __device__ unsigned long long g_xc_stats[16];
 #define XC_STAT(i, n) do { } while (0)
 #define XC_CLOCK() 0ull
 #endif
+
+// bytes [flushed, upto) of the frame leave the window for the slab, byte by byte (block ends, unaligned remainders)
+__device__ __noinline__ uint32_t xc_flush_bytes(const uint8_t *win, uint8_t *out, uint32_t flushed, uint32_t upto, int lane)
+{
+    for (uint32_t x = flushed + (uint32_t)lane; x < upto; x += 64) out[x] = win[x & (kXcWin - 1)];
+    return upto;
+}
+// the 512-byte unit at `flushed` (or the bytes up to the next unit boundary) leaves for the slab; -> the new `flushed`
+__device__ __forceinline__ uint32_t xc_flush_step(const uint8_t *win, uint8_t *out, uint32_t flushed, int lane)
+{
+    if ((flushed & (kXcFlush - 1)) == 0) {
+        const uint32_t x = flushed + 8u * (uint32_t)lane;
+        const uint64_t v = *(const uint64_t *)&win[x & (kXcWin - 1)];
+        ((U64U *)(out + x))->v = v;
+        return flushed + kXcFlush;
+    }
+    return xc_flush_bytes(win, out, flushed, (flushed + kXcFlush) & ~(kXcFlush - 1), lane);
+}
+// after a bulk write straight to the slab (Raw / RLE blocks, literal-only blocks): the window ring takes the last bytes of the
+// frame back from memory so that the next block's window matches find them
+__device__ __noinline__ void xc_reload_window(uint8_t *win, const uint8_t *out, uint32_t outPos, int lane)
+{
+    xb_wait_vm();  // the bulk stores are in memory (same CU: visible to the loads below)
+    const uint32_t lo = outPos > kXcWin ? outPos - kXcWin : 0u;
+    const uint32_t lo4 = (lo + 3u) & ~3u;
+    const uint32_t hi4 = outPos & ~3u;
+    for (uint32_t x = lo4 + 4u * (uint32_t)lane; x < hi4; x += 256) *(uint32_t *)&win[x & (kXcWin - 1)] = ((const U32U *)(out + x))->v;
+    for (uint32_t x = max(lo4, hi4) + (uint32_t)lane; x < outPos; x += 64) win[x & (kXcWin - 1)] = out[x];
+}
 
 #ifdef MZD_XC_NO_OOR  /* debugging: the predicated stores under exec masks instead */
 __device__ __forceinline__ void xc_lds_write_b32(uint32_t addr, uint32_t v) { if (addr < kXcOor) asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
@@ -151,11 +183,11 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 error = MZD_ERR_DST_FULL;
                 break;
             }
-            flushed = xb_flush_bytes(*(XbLds *)&sh, out, flushed, outPos, lane);  // (same ring: the first 4 KiB of the block)
+            flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);  // (same ring: the first 4 KiB of the block)
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
-            xb_reload_window(*(XbLds *)&sh, out, outPos, lane);
+            xc_reload_window(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -177,13 +209,13 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
         if (b.n_seq == 0) {
             // no sequences: the block IS its literals (sequence_execution.go:55-59) -- unless the Huffman stage has
             // already put them in place
-            flushed = xb_flush_bytes(*(XbLds *)&sh, out, flushed, outPos, lane);
+            flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);
             if (!b.pad[0]) {
                 if (litRle) xb_bulk_fill(out + outPos, lits[0], b.lit_regen, lane);
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
-            xb_reload_window(*(XbLds *)&sh, out, outPos, lane);
+            xc_reload_window(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
 #ifdef MZD_ABL_XC_NOFLUSH
                 while (P0 - fl >= kXcFlush) fl += kXcFlush;
 #else
-                while (P0 - fl >= kXcFlush) fl = uni(xb_flush_step(*(XbLds *)&sh, out, fl, lane));
+                while (P0 - fl >= kXcFlush) fl = uni(xc_flush_step(sh.win, out, fl, lane));
 #endif
                 flushed = fl;
             }
@@ -457,7 +489,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                         "v_xor_b32 %[t], %[t], %[ea]\n\t"
                         "v_xor_b32 %[u], %[u], %[eb]\n\t"
                         "v_or_b32 %[t], %[t], %[u]\n\t"
-                        "v_and_b32 %[t], 0x1000, %[t]\n\t"
+                        "v_and_b32 %[t], %[winbit], %[t]\n\t"
                         "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
                         "s_mov_b32 %[rounds], 0\n\t"
                         "s_waitcnt lgkmcnt(0)\n\t"
@@ -485,7 +517,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                           [eb] "=&v"(eb), [aa] "=&v"(aa), [ab] "=&v"(ab), [va] "=&v"(va), [vb] "=&v"(vb),
                           [sa] "=&s"(sa), [m] "=&s"(m), [rounds] "=&s"(rounds), [sbase] "+s"(sbase)
                         : [h0] "v"(H.x), [h1] "v"(H.y), [h2] "v"(H.z), [h3] "v"(H.w), [lblo] "v"(lblo), [lbhi] "v"(lbhi), [tab] "s"(tabA),
-                          [pa] "v"(pa), [pb] "v"(pb), [mask] "v"(vwmask), [wa] "v"(wa), [wb] "v"(wb), [lane] "v"(vlane)
+                          [pa] "v"(pa), [pb] "v"(pb), [mask] "v"(vwmask), [wa] "v"(wa), [wb] "v"(wb), [lane] "v"(vlane), [winbit] "s"(kXcWin)
                         : "memory", "vcc", "scc");
                     XC_STAT(3, rounds);
                     if (rounds >= 4) {
@@ -493,8 +525,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                         // byte copies: the element of the pass its window source falls on (its ring slot is one of the pass's)
                         XC_STAT(4, 1);
                         const uint32_t da = (wa - aa) & vwmask, db = (wb - ab) & vwmask;  // distance back to the source, for ring sources
-                        const int ra = (ea >> 12) == 0 && da <= (uint32_t)lane ? (int)((uint32_t)lane - da) : -1;
-                        const int rb = (eb >> 12) == 0 && db <= 64u + (uint32_t)lane ? (int)(64u + (uint32_t)lane - db) : -1;
+                        const int ra = ea < kXcWin && da <= (uint32_t)lane ? (int)((uint32_t)lane - da) : -1;
+                        const int rb = eb < kXcWin && db <= 64u + (uint32_t)lane ? (int)(64u + (uint32_t)lane - db) : -1;
                         // bytes whose source lies before the pass are final as read; the others start from their pointers
                         const uint2 r = xc_resolve_in_pass(va, vb, ra, rb, (uint32_t)lane);
                         sh.win[wa] = (uint8_t)r.x;
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             H0 = n0; H1 = n1; H2 = n2;
         }
     }
-    if (error == MZD_OK) flushed = xb_flush_bytes(*(XbLds *)&sh, out, flushed, outPos, lane);
+    if (error == MZD_OK) flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);
 #ifdef MZD_XC_STATS
     xcst[11] = XC_CLOCK() - xc_t0;
     xcst[12] = 1;
@@ -583,6 +615,74 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
         if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
         frame_status[fidx] = e;
         frame_out_len[fidx] = outPos;
+    }
+}
+
+// ---- batches of nothing but Raw / RLE blocks (framedecompressor.go:211-215,229-241; BASELINE configs[1]): the pass IS a copy.
+// k_exec gives such a frame one workgroup that walks its blocks -- 4 096 workgroups of two wavefronts for the config's 512 MiB,
+// 0.61 of the copy ceiling measured beside it.  Here the grid is (frame, 16 KiB chunk): workgroup (f, c) does chunk c of every
+// block of frame f, 256 lanes x 16 bytes per instruction, four loads in flight per lane before the stores; chunk 0 reports the
+// frame.  A block is at most 128 KiB: eight chunks.
+constexpr uint32_t kCopyChunk = 16384, kCopyChunksPerBlock = kBlockMax / kCopyChunk;
+__global__ __launch_bounds__(256) void k_copy_blocks(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
+                                                     const DBlock *__restrict__ blocks, int32_t *frame_status, uint64_t *frame_out_len,
+                                                     const uint32_t *__restrict__ order, uint32_t first, uint32_t n_frames)
+{
+    const uint32_t tid = threadIdx.x;
+    // (a grid of a few workgroups per CU walks the chunks with a stride, like the copy kernel the ceiling is measured with: 32 768
+    // workgroups of 16 KiB each spent a sixth of the pass being dispatched)
+    for (uint32_t w = blockIdx.x; w < n_frames * kCopyChunksPerBlock; w += gridDim.x) {
+    const uint32_t fi = w / kCopyChunksPerBlock, c = w % kCopyChunksPerBlock;
+    const uint32_t fidx = order ? order[first + fi] : first + fi;
+    const DFrame fr = frames[fidx];
+    uint8_t *out = out_blob + fr.out_offset;
+    int error = fr.plan_status;
+    uint64_t outPos = 0;
+    for (uint32_t bi = 0; bi < fr.n_blocks && error == MZD_OK; bi++) {
+        const DBlock b = blocks[fr.first_block + bi];
+        if (b.type == MZD_BLOCK_COMPRESSED) {  // (not in such a batch; a frame that has one is not this kernel's)
+            error = MZD_ERR_UNSUPPORTED;
+            break;
+        }
+        if (outPos + b.size > fr.out_capacity) {
+            error = MZD_ERR_DST_FULL;
+            break;
+        }
+        const uint32_t lo = c * kCopyChunk;
+        if (lo < b.size) {
+            const uint32_t n = min(kCopyChunk, b.size - lo);
+            uint8_t *dst = out + outPos + lo;
+            // (slabs are 256-byte aligned and a frame's blocks before the last are whole multiples of nothing in particular: the
+            // destination may be misaligned, so 16-byte accesses go through the packed type -- the hardware takes them)
+            const uint32_t n16 = n >> 4;
+            if (b.type == MZD_BLOCK_RAW) {
+                const uint8_t *src = in + b.src_off + lo;
+                uint32_t i = tid;
+                for (; i + 768 < n16; i += 1024) {
+                    const U128U v0 = *(const U128U *)(src + 16 * i), v1 = *(const U128U *)(src + 16 * (i + 256));
+                    const U128U v2 = *(const U128U *)(src + 16 * (i + 512)), v3 = *(const U128U *)(src + 16 * (i + 768));
+                    *(U128U *)(dst + 16 * i) = v0;
+                    *(U128U *)(dst + 16 * (i + 256)) = v1;
+                    *(U128U *)(dst + 16 * (i + 512)) = v2;
+                    *(U128U *)(dst + 16 * (i + 768)) = v3;
+                }
+                for (; i < n16; i += 256) *(U128U *)(dst + 16 * i) = *(const U128U *)(src + 16 * i);
+                for (uint32_t j = (n16 << 4) + tid; j < n; j += 256) dst[j] = src[j];
+            } else {
+                const uint32_t v = in[b.src_off] * 0x01010101u;
+                const U128U f{v, v, v, v};
+                for (uint32_t i = tid; i < n16; i += 256) *(U128U *)(dst + 16 * i) = f;
+                for (uint32_t j = (n16 << 4) + tid; j < n; j += 256) dst[j] = (uint8_t)v;
+            }
+        }
+        outPos += b.size;
+    }
+    if (c == 0 && tid == 0) {
+        int e = error;
+        if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
+        frame_status[fidx] = e;
+        frame_out_len[fidx] = outPos;
+    }
     }
 }
 

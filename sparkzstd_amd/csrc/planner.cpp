@@ -636,7 +636,7 @@ struct mzd_plan {
         fd.content_size = fp.content_size;
         fd.window_size = fp.window_size;
         fd.checksum = fp.checksum;
-        fd.flags = fp.status ? 0 : fp.flags;
+        fd.flags = (fp.status ? 0 : fp.flags) | (((uint32_t)fp.status & 0xFFu) << MZD_FRAME_PLAN_STATUS_SHIFT);
         for (auto b : fp.blocks) {
             b.src_off += rebase;
             b.lit_off += rebase;

@@ -130,6 +130,33 @@ def test_block_mode_many_frames_one_fixup_workgroup_each():
     c.close()
 
 
+def test_block_mode_fixup_rescue_when_workgroups_give_up():
+    """The fix-up walk of block mode lets G workgroups of a frame wait for each other; nothing promises that they are all
+    resident (another stream or process on the GPU).  mzd_debug_force_fixup_bail makes workgroup 1 of every frame give up at a
+    step of the walk as it would after its bounded wait; the rescue launch (one workgroup per such frame, redoing exactly the
+    chunk sets that were not gathered) then has to deliver the frames whole -- never MZD_ERR_DEVICE, never a wrong byte."""
+    from tools import synth_binding as sb
+    from sparkzstd_amd import _lib
+    L = _lib.load()
+    frames, datas = [], []
+    for k, n in enumerate([20 << 20, 9 << 20, 3 << 20 | 12345]):
+        d = sb.generate(sb.TEXT, 40 + k, n)
+        frames.append(sb.compress(d, sb.MODE_FULL)[0])
+        datas.append(d)
+    for variant in (3, 4):
+        for step in (1, 2, 7):
+            c = z.Context(0, exec_variant=variant)
+            assert L.mzd_debug_force_fixup_bail(c._c, step) == 0
+            outs, sts = _decode(frames, c)
+            assert sts == [0, 0, 0], (variant, step, sts)
+            for o, d in zip(outs, datas):
+                assert o == d, (variant, step)
+            assert L.mzd_debug_force_fixup_bail(c._c, 0) == 0
+            outs, sts = _decode(frames, c)
+            assert sts == [0, 0, 0] and all(o == d for o, d in zip(outs, datas))
+            c.close()
+
+
 def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
     """Damaged multi-block frames: block mode (a scan over the block summaries + per-block execution) names the same status
     and the same produced length per frame as k_exec_b walking the blocks in order -- the first failing block ends the frame

@@ -352,7 +352,8 @@ def test_decode_frames_over_two_contexts_splits_and_stitches(corpus):
             check_expected(name, got, length, sha, exp)
     blob, off, ln, ck, ns = sb.make_batch(4, 5, 257, frame_bytes=16384, threads=4)
     fr = [blob[int(o):int(o + l)].tobytes() for o, l in zip(off, ln)]
-    assert z.shard_frames(fr, 3) == [(0, 86), (86, 172), (172, 257)]
+    r3 = z.shard_frames(fr, 3)  # (frames of one regenerated size, compressed sizes that differ a little: balanced by C + D)
+    assert r3[0][0] == 0 and r3[2][1] == 257 and r3[0][1] == r3[1][0] and r3[1][1] == r3[2][0] and all(80 <= hi - lo <= 92 for lo, hi in r3)
     outs, errs = z.DecodeFrames(fr, devices=devs + [0])  # three contexts
     assert errs == [None] * len(fr)
     for o, k in zip(outs, ck):
