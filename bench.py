@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="keep the whole batch PER GPU instead (weak scaling)")
     ap.add_argument("--rendezvous", default=os.environ.get("MZD_BENCH_BACKEND", "gloo"), choices=["gloo", "nccl"],
                     help="how the ranks meet for the barrier and the max-over-ranks time (the data path has no collective)")
-    ap.add_argument("--exec-variant", type=int, default=0, help="0 auto, 1 k_exec (workgroup per frame), 2 k_exec_b (wavefront per frame, lane per byte), 3 k_exec_b with the blocks of a frame side by side, 4 the same in jobs of four blocks")
+    ap.add_argument("--exec-variant", type=int, default=0, help="0 auto, 1 k_exec (workgroup per frame), 2 k_exec_b (wavefront per frame, lane per byte), 3 k_exec_b with the blocks of a frame side by side, 4 the same in jobs of four blocks, 5 k_exec_c (two bytes per lane and pass, fixed-point passes: what 0 takes for batches with sequences)")
     ap.add_argument("--seq-variant", type=int, default=0)
     ap.add_argument("--verify-checksum", action="store_true", help="frames carry the zstd content checksum and the device verifies it after the pass (k_xxh64; an extension, off by default like in the reference)")
     ap.add_argument("--device-plan", action="store_true", help="parse the frame / block / section headers on the device too (mzd_batch_upload_frames) instead of in the host planner")
@@ -83,10 +83,10 @@ def parse():
                          "take longer, fewer distinct frames are generated and physically replicated")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--traffic-from", default="", help="JSON written by tools/profile_round.sh in the same gpurun "
-                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r3_traffic_<workload>.json. "
+                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r4_traffic_<workload>.json. "
                     "Quoted only if its kernel_src_sha16 and workload match this run")
     ap.add_argument("--issue-from", default="", help="JSON written by tools/profile_counters.sh (SQ counters per kernel); default: "
-                    "profiles/r3_issue_<workload>.json; quoted under the same condition")
+                    "profiles/r4_issue_<workload>.json; quoted under the same condition")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured copy ceiling (mzd_measure_copy)")
     return ap.parse_args()
 
@@ -503,12 +503,12 @@ def main():
                        f"same device sources ({j.get('kernel_src_sha16')}) and workload")
 
         traffic = None
-        tj, traffic_note = stamped(a.traffic_from or os.path.join(ROOT, "profiles", f"r3_traffic_{wl_tag}.json"), "traffic")
+        tj, traffic_note = stamped(a.traffic_from or os.path.join(ROOT, "profiles", f"r4_traffic_{wl_tag}.json"), "traffic")
         if tj:
             traffic = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in tj["kernels"].items() if k != "k_init")
             traffic_note += "; FETCH_SIZE (raw; gfx950 under-counts wide streaming reads up to 2x) + WRITE_SIZE summed over the pass's kernels"
         # what each kernel keeps busy inside the CU: the path is latency- and issue-bound, an HBM fraction alone does not show progress
-        ij, issue_note = stamped(a.issue_from or os.path.join(ROOT, "profiles", f"r3_issue_{wl_tag}.json"), "issue")
+        ij, issue_note = stamped(a.issue_from or os.path.join(ROOT, "profiles", f"r4_issue_{wl_tag}.json"), "issue")
         issue = {"source": issue_note}
         if ij:
             issue["kernels"] = {k: {f: v[f] for f in ("valu_wave_insts", "valu_frac", "lds_pipe_frac", "ta_busy_frac", "kernel_cycles") if f in v}

@@ -1695,7 +1695,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
         // (exec_variant 0: the chunked copy kernel; a forced variant: that kernel's own copy arms, as the parity tests want them)
         if (ctx->opt.exec_variant == 0 && !no_exec && db->n_frames > 0)
-            k_copy_blocks<<<(uint32_t)std::min<uint64_t>((uint64_t)db->n_frames * kCopyChunksPerBlock, (uint64_t)std::max(ctx->num_cus, 1) * 8), 256, 0, s>>>(
+            // (a workgroup per chunk: 0.176 ms for the config's 4 096 frames; the same chunks walked with a stride by eight workgroups
+            // per CU -- the shape of the kernel the copy ceiling is measured with -- 0.203 ms)
+            k_copy_blocks<<<db->n_frames * kCopyChunksPerBlock, 256, 0, s>>>(
                 db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_status, db->d_out_len, db->d_frame_order, 0u, db->n_frames);
         else
             launch_exec(s, 0, db->n_frames);

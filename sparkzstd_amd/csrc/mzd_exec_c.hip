@@ -629,8 +629,7 @@ __global__ __launch_bounds__(256) void k_copy_blocks(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ order, uint32_t first, uint32_t n_frames)
 {
     const uint32_t tid = threadIdx.x;
-    // (a grid of a few workgroups per CU walks the chunks with a stride, like the copy kernel the ceiling is measured with: 32 768
-    // workgroups of 16 KiB each spent a sixth of the pass being dispatched)
+    // (launched with a workgroup per chunk; the loop is there for a smaller grid)
     for (uint32_t w = blockIdx.x; w < n_frames * kCopyChunksPerBlock; w += gridDim.x) {
     const uint32_t fi = w / kCopyChunksPerBlock, c = w % kCopyChunksPerBlock;
     const uint32_t fidx = order ? order[first + fi] : first + fi;

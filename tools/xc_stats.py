@@ -6,9 +6,15 @@ sys.path.insert(0, ROOT)
 import sparkzstd_amd as z
 from sparkzstd_amd import _lib
 from tools import synth_binding as sb
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-blob, off, ln, ck, ns = sb.make_batch(4, 0, n, threads=8)
-frames = [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
+if len(sys.argv) > 1 and sys.argv[1] == "corpus":  # the reference's 100 frames, replicated
+    import json
+    golden = os.path.join(ROOT, "tests", "golden", "decodecorpus")
+    names = sorted(json.load(open(os.path.join(golden, "manifest.json"))))
+    frames = [open(os.path.join(golden, nm + ".zst"), "rb").read() for nm in names] * (int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+else:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    blob, off, ln, ck, ns = sb.make_batch(4, 0, n, threads=8)
+    frames = [bytes(blob[o:o + l]) for o, l in zip(off, ln)]
 ctx = z.Context(0, exec_variant=5)
 L = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
