@@ -30,8 +30,16 @@
 
 namespace mzd {
 
+// MZD_XC_PREPLACE: a staged match is not kept in a stage area and copied by the passes -- the setup stores its bytes straight into
+// the window ring at the match's place (exact-length byte-misaligned stores), the passes leave them alone (table entry 0: a byte
+// is its own source).  No stage area: the 2 KiB it took go to a ring of 8 KiB at 17 frames per CU, and a match up to 7 040 bytes
+// back -- instead of 3 968 -- is served by the ring: a quarter fewer of the 64-byte sectors the kernel's time is made of.
 #ifndef MZD_XC_WIN
+#ifdef MZD_XC_PREPLACE
+#define MZD_XC_WIN 8192
+#else
 #define MZD_XC_WIN 4096
+#endif
 #endif
 constexpr uint32_t kXcWin = MZD_XC_WIN;  // window ring at LDS offset 0 of the frame's block (a power of two, 4 KiB at least)
 constexpr uint32_t kXcLit = 512;       // literals of the current stretch
@@ -40,7 +48,13 @@ constexpr uint32_t kXcStage = 64 * kXcStageMl;
 constexpr uint32_t kXcStretch = 1024;  // output bytes per stretch at most (8 passes)
 constexpr uint32_t kXcFlush = 512;     // 64 lanes x 8 bytes leave for the slab at a time
 constexpr uint32_t kXcPass = 128;
+#ifdef MZD_XC_PREPLACE
+// (bytes are stored into the ring up to a whole stretch AHEAD of the passes: what they replace -- positions 8 192 back -- must not
+// be anything a pass of the stretch may still read)
+constexpr int kXcNear = (int)kXcWin - (int)kXcStretch - (int)kXcPass;
+#else
 constexpr int kXcNear = (int)kXcWin - (int)kXcPass;  // a window match this close to its pass is served by the ring
+#endif
 #ifndef MZD_XC_OOR
 #define MZD_XC_OOR 0x00FF0000u
 #endif
@@ -50,13 +64,17 @@ constexpr uint32_t kXcFarMark = 2 * kXcWin;   // table entry of a window match t
 struct XcLds {
     uint8_t win[kXcWin];
     uint8_t lit[kXcLit];
+#ifndef MZD_XC_PREPLACE
     uint8_t stage[kXcStage];
+#endif
     uint32_t bits[kXcStretch / 32];   // heads, one bit per output byte of the stretch; a pass reads four dwords
     uint32_t table[132];              // [0] the run that continues from the stretch before, [1 + k] head k of the stretch
     uint32_t pad[4];
 };
-static_assert(offsetof(XcLds, win) == 0 && offsetof(XcLds, lit) == kXcWin && offsetof(XcLds, stage) + kXcStage <= 2 * kXcWin &&
-                  offsetof(XcLds, bits) % 128 == 0 && sizeof(XcLds) % 16 == 0,
+#ifndef MZD_XC_PREPLACE
+static_assert(offsetof(XcLds, stage) + kXcStage <= 2 * kXcWin, "the stage inside region 1");
+#endif
+static_assert(offsetof(XcLds, win) == 0 && offsetof(XcLds, lit) == kXcWin && offsetof(XcLds, bits) % 128 == 0 && sizeof(XcLds) % 16 == 0,
               "ring = region 0, literals and stage inside region 0x1000, bitmap on a 128-byte boundary");
 static_assert(kXcStretch + kXcPass + kXcFlush <= kXcWin, "a window unit is issued before the ring wraps onto it");
 
@@ -101,6 +119,11 @@ __device__ __noinline__ void xc_reload_window(uint8_t *win, const uint8_t *out, 
     for (uint32_t x = max(lo4, hi4) + (uint32_t)lane; x < outPos; x += 64) win[x & (kXcWin - 1)] = out[x];
 }
 
+__device__ __forceinline__ void xc_lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi)
+{
+    const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 #ifdef MZD_XC_NO_OOR  /* debugging: the predicated stores under exec masks instead */
 __device__ __forceinline__ void xc_lds_write_b32(uint32_t addr, uint32_t v) { if (addr < kXcOor) asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void xc_lds_or_b32(uint32_t addr, uint32_t v) { if (addr < kXcOor) asm volatile("ds_or_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
@@ -124,7 +147,7 @@ __device__ __noinline__ uint2 xc_resolve_in_pass(uint32_t va, uint32_t vb, int r
     // state of an element in one dword: value | done << 8 | source element << 16
     uint32_t sa = (va & 0xFF) | (ra < 0 ? 0x100u : 0u) | ((uint32_t)(ra < 0 ? 0 : ra) << 16);
     uint32_t sb = (vb & 0xFF) | (rb < 0 ? 0x100u : 0u) | ((uint32_t)(rb < 0 ? 0 : rb) << 16);
-    for (;;) {
+    for (int round = 0; round < 8; round++) {  // (seven halvings end any chain of 128; the bound is there because a hang is not a failure mode)
         const bool da = (sa >> 8) & 1, db = (sb >> 8) & 1;
         if (!wave_any(!da || !db)) break;
         const uint32_t qa = sa >> 16, qb = sb >> 16;  // source elements (0..127)
@@ -316,7 +339,13 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             const bool mHere = T.ML > 0 && T.mstart < N.sEnd && T.mstart + T.ML > N.P;
             const uint32_t q0 = T.mstart - (uint32_t)T.off;
             const bool farm = mHere && T.off > kXcNear;
+#ifdef MZD_XC_PREPLACE
+            // stored into the ring by the setup: whole matches of whole tiles that do not run over the ring's end
+            const bool stg = farm && P == T.start && sEnd == T.E && T.ML >= 3 && T.ML <= kXcStageMl && q0 + T.ML <= confirmed &&
+                             (T.mstart & (kXcWin - 1)) + kXcStageMl <= kXcWin;
+#else
             const bool stg = farm && T.ML <= kXcStageMl && q0 + T.ML <= confirmed;
+#endif
             N.stg = wave_ballot(stg);
             N.stg2 = wave_ballot(stg && T.ML > 16);
             N.farwin = wave_ballot(farm && !stg);
@@ -355,7 +384,11 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 const uint32_t eL = ((T.lsrc - la - T.lstart) & (kXcWin - 1)) | kXcWin;
                 uint32_t eM = (uint32_t)(-T.off) & (kXcWin - 1);
                 if (T.off > kXcNear) eM = kXcFarMark | (uint32_t)lane;
+#ifdef MZD_XC_PREPLACE
+                if (stg) eM = 0u;  // its bytes are in the ring already: a byte is its own source
+#else
                 if (stg) eM = (((uint32_t)offsetof(XcLds, stage) + kXcStageMl * (uint32_t)lane - T.mstart) & (kXcWin - 1)) | kXcWin;
+#endif
                 const uint32_t hbm = hb + (litIn ? 1u : 0u);
                 xc_lds_write_b32(litIn ? tabA + 4u * hb : kXcOor, eL);
                 xc_lds_write_b32(mIn ? tabA + 4u * hbm : kXcOor, eM);
@@ -372,8 +405,11 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 if (contL) sh.table[0] = ((T.lsrc - la - T.lstart) & (kXcWin - 1)) | kXcWin;
                 if (contM) {
                     uint32_t e = (uint32_t)(-T.off) & (kXcWin - 1);
+#ifndef MZD_XC_PREPLACE
                     if (stg) e = (((uint32_t)offsetof(XcLds, stage) + kXcStageMl * (uint32_t)lane - T.mstart) & (kXcWin - 1)) | kXcWin;
-                    else if (T.off > kXcNear) e = kXcFarMark | (uint32_t)lane;
+                    else
+#endif
+                    if (T.off > kXcNear) e = kXcFarMark | (uint32_t)lane;
                     sh.table[0] = e;
                 }
                 // the sequence's literal run / match starts in this stretch
@@ -384,9 +420,47 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             xb_wait_vm();  // the staged bytes, the literals and the next tile's records are here; so is every window unit issued before
 #endif
             confirmed = uni(flushed);
+#ifdef MZD_XC_PREPLACE
+            if (C.stg) {
+                const uint32_t ML = T.ML, d = ldsBase + (T.mstart & (kXcWin - 1));
+                // matches of 17 to 32 bytes first, one lane at a time, as four 8-byte stores: what runs over a match's end lands on
+                // bytes that are made later -- by a pass, or by one of the exact stores below (later in program order)
+                for (uint64_t m2 = C.stg2; m2; m2 &= m2 - 1) {
+                    if (lane == __builtin_ctzll(m2)) {
+                        xc_lds_write_b64(d, C.sv.x, C.sv.y);
+                        xc_lds_write_b64(d + 8, C.sv.z, C.sv.w);
+                        xc_lds_write_b64(d + 16, C.sv2.x, C.sv2.y);
+                        xc_lds_write_b64(d + 24, C.sv2.z, C.sv2.w);
+                    }
+                }
+                // exact lengths, by size class (address-predicated: the other lanes store nowhere):
+                //   8..16 bytes: 8 at the start, 8 ending at the end;  4..7: 4 and 4;  3: 2 and 1
+                const bool c8 = stg && ML >= 8 && ML <= 16, c4 = stg && ML >= 4 && ML < 8, c3 = stg && ML == 3;
+                // the 8 source bytes that END at byte ML of the 16 in sv (ML 9..16: a shift of 1..8 bytes)
+                const uint32_t sh8 = ML - 8, q8 = (sh8 >> 2) & 3, r8 = sh8 & 3;
+                const uint32_t e0 = q8 == 0 ? C.sv.x : (q8 == 1 ? C.sv.y : C.sv.z);
+                const uint32_t e1 = q8 == 0 ? C.sv.y : (q8 == 1 ? C.sv.z : C.sv.w);
+                const uint32_t e2 = q8 == 0 ? C.sv.z : (q8 == 1 ? C.sv.w : 0u);
+                const uint32_t t8lo = __builtin_amdgcn_alignbyte(e1, e0, r8), t8hi = __builtin_amdgcn_alignbyte(e2, e1, r8);
+                // the 4 bytes that end at byte ML of the first 8 (ML 4..7: a shift of 0..3 bytes)
+                const uint32_t t4 = __builtin_amdgcn_alignbyte(C.sv.y, C.sv.x, (ML - 4) & 3);
+                xc_lds_write_b64(c8 ? d : kXcOor, C.sv.x, C.sv.y);
+                xc_lds_write_b64(c8 ? d + sh8 : kXcOor, t8lo, t8hi);
+                xc_lds_write_b32(c4 ? d : kXcOor, C.sv.x);
+                xc_lds_write_b32(c4 ? d + ML - 4 : kXcOor, t4);
+                if (wave_any(c3)) {
+                    if (c3) {
+                        sh.win[T.mstart & (kXcWin - 1)] = (uint8_t)C.sv.x;
+                        sh.win[(T.mstart + 1) & (kXcWin - 1)] = (uint8_t)(C.sv.x >> 8);
+                        sh.win[(T.mstart + 2) & (kXcWin - 1)] = (uint8_t)(C.sv.x >> 16);
+                    }
+                }
+            }
+#else
             // (every lane stores its 16 bytes: what a lane without a staged match leaves in its slot is never looked at)
             *(uint4 *)&sh.stage[kXcStageMl * lane] = make_uint4(C.sv.x, C.sv.y, C.sv.z, C.sv.w);
             if (C.stg2) *(uint4 *)&sh.stage[kXcStageMl * lane + 16] = make_uint4(C.sv2.x, C.sv2.y, C.sv2.z, C.sv2.w);
+#endif
             if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = C.lv;
             const bool farwin = C.farwin != 0;
             XC_STAT(1, 1);
@@ -525,8 +599,9 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                         // byte copies: the element of the pass its window source falls on (its ring slot is one of the pass's)
                         XC_STAT(4, 1);
                         const uint32_t da = (wa - aa) & vwmask, db = (wb - ab) & vwmask;  // distance back to the source, for ring sources
-                        const int ra = ea < kXcWin && da <= (uint32_t)lane ? (int)((uint32_t)lane - da) : -1;
-                        const int rb = eb < kXcWin && db <= 64u + (uint32_t)lane ? (int)(64u + (uint32_t)lane - db) : -1;
+                        // (distance 0: a byte that is its own source -- entry 0 -- is final as it stands)
+                        const int ra = ea < kXcWin && da != 0 && da <= (uint32_t)lane ? (int)((uint32_t)lane - da) : -1;
+                        const int rb = eb < kXcWin && db != 0 && db <= 64u + (uint32_t)lane ? (int)(64u + (uint32_t)lane - db) : -1;
                         // bytes whose source lies before the pass are final as read; the others start from their pointers
                         const uint2 r = xc_resolve_in_pass(va, vb, ra, rb, (uint32_t)lane);
                         sh.win[wa] = (uint8_t)r.x;
