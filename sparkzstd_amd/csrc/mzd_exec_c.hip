@@ -437,17 +437,25 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 //   8..16 bytes: 8 at the start, 8 ending at the end;  4..7: 4 and 4;  3: 2 and 1
                 const bool c8 = stg && ML >= 8 && ML <= 16, c4 = stg && ML >= 4 && ML < 8, c3 = stg && ML == 3;
                 // the 8 source bytes that END at byte ML of the 16 in sv (ML 9..16: a shift of 1..8 bytes)
-                const uint32_t sh8 = ML - 8, q8 = (sh8 >> 2) & 3, r8 = sh8 & 3;
-                const uint32_t e0 = q8 == 0 ? C.sv.x : (q8 == 1 ? C.sv.y : C.sv.z);
-                const uint32_t e1 = q8 == 0 ? C.sv.y : (q8 == 1 ? C.sv.z : C.sv.w);
-                const uint32_t e2 = q8 == 0 ? C.sv.z : (q8 == 1 ? C.sv.w : 0u);
-                const uint32_t t8lo = __builtin_amdgcn_alignbyte(e1, e0, r8), t8hi = __builtin_amdgcn_alignbyte(e2, e1, r8);
+                // (as 64-bit shifts of register pairs: a select chain over the four dwords of `sv` was turned into an indexed access of
+                // the plan in scratch memory -- 192 bytes per lane, every reload behind all of the wavefront's memory operations: 19.6 ms)
+                const uint32_t sh8 = ML - 8;
+                const uint64_t slo = (uint64_t)C.sv.x | ((uint64_t)C.sv.y << 32), shi = (uint64_t)C.sv.z | ((uint64_t)C.sv.w << 32);
+                const uint32_t b8 = 8u * (sh8 & 7u);
+                const uint64_t t8 = sh8 >= 8 ? shi : (b8 ? (slo >> b8) | (shi << (64u - b8)) : slo);
+                const uint32_t t8lo = (uint32_t)t8, t8hi = (uint32_t)(t8 >> 32);
                 // the 4 bytes that end at byte ML of the first 8 (ML 4..7: a shift of 0..3 bytes)
                 const uint32_t t4 = __builtin_amdgcn_alignbyte(C.sv.y, C.sv.x, (ML - 4) & 3);
-                xc_lds_write_b64(c8 ? d : kXcOor, C.sv.x, C.sv.y);
-                xc_lds_write_b64(c8 ? d + sh8 : kXcOor, t8lo, t8hi);
-                xc_lds_write_b32(c4 ? d : kXcOor, C.sv.x);
-                xc_lds_write_b32(c4 ? d + ML - 4 : kXcOor, t4);
+                // (under exec masks: an out-of-range 8-byte store is not free for the LDS pipe the way a 4-byte one is -- with these
+                // four predicated by address the kernel took 20.6 ms)
+                if (c8) {
+                    xc_lds_write_b64(d, C.sv.x, C.sv.y);
+                    xc_lds_write_b64(d + sh8, t8lo, t8hi);
+                }
+                if (c4) {
+                    xc_lds_write_b32(d, C.sv.x);
+                    xc_lds_write_b32(d + ML - 4, t4);
+                }
                 if (wave_any(c3)) {
                     if (c3) {
                         sh.win[T.mstart & (kXcWin - 1)] = (uint8_t)C.sv.x;
