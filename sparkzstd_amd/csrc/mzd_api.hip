@@ -1539,7 +1539,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // the batch is small -- the step latency does not depend on the number of lanes)
             const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1) * wg_per_cu;  // workgroups resident at a time
             const uint64_t rounds = (count + cus * nch - 1) / (cus * nch);
-            const uint32_t per_wg = (uint32_t)std::min<uint64_t>(nch, (count + rounds * cus - 1) / (rounds * cus));
+            uint32_t per_wg = (uint32_t)std::min<uint64_t>(nch, (count + rounds * cus - 1) / (rounds * cus));
+            if (exp_env("MZD_EXP_TAIL_FULL")) per_wg = nch;  // experiment: a partial round on as few CUs as hold it, the others free for the execution stage
             if (q4)
                 k_seq_q4<<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,

@@ -301,32 +301,37 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
             mA[q] = ((ma & 1u) * 0xFFu) | ((ma & 2u) * 0x7F80u) | ((ma & 4u) * 0x3FC000u) | ((ma & 8u) * 0x1FE00000u);  // bit i -> byte i
             mB[q] = ((mb & 1u) * 0xFFu) | ((mb & 2u) * 0x7F80u) | ((mb & 4u) * 0x3FC000u) | ((mb & 8u) * 0x1FE00000u);
         }
-        // the single bytes first (the compiler's own loads), the eight dwords behind them: one wait for all of them
+        // the single bytes first (the compiler's own loads), the dwords behind them: one wait for all of them
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if (get[j]) b8[j] = __hip_atomic_load(p0 + b8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (Four-byte agent-scope loads at BYTE-aligned addresses: the hardware takes them, C++ has no name for them -- an atomic
-        // load through a misaligned uint32_t pointer is undefined behaviour for the compiler -- so the eight of a chunk are
-        // written out, issued together, one wait behind them.  A dword without a group reads the chunk's own position.)
-        uint32_t vA[4], vB[4];
+        // load through a misaligned uint32_t pointer is undefined behaviour for the compiler -- so the eight of a chunk are written
+        // out in ONE asm statement, each under its own lane mask (a dword without a group loads nothing: unconditional loads from
+        // the chunk's own position cost the walk of one 1 GiB frame 20 %), with the wait inside the statement: a load left in
+        // flight across statements lands in a register the compiler believes it may already use for something else.)
+        uint32_t vA[4] = {0, 0, 0, 0}, vB[4] = {0, 0, 0, 0};
         {
-            const uint8_t *aA[4], *aB[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                aA[q] = p0 + (hasA[q] ? ldA[q] : C.x[k] + 4u * (uint32_t)q);
-                aB[q] = p0 + (hasB[q] ? ldB[q] : C.x[k] + 4u * (uint32_t)q);
-            }
-            asm volatile("global_load_dword %0, %8, off sc1\n\t"
-                         "global_load_dword %1, %9, off sc1\n\t"
-                         "global_load_dword %2, %10, off sc1\n\t"
-                         "global_load_dword %3, %11, off sc1\n\t"
-                         "global_load_dword %4, %12, off sc1\n\t"
-                         "global_load_dword %5, %13, off sc1\n\t"
-                         "global_load_dword %6, %14, off sc1\n\t"
-                         "global_load_dword %7, %15, off sc1\n\t"
+            const uint64_t mA0 = wave_ballot(hasA[0]), mA1 = wave_ballot(hasA[1]), mA2 = wave_ballot(hasA[2]), mA3 = wave_ballot(hasA[3]);
+            const uint64_t mB0 = wave_ballot(hasB[0]), mB1 = wave_ballot(hasB[1]), mB2 = wave_ballot(hasB[2]), mB3 = wave_ballot(hasB[3]);
+            unsigned long long save;
+            asm volatile("s_mov_b64 %[save], exec\n\t"
+                         "s_mov_b64 exec, %[mA0]\n\tglobal_load_dword %[a0], %[pa0], off sc1\n\t"
+                         "s_mov_b64 exec, %[mB0]\n\tglobal_load_dword %[b0], %[pb0], off sc1\n\t"
+                         "s_mov_b64 exec, %[mA1]\n\tglobal_load_dword %[a1], %[pa1], off sc1\n\t"
+                         "s_mov_b64 exec, %[mB1]\n\tglobal_load_dword %[b1], %[pb1], off sc1\n\t"
+                         "s_mov_b64 exec, %[mA2]\n\tglobal_load_dword %[a2], %[pa2], off sc1\n\t"
+                         "s_mov_b64 exec, %[mB2]\n\tglobal_load_dword %[b2], %[pb2], off sc1\n\t"
+                         "s_mov_b64 exec, %[mA3]\n\tglobal_load_dword %[a3], %[pa3], off sc1\n\t"
+                         "s_mov_b64 exec, %[mB3]\n\tglobal_load_dword %[b3], %[pb3], off sc1\n\t"
+                         "s_mov_b64 exec, %[save]\n\t"
                          "s_waitcnt vmcnt(0)"
-                         : "=&v"(vA[0]), "=&v"(vA[1]), "=&v"(vA[2]), "=&v"(vA[3]), "=&v"(vB[0]), "=&v"(vB[1]), "=&v"(vB[2]), "=&v"(vB[3])
-                         : "v"(aA[0]), "v"(aA[1]), "v"(aA[2]), "v"(aA[3]), "v"(aB[0]), "v"(aB[1]), "v"(aB[2]), "v"(aB[3])
+                         : [a0] "+v"(vA[0]), [a1] "+v"(vA[1]), [a2] "+v"(vA[2]), [a3] "+v"(vA[3]), [b0] "+v"(vB[0]), [b1] "+v"(vB[1]),
+                           [b2] "+v"(vB[2]), [b3] "+v"(vB[3]), [save] "=&s"(save)
+                         : [pa0] "v"(p0 + ldA[0]), [pa1] "v"(p0 + ldA[1]), [pa2] "v"(p0 + ldA[2]), [pa3] "v"(p0 + ldA[3]),
+                           [pb0] "v"(p0 + ldB[0]), [pb1] "v"(p0 + ldB[1]), [pb2] "v"(p0 + ldB[2]), [pb3] "v"(p0 + ldB[3]),
+                           [mA0] "s"(mA0), [mA1] "s"(mA1), [mA2] "s"(mA2), [mA3] "s"(mA3), [mB0] "s"(mB0), [mB1] "s"(mB1), [mB2] "s"(mB2),
+                           [mB3] "s"(mB3)
                          : "memory");
         }
 #pragma unroll
