@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--gen-seconds", type=float, default=60.0,
                     help="host time budget for generating the synthetic batch; if all-distinct frames would "
                          "take longer, fewer distinct frames are generated and physically replicated")
+    ap.add_argument("--window-log", type=int, default=0, help="synthetic frames: matches reach back at most 2^N bytes (what zstd's windowLog "
+                    "does: 23 at its levels up to 19); 0 = the generator's default, 2^27 -- the frames of BASELINE's configs are unaffected "
+                    "(128 KiB), large frames are: block mode spells an origin with three passes instead of four when offsets stay below 8 MiB")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--traffic-from", default="", help="JSON written by tools/profile_round.sh in the same gpurun "
                     "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r4_traffic_<workload>.json. "
@@ -275,6 +278,8 @@ def main():
     from tools import synth_binding as sb
 
     frame_bytes = a.frame_bytes
+    if a.window_log:
+        sb.set_max_offset(1 << a.window_log)
     assert frame_bytes % 256 == 0 and frame_bytes > 0
     corpus = None
     if a.workload == "corpus":
@@ -543,7 +548,7 @@ def main():
             "config": {"workload": (f"decodecorpus: the reference's {len(corpus['names'])} golden frames x {base} replicas at distinct HBM addresses "
                                     f"(content repeats, addresses do not); {corpus.get('sha_checked', 0)} frames checked by sha256, all by status and length")
                        if corpus else names.get(a.config, str(a.config)), "frames": total_frames, "frames_per_gpu": per,
-                       "frame_bytes": None if corpus else frame_bytes, "decompressed_bytes_all_gpus": d_bytes_all,
+                       "frame_bytes": None if corpus else frame_bytes, "window_log": a.window_log or None, "decompressed_bytes_all_gpus": d_bytes_all,
                        "compressed_bytes_per_gpu": c_bytes, "compressed_bytes_all_gpus": c_bytes_all,
                        "sequences_per_frame": round(float(stats.n_sequences) / max(per, 1), 1), "distinct_frames_per_gpu": distinct,
                        "parallelism": f"one batch of {total_frames} frames in contiguous ranges over {world} GPU(s), no collective"

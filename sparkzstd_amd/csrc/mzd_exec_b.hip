@@ -195,6 +195,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
         bi0 -= fr.first_block;
         // the passes after the first are for segments that can derive bytes from before their start
         if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (jb.flags & kBjDirect)))) return;
+        // the pass of the position's high bits is for frames whose matches may reach back 8 MiB or more (k_blk_scan)
+        if (bk.pass == 3 && !bk.bframes[fidx].high) return;
     }
     const uint32_t S = BM ? jb.start : 0u;  // the block's first byte (block mode)
     const uint8_t *const pat = bk.pat;

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
     uint32_t n_ok = error == MZD_OK ? fr.n_blocks : 0u;
     bool prev_direct = true;  // (the block before the frame's first: a job starts there anyway)
+    uint32_t reach = 0;       // the largest offset code of the frame's blocks (BlockSum::reach; ~0 when the sequence kernel does not say)
     for (uint32_t base = 0; base < fr.n_blocks; base += 64) {
         const uint32_t bi = base + lane;
         const bool valid = bi < fr.n_blocks;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
                 if (e == MZD_OK && bo > kBlockMax) e = MZD_ERR_CORRUPT_SIZES;
                 if (b.n_seq == 0) flags = kBjDirect;
                 else {
+                    reach = max(reach, s.reach);
                     hist = true;
                     h0 = s.hist[0];
                     h1 = s.hist[1];
@@ -161,6 +163,9 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
             }
         }
     }
+    // how far back the frame's matches go: an origin lies less than the largest offset below its segment's start, so with offsets
+    // up to 8 MiB the low 23 bits of the position say which one it is and the pass that spells the bits above is not run
+    reach = wave_max_u32(reach);
     if (lane == 0) {
         BFrame bf;
         bf.status = error;
@@ -169,7 +174,8 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
         bf.first_bad = 0xFFFFFFFFu;
         bf.cnt = 0;
         bf.bail = 0;
-        bf.pad[0] = bf.pad[1] = 0;
+        bf.high = reach > (1u << 23) ? 1u : 0u;
+        bf.pad = 0;
         bframes[f] = bf;
     }
 }
@@ -184,7 +190,7 @@ __global__ void k_blk_pattern(uint8_t *pat, uint64_t stride, uint32_t n, uint32_
         uint32_t w = 0;
         for (uint32_t j = 0; j < 4; j++) {
             const uint32_t y = x + j;
-            const uint32_t v = p + 1 < np ? (y >> (8 * p)) & 0xFFu : (y & 0xFFu) ^ (((y >> (8 * (np - 1))) & 0x7Fu) + 1u);
+            const uint32_t v = p < 2 ? (y >> (8 * p)) & 0xFFu : (p == 2 ? (y & 0xFFu) ^ (((y >> 16) & 0x7Fu) + 1u) : (y >> 23) & 0xFFu);
             w |= v << (8 * j);
         }
         *(uint32_t *)(pat + p * stride + x) = w;
@@ -208,6 +214,18 @@ __device__ __forceinline__ void fix_store16(uint8_t *p, u32x4 v)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// The origin of a derived byte from what the passes left at its position: byte 0 and byte 1 of the origin, the XOR term that
+// marks it as derived (1 + bits 16..22) and, for a frame whose matches may reach back 8 MiB or more, bits 23..30.  Without
+// those: the origin is the position below the segment's start S, within 8 MiB of it, that has these low 23 bits.
+template <int NP>
+__device__ __forceinline__ uint32_t fix_origin(uint32_t b0, uint32_t b1, uint32_t dj, uint32_t bh, uint32_t S, bool high)
+{
+    const uint32_t low = b0 | (b1 << 8) | ((dj - 1u) << 16);
+    if (NP == 4 && high) return low | (bh << 23);
+    if (NP == 3) return low;  // (frames below 8 MiB)
+    return (S - 1u) - (((S - 1u) - low) & 0x7FFFFFu);
+}
+
 template <int NP>
 struct FixChunks {
     U128U a[kFixK], e[kFixK], b1[kFixK], b2[kFixK];
@@ -216,8 +234,8 @@ struct FixChunks {
 };
 
 template <int NP>
-__device__ __forceinline__ void fix_load(FixChunks<NP> &C, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, const uint8_t *pE, uint32_t S,
-                                         uint32_t n, uint32_t c0, uint32_t cstep)
+__device__ __forceinline__ void fix_load(FixChunks<NP> &C, const uint8_t *p0, const uint8_t *p1, const uint8_t *pH, const uint8_t *pE, uint32_t S,
+                                         uint32_t n, uint32_t c0, uint32_t cstep, bool high)
 {
     const uint32_t nfull = n >> 4;  // whole chunks (the last bytes of a block go one by one)
 #pragma unroll
@@ -237,13 +255,13 @@ __device__ __forceinline__ void fix_load(FixChunks<NP> &C, const uint8_t *p0, co
         C.b1[k] = C.b2[k] = U128U{0, 0, 0, 0};
         if (C.need[k]) {
             C.b1[k] = *(const U128U *)(p1 + C.x[k]);
-            if (NP == 4) C.b2[k] = *(const U128U *)(p2 + C.x[k]);
+            if (NP == 4 && high) C.b2[k] = *(const U128U *)(pH + C.x[k]);
         }
     }
 }
 
 template <int NP>
-__device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, uint32_t S)
+__device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, uint32_t S, bool high)
 {
 #pragma unroll
     for (int k = 0; k < kFixK; k++) {
@@ -267,9 +285,7 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
             for (int i = 0; i < 4; i++) {
                 const int sh = 8 * i;
                 const uint32_t aj = (aw[q] >> sh) & 0xFF, dj = aj ^ ((ew[q] >> sh) & 0xFF);
-                uint32_t org = aj | (((w1[q] >> sh) & 0xFF) << 8);
-                if (NP == 4) org |= ((w2[q] >> sh) & 0xFF) << 16;
-                org |= (dj - 1) << (8 * (NP - 1));
+                uint32_t org = fix_origin<NP>(aj, (w1[q] >> sh) & 0xFF, dj, (w2[q] >> sh) & 0xFF, S, high);
                 const bool ok = dj != 0 && org < S && org >= (uint32_t)i;  // (beyond the job's start: only in a failed job; reads as 0)
                 dlt[i] = org - (uint32_t)i;
                 okq |= ok ? 1u << i : 0u;
@@ -372,8 +388,9 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
     const uint32_t nb = min(bf->n_ok, bf->first_bad);  // blocks [0, nb) executed without a defect
     uint8_t *p0 = out_blob + fr.out_offset;
     const uint8_t *p1 = pl1 + fr.out_offset;
-    const uint8_t *p2 = pl2 + fr.out_offset;                    // (NP == 3: this is the last plane)
-    const uint8_t *pE = (NP == 4 ? pl3 : pl2) + fr.out_offset;
+    const uint8_t *pE = pl2 + fr.out_offset;                    // the plane of the XOR term
+    const uint8_t *pH = NP == 4 ? pl3 + fr.out_offset : nullptr;  // the plane of the high position bits, written for frames with `high`
+    const bool high = NP == 4 && bf->high != 0;
     const uint32_t cstep = G * 256;
     uint32_t *fdone = done + (size_t)f * 64;
     __shared__ uint32_t go;
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
             for (uint32_t g = g0; g < (RESCUE ? G : g0 + 1); g++) {
                 if (RESCUE && fdone[g] > steps) continue;  // workgroup g gathered its chunks of this step
                 FixChunks<NP> C;
-                fix_load<NP>(C, p0, p1, p2, pE, S, n, g * 256 + tid, cstep);  // (nothing here was written by this kernel)
+                fix_load<NP>(C, p0, p1, pH, pE, S, n, g * 256 + tid, cstep, high);  // (nothing here was written by this kernel)
                 if (!RESCUE && G > 1 && steps > 0) {
                     // every workgroup of the frame is done with the jobs before this one (a bounded wait: all of them are
                     // resident -- the launch is sized for that -- but a hang is not an acceptable failure mode)
@@ -437,18 +454,16 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
                         return;
                     }
                 }
-                fix_gather<NP>(C, p0, S);
+                fix_gather<NP>(C, p0, S, high);
                 for (uint32_t c0 = g * 256 + tid + kFixK * cstep; c0 < nchunks; c0 += kFixK * cstep) {
-                    fix_load<NP>(C, p0, p1, p2, pE, S, n, c0, cstep);
-                    fix_gather<NP>(C, p0, S);
+                    fix_load<NP>(C, p0, p1, pH, pE, S, n, c0, cstep, high);
+                    fix_gather<NP>(C, p0, S, high);
                 }
                 if (g == 0 && tid < (n & 15)) {  // the job's last bytes
                     const uint32_t x = S + (n & ~15u) + tid;
                     const uint32_t aj = p0[x], dj = aj ^ pE[x];
                     if (dj) {
-                        uint32_t org = aj | ((uint32_t)p1[x] << 8);
-                        if (NP == 4) org |= (uint32_t)p2[x] << 16;
-                        org |= (dj - 1) << (8 * (NP - 1));
+                        const uint32_t org = fix_origin<NP>(aj, p1[x], dj, NP == 4 && high ? pH[x] : 0u, S, high);
                         *(volatile uint8_t *)(p0 + x) = org < S ? *(const volatile uint8_t *)(p0 + org) : (uint8_t)0;
                     }
                 }

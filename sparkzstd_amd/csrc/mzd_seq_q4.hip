@@ -873,6 +873,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             bs->hist[0] = (int)h0 >> 3;
             bs->hist[1] = (int)h1 >> 3;
             bs->hist[2] = (int)h2 >> 3;
+            bs->reach = maxv >> 3;  // the largest offset code = the largest new offset + 4 (block mode: how far back a frame's matches go)
         }
         shs->stC[lane] = status;
     } else if (lw == 7) {

@@ -116,6 +116,33 @@ def test_large_frames_blocks_side_by_side(exec_variant):
     c.close()
 
 
+@pytest.mark.parametrize("exec_variant", [0, 3, 4])
+def test_block_mode_matches_that_reach_back_more_than_8_mib(exec_variant):
+    """Block mode spells a derived byte's origin with three passes (23 bits of the position) when the frame's matches reach back
+    less than 8 MiB -- k_seq_q4 reports every block's largest offset, k_blk_scan decides per frame -- and with a fourth pass for
+    the bits above otherwise.  A frame whose incompressible 200 kB head is matched again 10 MiB and 22 MiB later (zeros in
+    between leave the compressor's hash table alone) needs the fourth; a text-like frame of 20 MiB beside it in the same batch
+    does not; both must come out byte for byte, together and alone."""
+    from tools import synth_binding as sb
+    A = sb.generate(sb.RANDOM, 99, 200000)
+    T = sb.generate(sb.TEXT, 98, 3 << 20)
+    far = A + bytes(10 << 20) + A[:150000] + T + bytes(9 << 20) + A[50000:] + T[:1 << 20]
+    near = sb.generate(sb.TEXT, 97, (20 << 20) + 777)
+    cfar, cnear = sb.compress(far, sb.MODE_FULL)[0], sb.compress(near, sb.MODE_FULL)[0]
+    assert len(cfar) < 1400000  # (the later copies of A were found: 1.2 MB; 1.8 MB without them)
+    c = z.Context(0, exec_variant=exec_variant)
+    for frames, want in ([cfar, cnear], [far, near]), ([cnear], [near]), ([cfar], [far]), ([cnear, cfar, cnear], [near, far, near]):
+        outs, sts = _decode(frames, c)
+        assert sts == [0] * len(frames)
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert len(o) == len(w), i
+            if o != w:
+                a, b = np.frombuffer(o, np.uint8), np.frombuffer(w, np.uint8)
+                bad = np.nonzero(a != b)[0]
+                raise AssertionError((i, len(bad), bad[:8].tolist()))
+    c.close()
+
+
 def test_block_mode_many_frames_one_fixup_workgroup_each():
     """1 100 two-block frames with blocks side by side: with that many frames the fix-up walk runs ONE workgroup per frame
     (no waiting between workgroups); fewer frames take several per frame (the tests above)."""

@@ -702,7 +702,8 @@ inline uint32_t rd32(const uint8_t *p)
 // matches reach back over its start into the blocks before it (ringbuffer.go:242-277 RepeatBeforeIndex), up to kMaxOffset --
 // single-segment frames, the window is the content.  (A frame of one block starts with an empty table: unchanged.)
 constexpr int kHashLog = 16;
-constexpr size_t kMaxOffset = (size_t)1 << 27;  // (the device path takes offsets below 2^28)
+static size_t g_max_offset = (size_t)1 << 27;  // (the device path takes offsets below 2^28); synth_set_max_offset: a smaller window
+#define kMaxOffset g_max_offset
 void find_sequences(const uint8_t *src, size_t b0, size_t bn, std::vector<int32_t> &table, std::vector<Seq> &seqs,
                     std::vector<uint8_t> &lits, int min_match, uint32_t rep[3])
 {
@@ -873,6 +874,10 @@ extern "C" {
 
 // frames produced from now on carry a content checksum (FHD bit 2 + 4 bytes after the last block)
 void synth_set_content_checksum(int on) { g_content_checksum = on != 0; }
+
+// matches of the frames produced from now on reach back at most `n` bytes (what zstd's windowLog does: 2^23 at its levels up
+// to 19); 0 restores the default, 2^27
+void synth_set_max_offset(uint64_t n) { g_max_offset = n ? (size_t)std::min<uint64_t>(n, (uint64_t)1 << 27) : (size_t)1 << 27; }
 
 // kinds of content
 enum { SYNTH_TEXT = 0, SYNTH_EXP = 1, SYNTH_RANDOM = 2, SYNTH_ZERO = 3 };

@@ -31,6 +31,8 @@ def lib():
         L.synth_make_batch.restype = u64
         L.synth_set_content_checksum.argtypes = [i32]
         L.synth_set_content_checksum.restype = None
+        L.synth_set_max_offset.argtypes = [u64]
+        L.synth_set_max_offset.restype = None
         _lib = L
     return _lib
 
@@ -38,6 +40,12 @@ def lib():
 def set_content_checksum(on: bool):
     """Frames produced from now on carry the zstd content checksum (low half of XXH64(content, 0))."""
     lib().synth_set_content_checksum(1 if on else 0)
+
+
+def set_max_offset(n: int):
+    """Matches of the frames produced from now on reach back at most n bytes (zstd's windowLog: 2^23 at levels up to 19);
+    0 = the default, 2^27."""
+    lib().synth_set_max_offset(n)
 
 
 def generate(kind: int, seed: int, n: int) -> bytes:
