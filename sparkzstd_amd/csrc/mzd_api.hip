@@ -1450,8 +1450,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         else if (ctx->opt.exec_variant == 0) {
             // (one 1 GiB frame, jobs of 1 / 4 blocks: passes 4 x 1.9 / 2.9 ms, fix-up 12.6 / 5.1 ms; 64 x 128 MiB: 65.4 / 67.3 ms per
             // pass -- with many frames the fix-up walks are short anyway and larger jobs fill the chip's last round worse)
+            // (round 4, the walk's workgroups over all XCDs -- see the launch: one 1 GiB frame, jobs of 2 / 3 / 4 / 6 blocks with as many
+            // workgroups as give every thread one chunk of a job: 40.2 / 32.3 / 29.3 / 31.2 ms; 2 x 512 MiB jobs of 2 / 4: 29.0 / 27.0;
+            // 4 x 256 MiB 24.8 / 26.5; 8 x 256 MiB 38.2 / 34.1; profiles/r4_blk_fixup_spread.txt)
             if (const char *e = exp_env("MZD_EXP_BLK_GS")) blk_gs = (uint32_t)std::max(1, atoi(e));
-            else blk_gs = db->n_frames <= 8 && db->n_blocks >= 4096 ? 2u : 1u;
+            else if (db->n_frames <= 8 && db->n_blocks >= 4096) blk_gs = db->n_frames >= 4 && db->n_frames < 8 ? 2u : 4u;
+            else if (db->n_frames <= 8 && db->n_blocks >= 2048) blk_gs = 2u;
         }
     }
     if (blk) {
@@ -1471,7 +1475,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
                          ensure(db->d_heads, db->cap_heads, ((size_t)db->n_blocks + 2) * 4) == hipSuccess &&
                          ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
-                         ensure(db->d_fixdone, db->cap_fixdone, (size_t)std::min<uint32_t>(db->n_frames, 1024u) * 64 * sizeof(uint32_t)) == hipSuccess &&
+                         ensure(db->d_fixdone, db->cap_fixdone, (size_t)std::min<uint32_t>(db->n_frames, 1024u) * kFixMaxG * sizeof(uint32_t)) == hipSuccess &&
                          ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256) == hipSuccess &&
                          ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride) == hipSuccess;
         if (db->cap_pat != pat_before) db->pat_n = db->pat_np = 0;
@@ -1661,25 +1665,39 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // 1 GiB, 32 / 64 with jobs of two blocks: 49.4 / 44.4 ms, 32 / 64 / 128 with jobs of one: 56.0 / 67.4 / 92.2 ms -- every
             // workgroup is a poller of its frame's counter)
             uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(64u, 1024u / db->n_frames);
-            if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::max(1, atoi(e));  // experiment
+            // Few frames (up to eight): a frame's workgroups on ALL XCDs instead of on one -- one XCD walking a 1 GiB frame moves its
+            // 5 GiB through one L2 (54.8 ms per pass, whatever the number of steps); 128 workgroups over the chip, jobs of four blocks:
+            // 29.3 ms.  As many workgroups as give every thread ONE 16-byte chunk of a job (32 per block of the job: a thread's second
+            // chunk would be loaded behind the wait, idle workgroups are pollers: 96 / 128 / 160 at jobs of four 40.6 / 29.3 / 39.5 ms),
+            // 256 at most over the frames.
+            // Up to four frames 128 workgroups in all, beyond that 256, sixteen per frame at least (2 x 512 MiB, 64 / 128 per frame:
+            // 27.0 / 28.9 ms; 4 x 256 MiB 32 / 64: 24.8 / 32.8; 8 x 256 MiB 16 / 32: 43.1 / 35.0; 16 x 128 MiB 8 / 16 spread / 64 on one XCD
+            // each: 41.3 / 32.6 / 51.4; 32 x 128 MiB 8 / 16 spread / 32 on one XCD: 55.9 / 51.7 / 57.5; 64 x 128 MiB 2 / 4 / 8 spread / 16
+            // on one XCD each: 141.6 / 103.3 / 89.8 / 88.9 -- every workgroup is a poller of its frame's counter).
+            bool spread = db->n_frames <= 64;
+            if (spread) G = std::min<uint32_t>(32u * blk_gs, db->n_frames <= 4 ? 128u / db->n_frames : std::max<uint32_t>(256u / db->n_frames, 16u));
+            if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::min(256, std::max(1, atoi(e)));  // experiment
             // (G > 1: the workgroups of a frame wait for each other.  Should some of them not be resident -- another stream or
             // process on the GPU --, the waiters give up after a bounded wait and a second launch, one workgroup per such frame,
             // finishes the frame's walk from what `d_fixdone` says each workgroup got done: slower, never wrong, never a hang)
-            if (G > 1) (void)hipMemsetAsync(db->d_fixdone, 0, (size_t)db->n_frames * 64 * sizeof(uint32_t), st);
+            if (const char *e = exp_env("MZD_EXP_BLK_SPREAD")) spread = atoi(e) != 0;
+            spread = spread && G > 1;
+            const uint32_t spread_arg = spread ? 1u : 0u, fix_wgs = db->n_frames * G * (G > 1 && !spread ? 8u : 1u);
+            if (G > 1) (void)hipMemsetAsync(db->d_fixdone, 0, (size_t)db->n_frames * kFixMaxG * sizeof(uint32_t), st);
             const uint32_t tb = ctx->test_fixup_bail;
             if (blk_np == 3) {
-                k_blk_fixup<3, false><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames,
-                                                                      db->d_jobs, db->d_bframes, G, blk_gs, db->d_fixdone, tb);
+                k_blk_fixup<3, false><<<fix_wgs, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames,
+                                                                      db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, tb);
                 if (G > 1)
                     k_blk_fixup<3, true><<<db->n_frames, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
-                                                                       db->d_bframes, G, blk_gs, db->d_fixdone, 0u);
+                                                                       db->d_bframes, G, spread_arg, db->d_fixdone, 0u);
             } else {
-                k_blk_fixup<4, false><<<db->n_frames * G * (G > 1 ? 8u : 1u), 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride,
-                                                                      db->d_planes + 2 * stride, db->d_frames, db->d_jobs, db->d_bframes, G, blk_gs,
+                k_blk_fixup<4, false><<<fix_wgs, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride,
+                                                                      db->d_planes + 2 * stride, db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg,
                                                                       db->d_fixdone, tb);
                 if (G > 1)
                     k_blk_fixup<4, true><<<db->n_frames, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
-                                                                       db->d_frames, db->d_jobs, db->d_bframes, G, blk_gs, db->d_fixdone, 0u);
+                                                                       db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, 0u);
             }
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;

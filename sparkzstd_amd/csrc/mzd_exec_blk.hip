@@ -208,6 +208,7 @@ __global__ void k_blk_pattern(uint8_t *pat, uint64_t stride, uint32_t n, uint32_
 // (sc0 sc1); a step is
 // published after a wait for its stores.
 constexpr int kFixK = 2;  // chunks per thread and round
+constexpr uint32_t kFixMaxG = 256;  // fix-up workgroups per frame at most (the stride of `done`)
 
 __device__ __forceinline__ void fix_store16(uint8_t *p, u32x4 v)
 {
@@ -371,13 +372,14 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
 template <int NP, bool RESCUE>
 __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
                                                    const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G,
-                                                   uint32_t gs, uint32_t *done, uint32_t test_bail_step)
+                                                   uint32_t spread, uint32_t *done, uint32_t test_bail_step)
 {
-    // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised): with several workgroups per
-    // frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a step's hand-off
-    // stays inside one L2
+    // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised).  Many frames (`spread` = 0): with
+    // several workgroups per frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a
+    // step's hand-off stays inside one L2.  Few frames (`spread` = 1): the launch is the frames' workgroups and a frame's sit on
+    // all XCDs -- one XCD cannot move a large frame's planes fast enough (mzd_api.hip)
     uint32_t w = blockIdx.x;
-    if (!RESCUE && G > 1) {
+    if (!RESCUE && G > 1 && !spread) {
         w = blockIdx.x >> 3;
         if ((blockIdx.x & 7) != ((w / G) & 7)) return;
     }
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
     const uint8_t *pH = NP == 4 ? pl3 + fr.out_offset : nullptr;  // the plane of the high position bits, written for frames with `high`
     const bool high = NP == 4 && bf->high != 0;
     const uint32_t cstep = G * 256;
-    uint32_t *fdone = done + (size_t)f * 64;
+    uint32_t *fdone = done + (size_t)f * kFixMaxG;
     __shared__ uint32_t go;
     // the frame's jobs after its first (which derives nothing: its blocks follow each other inside one job), in order.
     // (Loading the NEXT job's extent and plane bytes while this job's step runs -- a software pipeline over the jobs -- made the
