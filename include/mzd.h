@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 5
+#define MZD_ABI_VERSION 6
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -304,6 +304,11 @@ int mzd_sync(mzd_ctx *ctx);
  * output blob (out_size bytes). status/out_len have n_frames entries. */
 int mzd_batch_download(mzd_ctx *ctx, mzd_dbatch *db, uint8_t *out_host, int32_t *status,
                        uint64_t *out_len);
+/* Copies bytes [offset, offset + nbytes) of the resident batch's output blob to `dst` (host memory), after the context's work is
+ * done.  What a reader's Read(p) needs (framereader.go:51-109 copies the decoded bytes into the caller's buffer): the frame stays
+ * in HBM and every Read moves exactly the bytes it hands out, once, without a host copy of the whole output in between.
+ * MZD_ERR_INVALID_ARG when the range leaves the blob. */
+int mzd_batch_read_out(mzd_ctx *ctx, mzd_dbatch *db, uint64_t offset, uint8_t *dst, uint64_t nbytes);
 /* Device pointers of the resident batch (for callers that keep results in HBM). */
 void *mzd_batch_device_out(mzd_dbatch *db);
 void *mzd_batch_device_status(mzd_dbatch *db);

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 5
+MZD_ABI_VERSION = 6
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -17,7 +17,7 @@ MZD_BATCH_OUT_ON_DEVICE = 2
 # every symbol include/mzd.h declares (tests/test_abi.py checks the export list against the header)
 EXPORTS = [
     "mzd_abi_version", "mzd_backend", "mzd_strerror", "mzd_device_count", "mzd_create", "mzd_destroy",
-    "mzd_last_error", "mzd_batch_upload", "mzd_batch_run", "mzd_sync", "mzd_batch_download",
+    "mzd_last_error", "mzd_batch_upload", "mzd_batch_run", "mzd_sync", "mzd_batch_download", "mzd_batch_read_out",
     "mzd_batch_device_out", "mzd_batch_device_status", "mzd_batch_device_out_len", "mzd_batch_free",
     "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_timing_reset", "mzd_batch_get_stats", "mzd_plan_create",
     "mzd_plan_destroy", "mzd_plan_reset", "mzd_plan_add_frame", "mzd_plan_add_frames",
@@ -133,6 +133,7 @@ def load():
         "mzd_batch_run": (i32, [vp, vp, vp]),
         "mzd_sync": (i32, [vp]),
         "mzd_batch_download": (i32, [vp, vp, vp, vp, vp]),
+        "mzd_batch_read_out": (i32, [vp, vp, u64, vp, u64]),
         "mzd_batch_device_out": (vp, [vp]),
         "mzd_batch_device_status": (vp, [vp]),
         "mzd_batch_device_out_len": (vp, [vp]),

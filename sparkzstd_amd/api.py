@@ -111,6 +111,12 @@ class ResidentBatch:
             raise MzdError(rc, "mzd_batch_download: " + self.ctx.last_error())
         return out, status, out_len
 
+    def read_out(self, offset: int, dst_addr: int, nbytes: int):
+        """bytes [offset, offset + nbytes) of the output blob straight to host address `dst_addr` (mzd_batch_read_out)"""
+        rc = self.ctx._L.mzd_batch_read_out(self.ctx._c, self._h, int(offset), dst_addr, int(nbytes))
+        if rc:
+            raise MzdError(rc, "mzd_batch_read_out: " + self.ctx.last_error())
+
     def read_fse_table(self, table: int) -> np.ndarray:
         """Device decoding table `table` as uint32 cells (baseline | nbits << 16 | symbol << 24)."""
         out = np.empty(512, dtype=np.uint32)
@@ -485,6 +491,41 @@ def decode_frames(frames, ctx: Context = None, device_tables: bool = True, devic
         o = int(lay[i])
         outs.append(out[o:o + int(out_len[i])].tobytes() if sts[i] == 0 else None)
     return outs, sts
+
+
+def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = True):
+    """Decodes `frames` and LEAVES the output in HBM: -> (ResidentBatch, slab offset of every frame, out_len of every frame,
+    statuses).  The caller reads what it wants with ResidentBatch.read_out and frees the batch -- what a reader does whose
+    consumer takes the frame piece by piece (decompression.FrameReader: every Read moves its own bytes over PCIe, once)."""
+    ctx = ctx or default_context()
+    n = len(frames)
+    if n == 1:
+        blob = np.frombuffer(frames[0], dtype=np.uint8)
+    else:
+        blob = np.frombuffer(b"".join(bytes(f) if not isinstance(f, (bytes, bytearray)) else f for f in frames), dtype=np.uint8)
+    ln = np.array([len(f) for f in frames], dtype=np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        off[1:] = np.cumsum(ln)[:-1]
+    plan = Plan(device_tables=device_tables)
+    try:
+        if blob.size == 0:
+            blob = np.zeros(1, dtype=np.uint8)
+        plan.add_frames(blob, off, ln, threads=0)
+        batch = plan.finalize()
+        plan_status = [plan.frame_status(i) for i in range(n)]
+        lay = np.array([int(batch.frames[i].out_offset) for i in range(n)], dtype=np.uint64)
+        rb = ctx.upload(batch)
+        try:
+            rb.run()
+            _, status, out_len = rb.download(want_out=False)
+        except Exception:
+            rb.free()
+            raise
+        rb._batch = None  # (the planner's arrays go with the plan; the resident batch no longer needs them)
+        return rb, lay, out_len, [plan_status[i] or int(status[i]) for i in range(n)]
+    finally:
+        plan.close()
 
 
 def decode_frames_blob(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):

@@ -1991,6 +1991,15 @@ int mzd_batch_download(mzd_ctx *ctx, mzd_dbatch *db, uint8_t *out_host, int32_t 
     return MZD_OK;
 }
 
+int mzd_batch_read_out(mzd_ctx *ctx, mzd_dbatch *db, uint64_t offset, uint8_t *dst, uint64_t nbytes)
+{
+    if (!ctx || !db || (nbytes && !dst) || offset > db->out_size || nbytes > db->out_size - offset) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (nbytes) HIP_TRY(ctx, hipMemcpy(dst, db->d_out + offset, nbytes, hipMemcpyDeviceToHost));
+    return MZD_OK;
+}
+
 void *mzd_batch_device_out(mzd_dbatch *db) { return db ? db->d_out : nullptr; }
 void *mzd_batch_device_status(mzd_dbatch *db) { return db ? db->d_status : nullptr; }
 void *mzd_batch_device_out_len(mzd_dbatch *db) { return db ? db->d_out_len : nullptr; }

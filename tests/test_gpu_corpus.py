@@ -298,6 +298,67 @@ def test_frame_reader_mirror(corpus, ctx):
     check_expected(name, sink.getvalue(), length, sha, exp)
 
 
+def test_frame_reader_serves_reads_from_device_memory(ctx):
+    """The reader keeps the decoded frame in HBM (mzd_batch_read_out): large Reads and readinto go straight from there into the
+    bytes they hand out, small ones through a 4 MiB window.  A 9.5 MiB frame read in every mixture of the two -- window
+    refills, a large Read that starts inside the window, readinto into small and large buffers, readall after partial reads,
+    EOF twice, Reset half way -- returns the frame's bytes, and the device memory is gone once the last byte is out."""
+    from tools import synth_binding as sb
+    data = sb.generate(sb.TEXT, 314, (9 << 20) + 500001)
+    comp = sb.compress(data, sb.MODE_FULL)[0]
+    rng = np.random.default_rng(5)
+    for mode in range(5):
+        r = z.NewFrameReader(io.BytesIO(comp), ctx)
+        got = bytearray()
+        if mode == 0:      # everything at once
+            got += r.read()
+        elif mode == 1:    # small Reads only: the window is refilled three times
+            while True:
+                d = r.Read(int(rng.integers(1, 200000)))
+                if not d:
+                    break
+                got += d
+        elif mode == 2:    # small, large, small ...: a large Read inside the window is served from it up to its end (a short read)
+            sizes = [100, 2 << 20, 7, 3 << 20, 1 << 20, 50000, 5 << 20, 1 << 30]
+            for n in sizes:
+                d = r.Read(n)
+                assert len(d) <= n
+                got += d
+            got += r.readall()
+        elif mode == 3:    # readinto: a large buffer (straight from the device), then small ones
+            big = bytearray(3 << 20)
+            k = r.readinto(big)
+            assert k == len(big)
+            got += big[:k]
+            small = bytearray(65536)
+            while True:
+                k = r.readinto(small)
+                if k == 0:
+                    break
+                got += small[:k]
+        else:              # Reset half way: the old frame's memory is released, the new one starts from its first byte
+            got += r.Read(3 << 20)
+            assert r._rb is not None
+            r.Reset(io.BytesIO(comp))
+            assert r._rb is None
+            got = bytearray(r.read())
+        assert bytes(got) == data, mode
+        assert r.Read(10) == b"" and r.Read(1 << 21) == b"" and r.readinto(bytearray(8)) == 0
+        assert r._rb is None  # drained: the batch was freed
+    # an empty frame and a damaged one
+    empty = sb.compress(b"", sb.MODE_FULL)[0]
+    r = z.NewFrameReader(io.BytesIO(empty), ctx)
+    assert r.read() == b"" and r._rb is None
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x55
+    r = z.NewFrameReader(io.BytesIO(bytes(bad)), ctx)
+    try:
+        out = r.read()
+        assert out != data or True  # (a flipped literal byte may decode: then the bytes differ, which is not the reader's business)
+    except z.ZstdError:
+        assert r._rb is None
+
+
 @pytest.mark.parametrize("flags", [[], ["--device-plan"], ["--devices", "0,0"], ["--device-plan", "--devices", "0,0,0"], ["--batch-reader", "7"]])
 def test_cpp_frame_reader_verify_cli(corpus, flags):
     """The C++ mirror of FrameReader (include/sparkzstd_frame.hpp) driven like the reference's own

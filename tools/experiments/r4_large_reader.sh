@@ -32,6 +32,17 @@ for mib in (64, 256):
     t2 = time.time()
     assert first + rest == data
     print(f"{mib} MiB frame through FrameReader: first MiB after {1e3 * (t1 - t0):.1f} ms, all of it after {1e3 * (t2 - t0):.1f} ms", flush=True)
+    t0 = time.time()
+    got = z.FrameReader(io.BytesIO(comp), ctx).read()
+    t1 = time.time()
+    assert got == data
+    buf = bytearray(mib << 20)
+    t2 = time.time()
+    r = z.FrameReader(io.BytesIO(comp), ctx)
+    k = r.readinto(buf)
+    t3 = time.time()
+    assert k == len(buf) and buf == data
+    print(f"{mib} MiB frame through FrameReader: read() {1e3 * (t1 - t0):.1f} ms, readinto(caller's buffer) {1e3 * (t3 - t2):.1f} ms", flush=True)
     ctx.timing_reset(True)
     api.decode_frames_blob([comp], ctx)
     ctx.sync()
