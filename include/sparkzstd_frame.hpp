@@ -289,10 +289,13 @@ class FrameReader {
     {
         if (source) Reset(source);
     }
+    FrameReader(const FrameReader &) = delete;
+    FrameReader &operator=(const FrameReader &) = delete;
+    ~FrameReader() { release(); }
     void Reset(std::istream *source)  // framereader.go:35-49: magic number + frame header are checked here
     {
-        buffer_.clear();
-        pos_ = 0;
+        release();
+        pos_ = len_ = off_ = 0;
         decoded_ = false;
         source_ = source;
         head_.clear();
@@ -306,33 +309,91 @@ class FrameReader {
         }
     }
     // Read(p []byte) (int, error) -- framereader.go:51-109: up to n bytes; 0 == io.EOF (only after the
-    // last block has been drained)
+    // last block has been drained).  The frame is decoded at the first Read and stays in HBM: a Read of 1 MiB or more is ONE
+    // copy from there into p (mzd_batch_read_out), smaller ones come out of a 4 MiB window fetched the same way; the device
+    // memory is released with the last byte.
     size_t Read(uint8_t *p, size_t n)
     {
-        if (!decoded_) {
-            std::vector<uint8_t> frame(head_.begin(), head_.end());
-            frame.insert(frame.end(), std::istreambuf_iterator<char>(*source_), std::istreambuf_iterator<char>());
-            std::vector<int> st;
-            auto out = DecodeFrames({frame}, &st, ctx_);
-            if (st[0] != MZD_OK) throw Error(st[0], "Read");
-            buffer_ = std::move(out[0]);
-            decoded_ = true;
+        if (!decoded_) decode();
+        n = std::min<uint64_t>(n, len_ - pos_);
+        if (n == 0) return 0;
+        const bool in_window = pos_ >= win_lo_ && pos_ < win_hi_;
+        if (n >= kDirect && !in_window) {
+            const int rc = mzd_batch_read_out(ctx_, db_, off_ + pos_, p, n);
+            if (rc != MZD_OK) throw Error(rc, std::string("mzd_batch_read_out (") + mzd_last_error(ctx_) + ")");
+        } else {
+            if (!in_window) {
+                window_.resize((size_t)std::min<uint64_t>(kWindow, len_));
+                win_lo_ = pos_;
+                win_hi_ = std::min<uint64_t>(pos_ + window_.size(), len_);
+                const int rc = mzd_batch_read_out(ctx_, db_, off_ + win_lo_, window_.data(), win_hi_ - win_lo_);
+                if (rc != MZD_OK) throw Error(rc, std::string("mzd_batch_read_out (") + mzd_last_error(ctx_) + ")");
+            }
+            n = std::min<uint64_t>(n, win_hi_ - pos_);
+            std::memcpy(p, window_.data() + (pos_ - win_lo_), n);
         }
-        const size_t k = std::min(n, buffer_.size() - pos_);
-        std::memcpy(p, buffer_.data() + pos_, k);
-        pos_ += k;
-        readTotal_ += k;
-        return k;
+        pos_ += n;
+        readTotal_ += n;
+        if (pos_ >= len_) release();
+        return n;
     }
     bool PrintStatus = false;
 
   private:
+    static constexpr size_t kDirect = (size_t)1 << 20, kWindow = (size_t)4 << 20;
+    void release()
+    {
+        if (db_) mzd_batch_free(ctx_, db_);
+        db_ = nullptr;
+        win_lo_ = win_hi_ = 0;
+        std::vector<uint8_t>().swap(window_);
+    }
+    void decode()
+    {
+        if (!ctx_) ctx_ = default_context();
+        std::vector<uint8_t> frame(head_.begin(), head_.end());
+        frame.insert(frame.end(), std::istreambuf_iterator<char>(*source_), std::istreambuf_iterator<char>());
+        int32_t dst = MZD_OK;
+        uint64_t len = 0;
+        int st = MZD_OK, rc;
+        if (DevicePlanning()) {
+            const uint64_t o = 0, l = frame.size();
+            rc = mzd_batch_upload_frames(ctx_, frame.data(), frame.size(), 0, &o, &l, 1, nullptr, 0, &db_);
+            if (rc == MZD_OK) rc = mzd_batch_run(ctx_, db_, nullptr);
+            if (rc == MZD_OK) rc = mzd_batch_download(ctx_, db_, nullptr, &dst, &len);
+            if (rc == MZD_OK) rc = mzd_batch_frame_layout(db_, &off_, nullptr);
+        } else {
+            mzd_plan *plan = mzd_plan_create();
+            mzd_plan_set_device_tables(plan, 1);
+            st = mzd_plan_add_frame(plan, frame.data(), frame.size(), nullptr);
+            const mzd_batch *b = mzd_plan_finalize(plan);
+            rc = mzd_batch_upload(ctx_, b, &db_);
+            if (rc == MZD_OK) rc = mzd_batch_run(ctx_, db_, nullptr);
+            if (rc == MZD_OK) rc = mzd_batch_download(ctx_, db_, nullptr, &dst, &len);
+            if (rc == MZD_OK) off_ = b->frames[0].out_offset;
+            mzd_plan_destroy(plan);
+        }
+        if (rc != MZD_OK) {
+            const std::string why = mzd_last_error(ctx_);
+            release();
+            throw Error(rc, "Read (" + why + ")");
+        }
+        if (st == MZD_OK) st = dst;
+        if (st != MZD_OK) {
+            release();
+            throw Error(st, "Read");
+        }
+        len_ = len;
+        pos_ = 0;
+        decoded_ = true;
+        if (len_ == 0) release();
+    }
     std::istream *source_ = nullptr;
     mzd_ctx *ctx_ = nullptr;
+    mzd_dbatch *db_ = nullptr;
     std::vector<char> head_;
-    std::vector<uint8_t> buffer_;
-    size_t pos_ = 0;
-    uint64_t readTotal_ = 0;
+    std::vector<uint8_t> window_;
+    uint64_t off_ = 0, len_ = 0, pos_ = 0, win_lo_ = 0, win_hi_ = 0, readTotal_ = 0;
     bool decoded_ = false;
 };
 

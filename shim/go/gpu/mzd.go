@@ -133,6 +133,76 @@ func concat(frames [][]byte) (blob []byte, off, ln []uint64) {
 	return
 }
 
+// ResidentFrame is ONE frame decoded and left in HBM: what decompression.FrameReader holds between its Reads when the consumer
+// takes a large frame piece by piece (framereader.go:51-109 copies the decoded bytes into p; here ReadAt copies them from the
+// device into p, once, without a host copy of the whole frame in between -- mzd_batch_read_out).
+type ResidentFrame struct {
+	x   *Context
+	db  *C.mzd_dbatch
+	off uint64 // the frame's slab in the output blob
+	Len uint64 // regenerated bytes
+}
+
+// DecodeFrameResident plans `frame` on the device, decodes it and returns it resident; Free releases the device memory.
+func (x *Context) DecodeFrameResident(frame []byte) (*ResidentFrame, error) {
+	if len(frame) == 0 {
+		return nil, SentinelFor(1)
+	}
+	x.mu.Lock()
+	defer x.mu.Unlock()
+	off, ln := C.uint64_t(0), C.uint64_t(len(frame))
+	var db *C.mzd_dbatch
+	rc := C.mzd_batch_upload_frames(x.c, (*C.uint8_t)(unsafe.Pointer(&frame[0])), ln, 0, &off, &ln, 1, nil, 0, &db)
+	if rc != C.MZD_OK {
+		return nil, errors.New("mzd_batch_upload_frames: " + x.lastError())
+	}
+	var status C.int32_t
+	var outLen, slab C.uint64_t
+	if rc = C.mzd_batch_run(x.c, db, nil); rc == C.MZD_OK {
+		rc = C.mzd_batch_download(x.c, db, nil, &status, &outLen)
+	}
+	if rc == C.MZD_OK {
+		rc = C.mzd_batch_frame_layout(db, &slab, nil)
+	}
+	runtime.KeepAlive(frame)
+	if rc != C.MZD_OK {
+		C.mzd_batch_free(x.c, db)
+		return nil, errors.New("mzd_batch_run: " + x.lastError())
+	}
+	if e := SentinelFor(int32(status)); e != nil {
+		C.mzd_batch_free(x.c, db)
+		return nil, e
+	}
+	return &ResidentFrame{x: x, db: db, off: uint64(slab), Len: uint64(outLen)}, nil
+}
+
+// ReadAt copies bytes [pos, pos+len(p)) of the frame into p (clipped to the frame's end) and returns how many.
+func (r *ResidentFrame) ReadAt(p []byte, pos uint64) (int, error) {
+	if r.db == nil || pos >= r.Len || len(p) == 0 {
+		return 0, nil
+	}
+	n := uint64(len(p))
+	if n > r.Len-pos {
+		n = r.Len - pos
+	}
+	r.x.mu.Lock()
+	defer r.x.mu.Unlock()
+	if rc := C.mzd_batch_read_out(r.x.c, r.db, C.uint64_t(r.off+pos), (*C.uint8_t)(unsafe.Pointer(&p[0])), C.uint64_t(n)); rc != C.MZD_OK {
+		return 0, errors.New("mzd_batch_read_out: " + r.x.lastError())
+	}
+	return int(n), nil
+}
+
+// Free releases the frame's device memory (idempotent).
+func (r *ResidentFrame) Free() {
+	if r.db != nil {
+		r.x.mu.Lock()
+		C.mzd_batch_free(r.x.c, r.db)
+		r.x.mu.Unlock()
+		r.db = nil
+	}
+}
+
 // DecodeFrames decodes many independent zstd frames in ONE device batch (the entry where the device pays off;
 // the reference decodes one frame per FrameReader, cmd/sparkzstd/main.go:59,126).  out[i] is nil where errs[i] != nil.
 func (x *Context) DecodeFrames(frames [][]byte) (out [][]byte, errs []error, err error) {
