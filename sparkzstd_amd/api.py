@@ -8,6 +8,15 @@ from . import _lib
 from ._lib import Batch, BatchStats, Options
 
 
+# a bytes object that the copy engine fills before anybody sees it (the C API's way: PyBytes_FromStringAndSize(NULL, n))
+_PyBytes_New = ctypes.pythonapi.PyBytes_FromStringAndSize
+_PyBytes_New.restype = ctypes.py_object
+_PyBytes_New.argtypes = [ctypes.c_char_p, ctypes.c_ssize_t]
+_PyBytes_AsString = ctypes.pythonapi.PyBytes_AsString
+_PyBytes_AsString.restype = ctypes.c_void_p
+_PyBytes_AsString.argtypes = [ctypes.py_object]
+
+
 class MzdError(RuntimeError):
     def __init__(self, code, where=""):
         self.code = code
@@ -485,6 +494,28 @@ def decode_frames(frames, ctx: Context = None, device_tables: bool = True, devic
         else:
             return decode_frames_multi(frames, devices, device_tables=device_tables, device_plan=device_plan)
     ctx = ctx or default_context()
+    # few large frames: every frame's bytes go from HBM straight into the bytes object that is returned (mzd_batch_read_out) --
+    # a host blob first and a copy per frame out of it was most of the host side (one 256 MiB frame: 90.8 ms against 37.3 for
+    # the blob alone).  Many frames: one download and a slice each (a copy-engine call per 128 KiB frame would cost more).
+    total = sum(len(f) for f in frames)
+    if not device_plan and 0 < len(frames) <= 64 and total >= (4 << 20) * len(frames) // 4:
+        rb, lay, out_len, sts = decode_frames_resident(frames, ctx, device_tables=device_tables)
+        try:
+            outs = []
+            for i in range(len(sts)):
+                if sts[i] != 0:
+                    outs.append(None)
+                    continue
+                n = int(out_len[i])
+                if n == 0:
+                    outs.append(b"")
+                    continue
+                obj = _PyBytes_New(None, n)
+                rb.read_out(int(lay[i]), _PyBytes_AsString(obj), n)
+                outs.append(obj)
+        finally:
+            rb.free()
+        return outs, sts
     out, lay, out_len, sts = decode_frames_blob(frames, ctx, device_tables=device_tables, device_plan=device_plan)
     outs = []
     for i in range(len(sts)):

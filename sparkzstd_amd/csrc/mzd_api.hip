@@ -30,13 +30,11 @@ struct mzd_ctx {
     mzd_options opt{};
     std::string last_error;
     hipStream_t stream2 = nullptr;  // the execution kernel of the head of a split batch runs here
-    hipStream_t stream2_low = nullptr;  // experiment
     hipEvent_t ev_head_ready = nullptr, ev_head_done = nullptr, ev_init_done = nullptr, ev_huf_done = nullptr;
     int num_cus = 256;
     // HIP events around every kernel of every mzd_batch_run since the last mzd_timing_reset
     std::vector<hipEvent_t> ev;  // kEvPerRun per run
     std::vector<uint8_t> run_split;
-    std::vector<hipEvent_t> ev_slice;  // experiment: one per slice of the sequence stage
     size_t runs = 0;
     bool timing = true;
     bool attr_set = false;
@@ -1524,25 +1522,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             fA = lo;
         }
     }
-    std::vector<uint32_t> slices;
-    if (const char *e = exp_env("MZD_EXP_SLICES")) {
-        if (!ctx->opt.no_split && !serial && exec_c && db->n_seq_tasks > per_round) {
-            const uint64_t rounds_total = (db->n_seq_tasks + per_round - 1) / per_round;
-            const uint64_t rps = std::max<uint64_t>(1, (rounds_total + (uint64_t)std::max(1, atoi(e)) - 1) / (uint64_t)std::max(1, atoi(e)));
-            slices.push_back(0);
-            for (uint64_t lim = rps * per_round; lim < db->n_seq_tasks; lim += rps * per_round) {
-                uint32_t lo = 0, hi = db->n_frames;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1) / 2;
-                    if (db->frame_seq_task[mid] <= lim) lo = mid;
-                    else hi = mid - 1;
-                }
-                if (lo > slices.back() && lo < db->n_frames) slices.push_back(lo);
-            }
-            slices.push_back(db->n_frames);
-            if (slices.size() > 2) fA = slices[1];
-        }
-    }
     const bool split = fA < db->n_frames;
 
     hipEvent_t *ev = nullptr;
@@ -1728,14 +1707,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     //   s  : k_init -> k_seq(head) -> k_seq(tail) -> [wait huf] k_exec(tail) -> [wait head done]
     //   s2 : [wait init] k_huf -> [wait k_seq(head)] k_exec(head)
     hipStream_t s2 = ctx->stream2;
-    if (exp_env("MZD_EXP_S2_LOW")) {  // experiment: the second stream at the lowest priority (the sequence stage's workgroups first)
-        if (!ctx->stream2_low) {
-            int lo_p = 0, hi_p = 0;
-            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2_low, hipStreamNonBlocking, lo_p));
-        }
-        s2 = ctx->stream2_low;
-    }
     if (db->n_huf_tasks == 0 && db->n_seq_tasks == 0 && db->stats.n_blocks[2] == 0) {
         // Nothing but Raw / RLE blocks (BASELINE configs[1]): the pass IS the copy kernel -- no summaries to reset,
         // no second stream, no cross-stream events in front of it (they cost more than the 0.2 ms copy itself).
@@ -1833,40 +1804,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
     }
-    if (slices.size() > 2) {
-        // experiment (MZD_EXP_SLICES): the sequence stage in slices of whole rounds, the execution of each slice on the second
-        // stream beside the sequence stage of the next ones; the last slice's execution on the caller's stream
-        const size_t ns = slices.size() - 1;
-        while (ctx->ev_slice.size() < ns) {
-            hipEvent_t e;
-            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->ev_slice.push_back(e);
-        }
-        for (size_t i = 0; i + 1 < ns; i++) {
-            if (i > 0) {
-                seq_pack = true;
-                launch_seq(slices[i], slices[i + 1]);
-            }
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_slice[i], s));
-            HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_slice[i], 0));
-            if (ev && i == 0) HIP_TRY(ctx, hipEventRecord(ev[6], s2));
-            launch_exec(s2, slices[i], slices[i + 1] - slices[i]);
-            launch_verify(s2, slices[i], slices[i + 1] - slices[i]);
-        }
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[7], s2));
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[10], s2));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s2));
-        seq_pack = true;
-        launch_seq(slices[ns - 1], db->n_frames);
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
-        launch_exec(s, slices[ns - 1], db->n_frames - slices[ns - 1]);
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
-        launch_verify(s, slices[ns - 1], db->n_frames - slices[ns - 1]);
-        if (ev) HIP_TRY(ctx, hipEventRecord(ev[11], s));
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_head_done, 0));
-    } else if (split) {
+    if (split) {
         seq_pack = true;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_head_ready, s));
         HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_head_ready, 0));

@@ -1,3 +1,4 @@
+# (-DMZD_FIX_LOCAL was never committed: two lines of mzd_exec_blk.hip, see profiles/r4_blk_fixup_local_l2.txt)
 # block mode's fix-up walk with the hand-off kept inside the frame's XCD (plain stores, the counter's atomic without scope bits: the
 # lines stay in that L2; gathers bypass L1 only) against write-through stores and agent-scope atomics
 pick() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['roofline']['kernel_ms'], d['bit_exact'])" "$1"; }

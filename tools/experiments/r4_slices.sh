@@ -1,3 +1,4 @@
+# (the MZD_EXP_SLICES / MZD_EXP_S2_LOW hooks lived in commit 8e291ae only; result: profiles/r4_seq_exec_slices.txt)
 # the sequence stage in slices of whole rounds, each slice's execution beside the sequence stage of the next (MZD_EXP_SLICES),
 # with fewer chains per CU (MZD_SEQ_NCH: LDS left for execution wavefronts) and the second stream at low priority (MZD_EXP_S2_LOW)
 pick() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['roofline']['kernel_ms'], d['bit_exact'])" "$1"; }
