@@ -1634,11 +1634,20 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 db->pat_n = (uint32_t)(blk_maxcap + 64);
                 db->pat_np = blk_np;
             }
-            for (uint32_t p = 0; p < blk_np; p++)
-                k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(  // (as many wavefronts as blocks: the ones beyond the job list exit)
-                    db->d_in, p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
-                    db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u,
-                    XbBlk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p});
+            // the passes: k_exec_c's method (exec_variant 0 and 4), k_exec_b's (3: the parity tests keep both alive)
+            bool blk_xc = ctx->opt.exec_variant != 3;
+            if (exp_env("MZD_EXP_BLK_XB")) blk_xc = false;  // experiment: the round-3 passes
+            for (uint32_t p = 0; p < blk_np; p++) {
+                uint8_t *plane = p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride;
+                const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p};
+                // (as many wavefronts as blocks: the ones beyond the job list exit)
+                if (blk_xc)
+                    k_exec_c<true><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                                                             db->d_status, db->d_out_len, nullptr, 0u, bk);
+                else
+                    k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                                                                        db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
+            }
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
             // (frames whose blocks reach back -- 64 x 128 MiB, 8 / 16 / 32 per frame: 113.8 / 103.7 / 114.8 ms per pass; one frame of
             // 1 GiB, 32 / 64 with jobs of two blocks: 49.4 / 44.4 ms, 32 / 64 / 128 with jobs of one: 56.0 / 67.4 / 92.2 ms -- every
@@ -1682,8 +1691,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             return;
         }
         if (exec_c) {
-            k_exec_c<<<count, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf, db->d_status,
-                                           db->d_out_len, db->d_frame_order, first);
+            k_exec_c<false><<<count, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf, db->d_status,
+                                           db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
         if (exec_b) {

@@ -162,31 +162,61 @@ __device__ __noinline__ uint2 xc_resolve_in_pass(uint32_t va, uint32_t vb, int r
     return make_uint2(sa & 0xFF, sb & 0xFF);
 }
 
+// BM (block mode, mzd_exec_blk.hip): as k_exec_b<true> -- the wavefront's job is ONE SEGMENT of a frame (a few consecutive blocks
+// with sequences, from a block flagged kBjHead to the next; a Raw / RLE / literal-only block is a job of its own), `out_blob` is
+// the plane of this pass, and whatever lies before the segment's start S is read from the pass's pattern `bk.pat`: the ring is
+// preloaded with it, staged and far reads below S go to it.
+template <bool BM>
 __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
                                                   int32_t *frame_status, uint64_t *frame_out_len,
-                                                  const uint32_t *__restrict__ order, uint32_t first)
+                                                  const uint32_t *__restrict__ order, uint32_t first, XbBlk bk)
 {
     __shared__ __attribute__((aligned(128))) XcLds sh;
     const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
-    const uint32_t fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    uint32_t fidx, bi0 = 0;
+    BJob jb{};
+    if (BM) {
+        if (blockIdx.x >= bk.heads[0]) return;  // (the job list k_blk_scan made: heads[0] jobs, heads[1 + j] = job j's first block)
+        const uint32_t g = bk.heads[1 + blockIdx.x];
+        jb = bk.jobs[g];
+        fidx = jb.frame;
+        bi0 = g;  // (global for now)
+    } else {
+        fidx = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    }
     const DFrame fr = frames[fidx];
     uint8_t *out = out_blob + fr.out_offset;
+    if (BM) {
+        bi0 -= fr.first_block;
+        // the passes after the first are for segments that can derive bytes from before their start
+        if ((jb.flags & kBjSkip) || (bk.pass > 0 && (bi0 == 0 || (jb.flags & kBjDirect)))) return;
+        // the pass of the position's high bits is for frames whose matches may reach back 8 MiB or more (k_blk_scan)
+        if (bk.pass == 3 && !bk.bframes[fidx].high) return;
+    }
+    const uint32_t S = BM ? jb.start : 0u;  // the segment's first byte (block mode)
+    const uint8_t *const pat = bk.pat;
 
-    int error = fr.plan_status;
-    uint32_t outPos = 0;         // bytes of this frame produced so far (frames of 4 GiB and more take k_exec)
-    uint32_t flushed = 0;        // [0, flushed) has left for the slab (the youngest units may still be in flight)
-    uint32_t confirmed = 0;      // [0, confirmed) has ARRIVED in the slab: a wait on memory came after its stores
+    int error = BM ? (int)MZD_OK : fr.plan_status;
+    uint32_t outPos = S;         // bytes of this frame produced so far (frames of 4 GiB and more take k_exec)
+    uint32_t flushed = S;        // [0, flushed) has left for the slab (the youngest units may still be in flight)
+    uint32_t confirmed = S;      // [0, confirmed) has ARRIVED in the slab: a wait on memory came after its stores
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
+    if (BM) {
+        H0 = jb.H0;
+        H1 = jb.H1;
+        H2 = jb.H2;
+    }
     // LDS addresses of the areas the predicated stores go to (the kernel's only shared object: its offset is what the
     // compiler assigned, normally 0; the region arithmetic below is relative to it)
     const uint32_t ldsBase = (uint32_t)(uintptr_t)&sh;
     const uint32_t tabA = ldsBase + (uint32_t)offsetof(XcLds, table), bitsA = ldsBase + (uint32_t)offsetof(XcLds, bits);
     for (int i = lane; i < 132; i += 64) sh.table[i] = 0u;
     if (lane < (int)(kXcStretch / 32)) sh.bits[lane] = 0u;
-    uint32_t bi = 0;
+    if (BM && S > 0 && !(jb.flags & kBjDirect)) xc_reload_window(sh.win, pat, S, lane);  // the ring's view of the frame before the segment
+    uint32_t bi = bi0;
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
     uint32_t vwmask = kXcWin - 1;
     uint32_t lblo = lane < 32 ? 1u << lane : 0u, lbhi = lane < 32 ? 0u : 1u << (lane - 32);
@@ -199,6 +229,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
 #endif
 
     for (; bi < fr.n_blocks && error == MZD_OK; bi++) {
+        // (block mode: the job ends where the next one starts, or where the frame ended)
+        if (BM && bi > bi0 && (bk.jobs[fr.first_block + bi].flags & (kBjHead | kBjSkip))) break;
         const DBlock b = blocks[fr.first_block + bi];
         if (b.type != MZD_BLOCK_COMPRESSED) {
             // Raw (framedecompressor.go:211-215) / RLE (:229-241): straight copy / fill
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
-            xc_reload_window(sh.win, out, outPos, lane);
+            if (!BM) xc_reload_window(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -238,7 +270,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
-            xc_reload_window(sh.win, out, outPos, lane);
+            if (!BM) xc_reload_window(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -344,8 +376,10 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             const bool stg = farm && P == T.start && sEnd == T.E && T.ML >= 3 && T.ML <= kXcStageMl && q0 + T.ML <= confirmed &&
                              (T.mstart & (kXcWin - 1)) + kXcStageMl <= kXcWin;
 #else
-            const bool stg = farm && T.ML <= kXcStageMl && q0 + T.ML <= confirmed;
+            // (block mode: a source that straddles the segment's start is left to the pass)
+            const bool stg = farm && T.ML <= kXcStageMl && q0 + T.ML <= confirmed && (!BM || q0 >= S || q0 + T.ML <= S);
 #endif
+            const uint8_t *const rb = BM && q0 < S ? pat : (const uint8_t *)out;
             N.stg = wave_ballot(stg);
             N.stg2 = wave_ballot(stg && T.ML > 16);
             N.farwin = wave_ballot(farm && !stg);
@@ -353,8 +387,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             // all 64 lanes loading, idle ones from one hot line, TA_TA_BUSY went from 46 % to 81 % of the kernel's time)
             N.sv = N.sv2 = U128U{0, 0, 0, 0};
 #ifndef MZD_ABL_XC_NOSTAGE
-            if (stg) N.sv = *(const U128U *)(out + q0);
-            if (stg && T.ML > 16) N.sv2 = *(const U128U *)(out + q0 + 16);
+            if (stg) N.sv = *(const U128U *)(rb + q0);
+            if (stg && T.ML > 16) N.sv2 = *(const U128U *)(rb + q0 + 16);
 #endif
             // the stretch's literals: [la, lb) of the block's literals (lb <= lit_regen)
             N.lv = 0;
@@ -639,8 +673,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                         const uint32_t offa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ea & 63) << 2), T.off);
                         const uint32_t offb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((eb & 63) << 2), T.off);
                         // (a byte this far back has left the ring for the slab: off > kXcNear and the units up to P0 - 511 are out)
-                        if (fa) va = out[pa - offa];
-                        if (fb) vb = out[pb - offb];
+                        if (fa) va = (BM && pa - offa < S ? pat : (const uint8_t *)out)[pa - offa];
+                        if (fb) vb = (BM && pb - offb < S ? pat : (const uint8_t *)out)[pb - offb];
                     }
                     sh.win[wa] = (uint8_t)va;
                     sh.win[wb] = (uint8_t)vb;
@@ -688,6 +722,11 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
         }
     }
     if (error == MZD_OK) flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);
+    if (BM) {
+        // an offset beyond the produced data (the one defect the scan cannot see): the frame ends at its first such block
+        if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi);
+        return;
+    }
 #ifdef MZD_XC_STATS
     xcst[11] = XC_CLOCK() - xc_t0;
     xcst[12] = 1;
