@@ -225,11 +225,12 @@ typedef struct mzd_options {
                                  self-synchronise); 3 = k_huf first with the transposed bulk phase; see DESIGN.md */
     uint32_t exec_variant;    /* execution kernel: 0 = by the batch; 1 = k_exec (a workgroup per frame, a lane per sequence,
                                  dataflow on an 8 KiB LDS chunk); 2 = k_exec_b (a wavefront per frame, a lane per output
-                                 byte, strictly in order; 7.7 KiB of LDS per frame); 3 = k_exec_b in BLOCK MODE (a wavefront
-                                 per block: the blocks of a frame side by side, 3 or 4 passes + an in-order fix-up walk;
-                                 frames below 2 GiB) -- what 0 picks for batches of few large frames; 4 = the same with jobs
-                                 of four consecutive blocks (fewer fix-up steps; 0 picks the job size by the batch); 5 = k_exec_c
-                                 (k_exec_b's method, two bytes per lane and pass, fixed-point passes) */
+                                 byte, strictly in order; 7.7 KiB of LDS per frame); 3 = BLOCK MODE (a wavefront per
+                                 block: the blocks of a frame side by side, 3 or 4 passes + an in-order fix-up walk; frames
+                                 below 2 GiB) with k_exec_b's passes, jobs of one block; 4 = block mode with k_exec_c's
+                                 passes, jobs of four consecutive blocks (fewer fix-up steps) -- what 0 picks for batches of
+                                 few large frames, with the job size chosen by the batch; 5 = k_exec_c (k_exec_b's method,
+                                 two bytes per lane and pass, fixed-point passes) */
 } mzd_options;
 
 mzd_ctx *mzd_create(int device, const mzd_options *opt, int *err);

@@ -21,7 +21,11 @@ rm -rf gpurun_out/${TAG}_blk_prof
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_blk_prof --output-format csv -- python3 bench.py --cpu-seconds 0 --no-ceiling --steps 2 --warmup 1 --frames 64 --frame-bytes 134217728 --gen-seconds 200 2>gpurun_out/${TAG}_blk64.err | tee gpurun_out/${TAG}_large_64x128MiB_bench.json | pick "64 x 128 MiB"
 find gpurun_out/${TAG}_blk_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_large_64x128MiB_kernel_stats.csv
 rm -rf gpurun_out/${TAG}_blk_prof
-timeout 900 python bench.py --cpu-seconds 0 --no-ceiling --steps 2 --warmup 1 --frames 1 --frame-bytes 1073741824 --gen-seconds 200 2>/dev/null | tee gpurun_out/${TAG}_large_1x1GiB_bench.json | pick "1 x 1 GiB"
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_blk_prof --output-format csv -- python3 bench.py --cpu-seconds 0 --no-ceiling --steps 2 --warmup 1 --frames 1 --frame-bytes 1073741824 --gen-seconds 200 2>gpurun_out/${TAG}_blk1.err | tee gpurun_out/${TAG}_large_1x1GiB_bench.json | pick "1 x 1 GiB"
+find gpurun_out/${TAG}_blk_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_large_1x1GiB_kernel_stats.csv
+rm -rf gpurun_out/${TAG}_blk_prof
+for cfg in "4 268435456" "16 134217728"; do set -- $cfg; timeout 600 python bench.py --cpu-seconds 0 --no-ceiling --steps 3 --warmup 1 --frames $1 --frame-bytes $2 --gen-seconds 200 2>/dev/null | tee gpurun_out/${TAG}_large_${1}x$(($2 >> 20))MiB_bench.json | pick "$1 x $(($2 >> 20)) MiB"; done
+timeout 900 python bench.py --cpu-seconds 0 --no-ceiling --steps 2 --warmup 1 --frames 64 --frame-bytes 134217728 --gen-seconds 200 --window-log 23 2>/dev/null | tee gpurun_out/${TAG}_large_64x128MiB_wlog23_bench.json | pick "64 x 128 MiB, offsets within 8 MiB"
 timeout 900 python bench.py --cpu-seconds 0 --no-ceiling --steps 3 --warmup 1 --frames 8192 --frame-bytes 1048576 2>/dev/null | tee gpurun_out/${TAG}_large_8192x1MiB_bench.json | pick "8192 x 1 MiB"
 timeout 600 python tools/stream_bench.py 8192 12 1,2,3 2>/dev/null | tail -3 | tee gpurun_out/${TAG}_stream.json
 timeout 600 python tools/reader_bench.py 1024 67108864 2>/dev/null | tail -6 | tee gpurun_out/${TAG}_reader.txt
