@@ -1452,8 +1452,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // workgroups as give every thread one chunk of a job: 40.2 / 32.3 / 29.3 / 31.2 ms; 2 x 512 MiB jobs of 2 / 4: 29.0 / 27.0;
             // 4 x 256 MiB 24.8 / 26.5; 8 x 256 MiB 38.2 / 34.1; profiles/r4_blk_fixup_spread.txt)
             if (const char *e = exp_env("MZD_EXP_BLK_GS")) blk_gs = (uint32_t)std::max(1, atoi(e));
-            else if (db->n_frames <= 8 && db->n_blocks >= 4096) blk_gs = db->n_frames >= 4 && db->n_frames < 8 ? 2u : 4u;
-            else if (db->n_frames <= 8 && db->n_blocks >= 2048) blk_gs = 2u;
+            // (with every pass of every job in ONE launch -- below -- longer jobs cost the passes little: one 1 GiB frame, jobs of 4 / 8 /
+            // 16 blocks: 25.2 / 19.1 / 19.6 ms; 2 x 512 MiB 4 / 8: 23.1 / 16.7; 4 x 256 MiB: 22.3 / 17.0; 8 x 256 MiB: 32.5 / 30.0; one 256 MiB
+            // frame 2 / 4 / 8: 11.5 / 8.6 / 9.0; one 64 MiB frame 1 / 2 / 4: 6.4 / 5.2 / 5.4; 16 x 128 MiB 1 / 2 / 4: 30.4 / 29.7 / 28.0;
+            // profiles/r4_blk_fused_passes.txt)
+            else if (db->n_frames <= 16) {
+                blk_gs = db->n_blocks >= 8192 ? 8u : (db->n_blocks >= 2048 ? 4u : (db->n_blocks >= 512 ? 2u : 1u));
+            } else if (db->n_frames <= 64 && db->n_blocks / 2 <= 20480u) {
+                blk_gs = 2u;  // (32 x 128 MiB, jobs of 1 / 2: 49.8 / 47.5 ms; 16 x 128 MiB 4 / 8: 27.8 / 26.5)
+            }
         }
     }
     if (blk) {
@@ -1637,9 +1644,20 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // the passes: k_exec_c's method (exec_variant 0 and 4), k_exec_b's (3: the parity tests keep both alive)
             bool blk_xc = ctx->opt.exec_variant != 3;
             if (exp_env("MZD_EXP_BLK_XB")) blk_xc = false;  // experiment: the round-3 passes
-            for (uint32_t p = 0; p < blk_np; p++) {
+            // ... all of them in ONE launch, a job's passes in neighbouring wavefronts: they are independent of each other, few large
+            // frames have fewer jobs than the chip holds wavefronts (one 1 GiB frame: 2 048 jobs of four blocks, a pass 2.4 ms each
+            // whatever runs beside it), and the passes of a job read the same records and literals
+            // (16 x 128 MiB, 16 384 jobs: 31.1 -> 30.4 ms; 64 x 128 MiB, 65 536 jobs: 83.3 -> 85.5 -- a full chip gains nothing from the
+            // passes side by side and loses by their interleaving: a launch per pass from 20 480 jobs on)
+            bool fused = blk_xc && db->n_blocks / blk_gs <= 20480u && !exp_env("MZD_EXP_BLK_SERIAL_PASSES");
+            if (fused) {
+                const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat, 0u, blk_np, pstride, stride, db->d_planes};
+                k_exec_c<true><<<db->n_blocks * blk_np, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                                                                  db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
+            }
+            for (uint32_t p = 0; p < (fused ? 0u : blk_np); p++) {
                 uint8_t *plane = p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride;
-                const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p};
+                const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p, 0u, 0ull, 0ull, nullptr};
                 // (as many wavefronts as blocks: the ones beyond the job list exit)
                 if (blk_xc)
                     k_exec_c<true><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
@@ -1663,7 +1681,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // each: 41.3 / 32.6 / 51.4; 32 x 128 MiB 8 / 16 spread / 32 on one XCD: 55.9 / 51.7 / 57.5; 64 x 128 MiB 2 / 4 / 8 spread / 16
             // on one XCD each: 141.6 / 103.3 / 89.8 / 88.9 -- every workgroup is a poller of its frame's counter).
             bool spread = db->n_frames <= 64;
-            if (spread) G = std::min<uint32_t>(32u * blk_gs, db->n_frames <= 4 ? 128u / db->n_frames : std::max<uint32_t>(256u / db->n_frames, 16u));
+            // (round 4, later, with the passes in one launch and longer jobs: 256 workgroups in all up to four frames -- one 1 GiB frame, jobs
+            // of eight, 128 / 192 / 256: 23.1 / 26.2 / 19.1 ms; 2 x 512 MiB 64 / 128 per frame: 22.4 / 16.7; 4 x 256 MiB 32 / 64: 21.6 / 17.0 --,
+            // 512 up to sixteen -- 8 x 256 MiB 32 / 64: 31.1 / 30.0; 16 x 128 MiB, jobs of four, 32: 28.0)
+            if (spread)
+                G = std::min<uint32_t>(32u * blk_gs, db->n_frames <= 4 ? 256u / db->n_frames
+                                                                          : (db->n_frames <= 16 ? 512u / db->n_frames : std::max<uint32_t>(256u / db->n_frames, 16u)));
             if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::min(256, std::max(1, atoi(e)));  // experiment
             // (G > 1: the workgroups of a frame wait for each other.  Should some of them not be resident -- another stream or
             // process on the GPU --, the waiters give up after a bounded wait and a second launch, one workgroup per such frame,

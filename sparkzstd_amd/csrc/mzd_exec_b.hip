@@ -157,8 +157,13 @@ struct XbBlk {
     const BJob *jobs;     // per block
     const uint32_t *heads;  // the jobs: [0] their number, [1 + j] the first block of job j
     BFrame *bframes;
-    const uint8_t *pat;   // indexed by the frame-relative position
-    uint32_t pass;
+    const uint8_t *pat;   // this pass's pattern, indexed by the frame-relative position (np > 0: pass 0's; the others follow at pstride)
+    uint32_t pass;        // np == 0: the launch is ONE pass, this one
+    // np > 0: the launch is ALL np passes -- workgroup b is pass b % np of job b / np (a job's passes next to each other: they read
+    // the same records and literals), pass p > 0 writes to planes + (p - 1) * plane_stride instead of the kernel's output blob
+    uint32_t np;
+    uint64_t pstride, plane_stride;
+    uint8_t *planes;
 };
 
 template <bool BM>

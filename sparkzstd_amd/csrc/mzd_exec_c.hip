@@ -179,8 +179,15 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
     uint32_t fidx, bi0 = 0;
     BJob jb{};
     if (BM) {
-        if (blockIdx.x >= bk.heads[0]) return;  // (the job list k_blk_scan made: heads[0] jobs, heads[1 + j] = job j's first block)
-        const uint32_t g = bk.heads[1 + blockIdx.x];
+        uint32_t job = blockIdx.x;
+        if (bk.np) {  // every pass in one launch
+            job = blockIdx.x / bk.np;
+            bk.pass = blockIdx.x - job * bk.np;
+            bk.pat += (size_t)bk.pass * bk.pstride;
+            if (bk.pass) out_blob = bk.planes + (size_t)(bk.pass - 1) * bk.plane_stride;
+        }
+        if (job >= bk.heads[0]) return;  // (the job list k_blk_scan made: heads[0] jobs, heads[1 + j] = job j's first block)
+        const uint32_t g = bk.heads[1 + job];
         jb = bk.jobs[g];
         fidx = jb.frame;
         bi0 = g;  // (global for now)
