@@ -498,8 +498,8 @@ def decode_frames(frames, ctx: Context = None, device_tables: bool = True, devic
     # a host blob first and a copy per frame out of it was most of the host side (one 256 MiB frame: 90.8 ms against 37.3 for
     # the blob alone).  Many frames: one download and a slice each (a copy-engine call per 128 KiB frame would cost more).
     total = sum(len(f) for f in frames)
-    if not device_plan and 0 < len(frames) <= 64 and total >= (4 << 20) * len(frames) // 4:
-        rb, lay, out_len, sts = decode_frames_resident(frames, ctx, device_tables=device_tables)
+    if 0 < len(frames) <= 64 and total >= (4 << 20) * len(frames) // 4:
+        rb, lay, out_len, sts = decode_frames_resident(frames, ctx, device_tables=device_tables, device_plan=device_plan)
         try:
             outs = []
             for i in range(len(sts)):
@@ -524,7 +524,7 @@ def decode_frames(frames, ctx: Context = None, device_tables: bool = True, devic
     return outs, sts
 
 
-def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = True):
+def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):
     """Decodes `frames` and LEAVES the output in HBM: -> (ResidentBatch, slab offset of every frame, out_len of every frame,
     statuses).  The caller reads what it wants with ResidentBatch.read_out and frees the batch -- what a reader does whose
     consumer takes the frame piece by piece (decompression.FrameReader: every Read moves its own bytes over PCIe, once)."""
@@ -538,6 +538,15 @@ def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = Tr
     off = np.zeros(n, dtype=np.uint64)
     if n > 1:
         off[1:] = np.cumsum(ln)[:-1]
+    if device_plan:
+        rb = ctx.upload_frames(blob, off, ln)
+        try:
+            rb.run()
+            _, status, out_len = rb.download(want_out=False)
+        except Exception:
+            rb.free()
+            raise
+        return rb, np.asarray(rb.frame_out_offset, dtype=np.uint64), out_len, [int(x) for x in status]
     plan = Plan(device_tables=device_tables)
     try:
         if blob.size == 0:
