@@ -12,11 +12,11 @@ from tests.conftest import check_expected
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4, 5], ids=["exec_auto", "k_exec", "k_exec_b", "k_exec_b_blocks", "k_exec_b_segments", "k_exec_c"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4, 5], ids=["exec_auto", "k_exec", "k_exec_b", "blocks_k_exec_b", "blocks_k_exec_c_jobs_of_four", "k_exec_c"])
 def ctx(request):
-    """every test that takes `ctx` runs with both execution kernels, the default choice between them, and with the blocks of
-    every frame executed side by side (k_exec_b in block mode: what a batch of few large frames takes by default), as jobs of one
-    block and as jobs of four consecutive blocks"""
+    """every test that takes `ctx` runs with the three execution kernels, the default choice between them, and with the blocks of
+    every frame executed side by side (block mode: what a batch of few large frames takes by default) -- with k_exec_b's passes as
+    jobs of one block, and with k_exec_c's passes, all in one launch, as jobs of four consecutive blocks"""
     return z.Context(0, exec_variant=request.param)
 
 
@@ -140,6 +140,27 @@ def test_block_mode_matches_that_reach_back_more_than_8_mib(exec_variant):
                 a, b = np.frombuffer(o, np.uint8), np.frombuffer(w, np.uint8)
                 bad = np.nonzero(a != b)[0]
                 raise AssertionError((i, len(bad), bad[:8].tolist()))
+    c.close()
+
+
+@pytest.mark.parametrize("count,frame_bytes,what", [
+    (1, 64 << 20, "one frame of 512 blocks: jobs of two blocks, every pass in one launch, 64 fix-up workgroups over all XCDs"),
+    (17, 4 << 20, "17 frames: jobs of two blocks, sixteen fix-up workgroups per frame over all XCDs"),
+    (70, 3 << 20, "more than 64 frames: a frame's fix-up workgroups on one XCD, a launch with eight times the workgroups"),
+    (5, 24 << 20, "five frames of 192 blocks (four planes): jobs of two, 64 fix-up workgroups per frame"),
+])
+def test_block_mode_policy_branches(count, frame_bytes, what):
+    """exec_variant 0 on batches that take block mode by themselves, one per branch of its launch policy (blocks per job, passes in
+    one launch or one per pass, fix-up workgroups per frame, on one XCD or on all): every frame against the generator's checksum."""
+    from tools import synth_binding as sb
+    blob, off, ln, ck, ns = sb.make_batch(4, 700 + count, count, frame_bytes=frame_bytes, threads=8)
+    frames = [blob[int(o):int(o + l)].tobytes() for o, l in zip(off, ln)]
+    c = z.Context(0)
+    for _ in range(2):
+        outs, sts = _decode(frames, c)
+        assert sts == [0] * count, what
+        for o, k in zip(outs, ck):
+            assert len(o) == frame_bytes and sb.checksum64(o) == int(k), what
     c.close()
 
 
