@@ -110,6 +110,7 @@ struct mzd_dbatch {
     uint32_t seq_cells[3] = {512, 512, 256};  // largest LL / ML / OF table of the batch's sequence tasks (cells)
     std::vector<uint32_t> frame_seq_task;  // host: index of the first SeqTask of every frame (+ total)
     std::vector<uint64_t> frame_out_off, frame_out_cap;  // host: output slab of every frame
+    double max_frame_serial_ms = 0;  // the longest frame as ONE wavefront's job, from its blocks' sequence counts (0: not known -- planned on the device)
     std::vector<uint64_t> frame_in_lo, frame_in_hi;      // host: extent of the frame's sequence bitstreams in the blob (lo > hi: none)
     float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
     // heterogeneous batches (real data: blocks of 10 and of 40 000 sequences side by side): work lists ordered by size, so
@@ -694,9 +695,19 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->frame_in_hi = std::move(frame_in_hi);
     db->frame_out_off.resize(b->n_frames);
     db->frame_out_cap.resize(b->n_frames);
+    db->max_frame_serial_ms = 0;
     for (uint32_t f = 0; f < b->n_frames; f++) {
         db->frame_out_off[f] = b->frames[f].out_offset;
         db->frame_out_cap[f] = b->frames[f].out_capacity;
+        // what the frame costs a wavefront that walks its blocks in order: 2 us per 64 sequences (a text-like 128 KiB block of
+        // 13.4 k sequences: 0.42 ms), 6 us per block, a Raw / RLE block at 8 KiB per us
+        const mzd_frame_desc &fd = b->frames[f];
+        double us = 0;
+        for (uint32_t k = 0; k < fd.n_blocks && fd.first_block + k < b->n_blocks; k++) {
+            const mzd_block_desc &bd = b->blocks[fd.first_block + k];
+            us += 6.0 + (bd.type == MZD_BLOCK_COMPRESSED ? (double)bd.n_seq * (2.0 / 64.0) + (double)bd.lit_regen / 8192.0 : (double)bd.size / 8192.0);
+        }
+        db->max_frame_serial_ms = std::max(db->max_frame_serial_ms, us * 1e-3);
     }
     db->out_size = b->out_size;
     db->stats = st;
@@ -932,6 +943,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     std::vector<uint32_t> frame_seq_task(n_frames + 1, 0);
     db->frame_out_off.assign(n_frames, 0);
     db->frame_out_cap.assign(n_frames, 0);
+    db->max_frame_serial_ms = 0;  // (no per-block sequence counts on the host: the bound-based estimate)
     db->frame_in_lo.assign(n_frames, ~0ull);
     db->frame_in_hi.assign(n_frames, 0);
     uint64_t n_blocks = 0, n_seq = 0, n_hufb = 0, n_fse_tab = 3, n_fse_src = 0, n_fse_dev = 0, n_huf_tab = 0, n_huf_src = 0, n_huf_dev = 0,
@@ -1437,8 +1449,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // (measured, 8 GiB of output as n frames whose blocks reach back, serial / block mode per pass: 2 048 x 4 MiB 30.2 / 82.1 ms;
         // 512 x 16 MiB 91.8 / 117.0; 256 x 32 MiB 168 / 98.6; 128 x 64 MiB 325 / 97.2 -- a frame's workgroup makes a block in
         // ~0.42 ms; the passes cost ~12 % more than the plain kernel, the fix-up walk ~5 ms per GiB + 6 us per block)
-        const double t_serial = std::max((double)blk_maxcap / kBlockMax * 0.42, chip);
+        // (the largest frame's serial walk: from its blocks' sequence counts when the host planned the batch -- a frame's output BOUND
+        // says little: the reference's corpus has frames of 70 blocks of a few KiB each, bound 9 MiB, and batches of 0.4-1.5 GiB of
+        // it took block mode, four passes, for an execution stage of 7-15 ms where the blocks in order take 6)
+        const double t_serial = std::max(db->max_frame_serial_ms > 0 ? db->max_frame_serial_ms : (double)blk_maxcap / kBlockMax * 0.42, chip);
         const double t_blk = blk_np * chip * 1.12 + (double)db->out_size / (1u << 30) * 5.0 + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
+        // (`profiles/r4_corpus_sizes.txt`: 1 GiB of the corpus 19.5 ms in block mode against 11.9 with the blocks in order)
         blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant >= 3 || t_blk < 0.85 * t_serial);
         if (blk) {
             exec_b = true;
