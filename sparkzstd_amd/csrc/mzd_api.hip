@@ -110,6 +110,9 @@ struct mzd_dbatch {
     uint32_t seq_cells[3] = {512, 512, 256};  // largest LL / ML / OF table of the batch's sequence tasks (cells)
     std::vector<uint32_t> frame_seq_task;  // host: index of the first SeqTask of every frame (+ total)
     std::vector<uint64_t> frame_out_off, frame_out_cap;  // host: output slab of every frame
+    uint32_t n_multi = 0;  // frames of more than one block: the ones block mode's fix-up walk has anything to do for
+    uint32_t *d_walk = nullptr;  // block mode: [0] their number as k_blk_scan found it, [1 ...] the frames
+    size_t cap_walk = 0;
     double max_frame_serial_ms = 0;  // the longest frame as ONE wavefront's job, from its blocks' sequence counts (0: not known -- planned on the device)
     std::vector<uint64_t> frame_in_lo, frame_in_hi;      // host: extent of the frame's sequence bitstreams in the blob (lo > hi: none)
     float parse_ms = 0;  // k_parse<0> + k_parse<1> (device-side planning only)
@@ -370,6 +373,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_heads);
     (void)hipFree(db->d_bframes);
     (void)hipFree(db->d_fixdone);
+    (void)hipFree(db->d_walk);
     (void)hipFree(db->d_planes);
     (void)hipFree(db->d_pat);
     free_parse_temps(db->tmp);
@@ -696,7 +700,9 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->frame_out_off.resize(b->n_frames);
     db->frame_out_cap.resize(b->n_frames);
     db->max_frame_serial_ms = 0;
+    db->n_multi = 0;
     for (uint32_t f = 0; f < b->n_frames; f++) {
+        db->n_multi += b->frames[f].n_blocks > 1 ? 1u : 0u;
         db->frame_out_off[f] = b->frames[f].out_offset;
         db->frame_out_cap[f] = b->frames[f].out_capacity;
         // what the frame costs a wavefront that walks its blocks in order: 2 us per 64 sequences (a text-like 128 KiB block of
@@ -944,6 +950,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     db->frame_out_off.assign(n_frames, 0);
     db->frame_out_cap.assign(n_frames, 0);
     db->max_frame_serial_ms = 0;  // (no per-block sequence counts on the host: the bound-based estimate)
+    db->n_multi = 0;
     db->frame_in_lo.assign(n_frames, ~0ull);
     db->frame_in_hi.assign(n_frames, 0);
     uint64_t n_blocks = 0, n_seq = 0, n_hufb = 0, n_fse_tab = 3, n_fse_src = 0, n_fse_dev = 0, n_huf_tab = 0, n_huf_src = 0, n_huf_dev = 0,
@@ -976,6 +983,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         fb.out_off = out_at;
         fb.out_cap = c.status == MZD_OK ? c.out_bound : 0;
         frame_seq_task[f] = (uint32_t)n_seq;
+        db->n_multi += c.n_blocks > 1 ? 1u : 0u;
         if (c.n_seq && frame_off[f] <= in_size && frame_len[f] <= in_size - frame_off[f]) {
             db->frame_in_lo[f] = frame_off[f];
             db->frame_in_hi[f] = frame_off[f] + frame_len[f];
@@ -1442,6 +1450,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // 1 GiB frame: 8 192 steps of 1.7 us were 14 of its 22.7 ms), as long as there are jobs enough to fill the chip.
     // (exec_variant 3 forces block mode with segments of one block, 4 with segments of four: the parity tests run both.)
     uint32_t blk_gs = 1;
+    // (the frames that count for the walk's policy are the ones of more than one block: 2 000 frames of 128 KiB and two of 64 MiB
+    // are a batch of TWO frames for it -- it used to get one fix-up workgroup per frame: 78.6 ms, `profiles/r4_mixed_batches.txt`)
+    const uint32_t n_walk = std::max(db->n_multi, 1u);
     if (db->n_seq_tasks > 0 && db->n_frames > 0 && (ctx->opt.exec_variant == 0 || ctx->opt.exec_variant == 3 || ctx->opt.exec_variant == 4)) {
         for (uint32_t f = 0; f < db->n_frames; f++) blk_maxcap = std::max<uint64_t>(blk_maxcap, db->frame_out_cap[f]);
         blk_np = blk_maxcap <= (1u << 23) ? 3u : 4u;
@@ -1472,9 +1483,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // 16 blocks: 25.2 / 19.1 / 19.6 ms; 2 x 512 MiB 4 / 8: 23.1 / 16.7; 4 x 256 MiB: 22.3 / 17.0; 8 x 256 MiB: 32.5 / 30.0; one 256 MiB
             // frame 2 / 4 / 8: 11.5 / 8.6 / 9.0; one 64 MiB frame 1 / 2 / 4: 6.4 / 5.2 / 5.4; 16 x 128 MiB 1 / 2 / 4: 30.4 / 29.7 / 28.0;
             // profiles/r4_blk_fused_passes.txt)
-            else if (db->n_frames <= 16) {
+            else if (n_walk <= 16) {
                 blk_gs = db->n_blocks >= 8192 ? 8u : (db->n_blocks >= 2048 ? 4u : (db->n_blocks >= 512 ? 2u : 1u));
-            } else if (db->n_frames <= 64 && db->n_blocks / 2 <= 20480u) {
+            } else if (n_walk <= 64 && db->n_blocks / 2 <= 20480u) {
                 blk_gs = 2u;  // (32 x 128 MiB, jobs of 1 / 2: 49.8 / 47.5 ms; 16 x 128 MiB 4 / 8: 27.8 / 26.5)
             }
         }
@@ -1496,7 +1507,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
                          ensure(db->d_heads, db->cap_heads, ((size_t)db->n_blocks + 2) * 4) == hipSuccess &&
                          ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
-                         ensure(db->d_fixdone, db->cap_fixdone, (size_t)std::min<uint32_t>(db->n_frames, 1024u) * kFixMaxG * sizeof(uint32_t)) == hipSuccess &&
+                         ensure(db->d_fixdone, db->cap_fixdone, (size_t)std::min<uint32_t>(n_walk, 1024u) * kFixMaxG * sizeof(uint32_t)) == hipSuccess &&
+                         ensure(db->d_walk, db->cap_walk, ((size_t)db->n_frames + 1) * 4) == hipSuccess &&
                          ensure(db->d_planes, db->cap_planes, (size_t)(blk_np - 1) * stride + 256) == hipSuccess &&
                          ensure(db->d_pat, db->cap_pat, (size_t)blk_np * pstride) == hipSuccess;
         if (db->cap_pat != pat_before) db->pat_n = db->pat_np = 0;
@@ -1651,7 +1663,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // (the whole batch: block mode never splits)
             const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
             (void)hipMemsetAsync(db->d_heads, 0, 4, st);
-            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads);
+            (void)hipMemsetAsync(db->d_walk, 0, 4, st);
+            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads, db->d_walk);
             if (db->pat_n != (uint32_t)(blk_maxcap + 64) || db->pat_np != blk_np) {
                 k_blk_pattern<<<(uint32_t)((blk_maxcap + 64 + 1023) / 1024), 256, 0, st>>>(db->d_pat, pstride, (uint32_t)(blk_maxcap + 64), blk_np);
                 db->pat_n = (uint32_t)(blk_maxcap + 64);
@@ -1686,7 +1699,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // (frames whose blocks reach back -- 64 x 128 MiB, 8 / 16 / 32 per frame: 113.8 / 103.7 / 114.8 ms per pass; one frame of
             // 1 GiB, 32 / 64 with jobs of two blocks: 49.4 / 44.4 ms, 32 / 64 / 128 with jobs of one: 56.0 / 67.4 / 92.2 ms -- every
             // workgroup is a poller of its frame's counter)
-            uint32_t G = db->n_frames >= 1024 ? 1u : std::min<uint32_t>(64u, 1024u / db->n_frames);
+            uint32_t G = n_walk >= 1024 ? 1u : std::min<uint32_t>(64u, 1024u / n_walk);
             // Few frames (up to eight): a frame's workgroups on ALL XCDs instead of on one -- one XCD walking a 1 GiB frame moves its
             // 5 GiB through one L2 (54.8 ms per pass, whatever the number of steps); 128 workgroups over the chip, jobs of four blocks:
             // 29.3 ms.  As many workgroups as give every thread ONE 16-byte chunk of a job (32 per block of the job: a thread's second
@@ -1696,35 +1709,34 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // 27.0 / 28.9 ms; 4 x 256 MiB 32 / 64: 24.8 / 32.8; 8 x 256 MiB 16 / 32: 43.1 / 35.0; 16 x 128 MiB 8 / 16 spread / 64 on one XCD
             // each: 41.3 / 32.6 / 51.4; 32 x 128 MiB 8 / 16 spread / 32 on one XCD: 55.9 / 51.7 / 57.5; 64 x 128 MiB 2 / 4 / 8 spread / 16
             // on one XCD each: 141.6 / 103.3 / 89.8 / 88.9 -- every workgroup is a poller of its frame's counter).
-            bool spread = db->n_frames <= 64;
+            bool spread = n_walk <= 64;
             // (round 4, later, with the passes in one launch and longer jobs: 256 workgroups in all up to four frames -- one 1 GiB frame, jobs
             // of eight, 128 / 192 / 256: 23.1 / 26.2 / 19.1 ms; 2 x 512 MiB 64 / 128 per frame: 22.4 / 16.7; 4 x 256 MiB 32 / 64: 21.6 / 17.0 --,
             // 512 up to sixteen -- 8 x 256 MiB 32 / 64: 31.1 / 30.0; 16 x 128 MiB, jobs of four, 32: 28.0)
             if (spread)
-                G = std::min<uint32_t>(32u * blk_gs, db->n_frames <= 4 ? 256u / db->n_frames
-                                                                          : (db->n_frames <= 16 ? 512u / db->n_frames : std::max<uint32_t>(256u / db->n_frames, 16u)));
+                G = std::min<uint32_t>(32u * blk_gs, n_walk <= 4 ? 256u / n_walk : (n_walk <= 16 ? 512u / n_walk : std::max<uint32_t>(256u / n_walk, 16u)));
             if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::min(256, std::max(1, atoi(e)));  // experiment
             // (G > 1: the workgroups of a frame wait for each other.  Should some of them not be resident -- another stream or
             // process on the GPU --, the waiters give up after a bounded wait and a second launch, one workgroup per such frame,
             // finishes the frame's walk from what `d_fixdone` says each workgroup got done: slower, never wrong, never a hang)
             if (const char *e = exp_env("MZD_EXP_BLK_SPREAD")) spread = atoi(e) != 0;
             spread = spread && G > 1;
-            const uint32_t spread_arg = spread ? 1u : 0u, fix_wgs = db->n_frames * G * (G > 1 && !spread ? 8u : 1u);
-            if (G > 1) (void)hipMemsetAsync(db->d_fixdone, 0, (size_t)db->n_frames * kFixMaxG * sizeof(uint32_t), st);
+            const uint32_t spread_arg = spread ? 1u : 0u, fix_wgs = n_walk * G * (G > 1 && !spread ? 8u : 1u);
+            if (G > 1) (void)hipMemsetAsync(db->d_fixdone, 0, (size_t)n_walk * kFixMaxG * sizeof(uint32_t), st);
             const uint32_t tb = ctx->test_fixup_bail;
             if (blk_np == 3) {
                 k_blk_fixup<3, false><<<fix_wgs, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames,
-                                                                      db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, tb);
+                                                                      db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, tb, db->d_walk);
                 if (G > 1)
-                    k_blk_fixup<3, true><<<db->n_frames, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
-                                                                       db->d_bframes, G, spread_arg, db->d_fixdone, 0u);
+                    k_blk_fixup<3, true><<<n_walk, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
+                                                                       db->d_bframes, G, spread_arg, db->d_fixdone, 0u, db->d_walk);
             } else {
                 k_blk_fixup<4, false><<<fix_wgs, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride,
                                                                       db->d_planes + 2 * stride, db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg,
-                                                                      db->d_fixdone, tb);
+                                                                      db->d_fixdone, tb, db->d_walk);
                 if (G > 1)
-                    k_blk_fixup<4, true><<<db->n_frames, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
-                                                                       db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, 0u);
+                    k_blk_fixup<4, true><<<n_walk, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
+                                                                       db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, 0u, db->d_walk);
             }
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;

@@ -27,7 +27,7 @@ namespace mzd {
 // ---- scan: a wavefront per frame, 64 blocks per round (their summaries loaded side by side, then walked in order)
 __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                  const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes,
-                                                 uint32_t gs, uint32_t *__restrict__ heads)
+                                                 uint32_t gs, uint32_t *__restrict__ heads, uint32_t *__restrict__ walk)
 {
     // heads: [0] a counter (zero at launch), [1 ...] the blocks where a job starts, in no particular order
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
@@ -167,6 +167,8 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
     // up to 8 MiB the low 23 bits of the position say which one it is and the pass that spells the bits above is not run
     reach = wave_max_u32(reach);
     if (lane == 0) {
+        // the frames the fix-up walk has anything to do for (a frame of one block is final after pass 0): walk[0] counts them
+        if (fr.n_blocks > 1) walk[1 + atomicAdd(&walk[0], 1u)] = f;
         BFrame bf;
         bf.status = error;
         bf.out_len = (uint32_t)outPos;
@@ -372,7 +374,7 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
 template <int NP, bool RESCUE>
 __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
                                                    const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G,
-                                                   uint32_t spread, uint32_t *done, uint32_t test_bail_step)
+                                                   uint32_t spread, uint32_t *done, uint32_t test_bail_step, const uint32_t *__restrict__ walk)
 {
     // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised).  Many frames (`spread` = 0): with
     // several workgroups per frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a
@@ -381,9 +383,13 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
     uint32_t w = blockIdx.x;
     if (!RESCUE && G > 1 && !spread) {
         w = blockIdx.x >> 3;
-        if ((blockIdx.x & 7) != ((w / G) & 7)) return;
+        if ((blockIdx.x & 7) != ((w / G) & 7)) return;  // (w / G: the frame's slot in the walk list)
     }
-    const uint32_t f = RESCUE ? w : w / G, g0 = RESCUE ? 0u : w % G, tid = threadIdx.x;
+    // (the launch is for the frames of more than one block, listed by k_blk_scan: in a batch of 2 000 single-block frames and two
+    // large ones, two frames are walked, each by as many workgroups as a batch of two would give it)
+    const uint32_t slot = RESCUE ? w : w / G, g0 = RESCUE ? 0u : w % G, tid = threadIdx.x;
+    if (slot >= walk[0]) return;
+    const uint32_t f = walk[1 + slot];
     const DFrame fr = frames[f];
     BFrame *bf = &bframes[f];
     if (RESCUE && !bf->bail) return;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint
     const uint8_t *pH = NP == 4 ? pl3 + fr.out_offset : nullptr;  // the plane of the high position bits, written for frames with `high`
     const bool high = NP == 4 && bf->high != 0;
     const uint32_t cstep = G * 256;
-    uint32_t *fdone = done + (size_t)f * kFixMaxG;
+    uint32_t *fdone = done + (size_t)slot * kFixMaxG;
     __shared__ uint32_t go;
     // the frame's jobs after its first (which derives nothing: its blocks follow each other inside one job), in order.
     // (Loading the NEXT job's extent and plane bytes while this job's step runs -- a software pipeline over the jobs -- made the

@@ -164,6 +164,24 @@ def test_block_mode_policy_branches(count, frame_bytes, what):
     c.close()
 
 
+def test_block_mode_mixed_batch_walks_only_the_multi_block_frames():
+    """A batch of many single-block frames and a few large ones: the fix-up walk is launched for the frames of more than one block
+    (k_blk_scan lists them) with the workgroup count a batch of THOSE frames would get -- 1 200 frames of 128 KiB and two of 24 MiB
+    are a batch of two frames for it, not of 1 202 (one workgroup per frame: ten times slower) -- in any order of the frames."""
+    from tools import synth_binding as sb
+    blob, off, ln, ck, ns = sb.make_batch(4, 31, 1200, frame_bytes=131072, threads=8)
+    small = [(blob[int(o):int(o + l)].tobytes(), 131072, int(k)) for o, l, k in zip(off, ln, ck)]
+    blob2, off2, ln2, ck2, ns2 = sb.make_batch(4, 77, 2, frame_bytes=24 << 20, threads=2)
+    large = [(blob2[int(o):int(o + l)].tobytes(), 24 << 20, int(k)) for o, l, k in zip(off2, ln2, ck2)]
+    c = z.Context(0)
+    for order in (small[:600] + large[:1] + small[600:] + large[1:], large + small, small + large):
+        outs, sts = _decode([f for f, _, _ in order], c)
+        assert sts == [0] * len(order)
+        for o, (_, n, k) in zip(outs, order):
+            assert len(o) == n and sb.checksum64(o) == k
+    c.close()
+
+
 def test_block_mode_many_frames_one_fixup_workgroup_each():
     """1 100 two-block frames with blocks side by side: with that many frames the fix-up walk runs ONE workgroup per frame
     (no waiting between workgroups); fewer frames take several per frame (the tests above)."""
