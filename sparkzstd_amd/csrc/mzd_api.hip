@@ -1523,7 +1523,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // Heterogeneous batches: the Huffman kernel runs on the second stream BESIDE the sequence stage -- that stage is bound by
     // its longest chain there (real data: 42 k sequences = 5.9 ms of a 7.5 ms kernel with most CUs idle), the Huffman
     // classes with large tables (up to 64 KiB of LDS per wavefront) fill the CUs it leaves.
-    const bool huf_het_beside = serial && !blk && ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_HET_HUF_FIRST");
+    // (block mode too, round 4: the frames' literals are not needed before the passes -- one 64 MiB frame 5.18 -> 4.77 ms, 100 frames of
+    // the reference's corpus, which take block mode, 12.5 -> 10.2 ms, 64 x 128 MiB 83.3 -> 82.9; profiles/r4_huf_beside_block_mode.txt)
+    const bool huf_het_beside = serial && ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_HET_HUF_FIRST");
     const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
                             db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) &&
