@@ -1805,8 +1805,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // segments in parallel (k_huf_seg) is the one that fills the chip.
         const uint32_t hv = ctx->opt.huf_variant;
         const uint64_t streams = std::max<uint64_t>(db->stats.n_huf_streams, 1);
-        const bool seg = hv == 2 || (hv == 0 && streams < 64ull * 8 * (uint64_t)std::max(ctx->num_cus, 1) &&
-                                     db->huf_out_bytes / streams >= 2048);
+        // (... or many long streams under LARGE tables: a lane-per-stream wavefront keeps 16 tables in LDS, with tables of 2 048 cells
+        // that is 64 KiB per wavefront and ~24 k streams in flight on the chip however many there are -- 392 GB/s whatever the streams'
+        // length, against k_huf_seg's 1.2 TB/s: BASELINE config 3 at 65 536 frames 23.5 -> 7.3 ms, `profiles/r4_huf_crossover.txt`; with
+        // tables of up to 32 cells -- config 4 -- the lane-per-stream kernel keeps its transposed bulk phase and many wavefronts per CU;
+        // and with sequences to decode the Huffman kernel runs beside that stage, where k_huf_seg costs it more than it saves:
+        // 8 192 x 1 MiB 26.3 -> 27.5 ms)
+        const bool seg = hv == 2 || (hv == 0 && db->huf_out_bytes / streams >= 2048 &&
+                                     (streams < 64ull * 8 * (uint64_t)std::max(ctx->num_cus, 1) || (db->huf_slot_cells > 32 && db->n_seq_tasks == 0)));
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
