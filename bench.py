@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--issue-from", default="", help="JSON written by tools/profile_counters.sh (SQ counters per kernel); default: "
                     "profiles/r4_issue_<workload>.json; quoted under the same condition")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured copy ceiling (mzd_measure_copy)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (the other BASELINE configs, real data, the "
+                    "8192-frame shard and one large frame, measured in the same process after the headline; only the default headline "
+                    "invocation on one GPU carries it)")
     return ap.parse_args()
 
 
@@ -250,6 +253,149 @@ def libzstd_line(blob, off, ln, exp_len, n1, cores):
             "note": "context only: third-party libzstd via dlopen, not the reference"}
 
 
+def load_corpus(gib, world=1):
+    """The reference's own golden frames (tests/golden/decodecorpus, committed with their sha256 / length manifest): one REPLICA =
+    the 100 frames in order; a batch is as many replicas as give `gib` GiB of output."""
+    gdir = os.path.join(ROOT, "tests", "golden", "decodecorpus")
+    manifest = json.load(open(os.path.join(gdir, "manifest.json")))
+    names = sorted(manifest)
+    cframes = [np.frombuffer(open(os.path.join(gdir, n + ".zst"), "rb").read(), dtype=np.uint8) for n in names]
+    clens = np.array([manifest[n]["length"] for n in names], dtype=np.uint64)
+    reps_total = max(world, int(gib * 2**30 / float(clens.sum()) + 0.5))
+    return {"names": names, "sha": [manifest[n]["sha256"] for n in names], "lens": clens, "frames": cframes, "reps": reps_total}
+
+
+def corpus_batch(corpus, reps):
+    """`reps` replicas of the corpus as one host blob -> (blob, off, ln, exp_len)"""
+    one = np.concatenate(corpus["frames"])
+    o1 = np.concatenate([[0], np.cumsum([f.size for f in corpus["frames"]])[:-1]]).astype(np.uint64)
+    l1 = np.array([f.size for f in corpus["frames"]], dtype=np.uint64)
+    blob = np.tile(one, reps)
+    off = np.concatenate([o1 + np.uint64(r * one.size) for r in range(reps)])
+    return blob, off, np.tile(l1, reps), np.tile(corpus["lens"], reps)
+
+
+def verify_corpus(torch, d_out, rb, corpus, exp_len, n_frames):
+    """sha256 against the manifest: the whole first replica and one frame of every other replica (a different one each time),
+    read back from their slabs in HBM -> (ok, frames checked)"""
+    lay = rb.frame_layout()[0]
+    nf = len(corpus["names"])
+    sample = list(range(nf)) + [r * nf + (r * 37) % nf for r in range(1, n_frames // nf)]
+    ok = True
+    for i in sample:
+        o, n = int(lay[i]), int(exp_len[i])
+        got = d_out[o:o + n].cpu().numpy().tobytes()
+        ok = ok and hashlib.sha256(got).hexdigest() == corpus["sha"][i % nf]
+    return ok, len(sample)
+
+
+def verify_synth(torch, d_out, per, frame_bytes, cks):
+    """every frame of a synthetic batch against the checksum the generator took from its ORIGINAL content (a weighted sum of its
+    64-bit words), computed on the device from the slabs (frames of one size lie back to back)"""
+    exp = torch.from_numpy(cks.view(np.int64)).cuda()
+    words = frame_bytes // 8
+    wts = (2 * torch.arange(words, dtype=torch.int64, device="cuda") + 1)
+    o64 = d_out[:per * frame_bytes].view(torch.int64).view(per, words)
+    chunk = max(1, min(4096, (1 << 28) // words))
+    ok = True
+    for c in range(0, per, chunk):
+        got = (o64[c:c + chunk] * wts).sum(dim=1)
+        ok = ok and bool((got == exp[c:c + chunk]).all())
+    return ok
+
+
+def secondary_workloads(z, sb, torch, device, headline):
+    """What the driver's ONE default run also measures, after the headline and outside its timed region: the other BASELINE
+    configs at their stated sizes, real data, the shard one of eight GPUs gets, one large frame.  Same process, same library,
+    the library's own kernel choices (default options), each bit-exact on a pass into a POISONED output blob, each with the
+    copy ceiling measured for its own C and D bytes.  -> {name: {...}}"""
+    out = {}
+    threads = max(1, usable_cores()[0])
+
+    def measure(name, blob, off, ln, exp_len, check, steps=10, warmup=2, note=None):
+        t_all = time.perf_counter()
+        ctx = z.Context(device)
+        rb = None
+        try:
+            plan = z.Plan(device_tables=True)
+            assert plan.add_frames(blob, off, ln, threads=threads) == 0
+            batch = plan.finalize()
+            pad = 64
+            d_in = torch.zeros(blob.size + 2 * pad, dtype=torch.uint8, device="cuda")
+            d_in[pad:pad + blob.size].copy_(torch.from_numpy(blob))
+            d_out = torch.zeros(batch.out_size, dtype=torch.uint8, device="cuda")
+            rb = ctx.upload(batch, device_in_ptr=d_in.data_ptr() + pad, device_out_ptr=d_out.data_ptr())
+            stats = rb.stats()
+            stream = torch.cuda.current_stream().cuda_stream
+            for _ in range(warmup):
+                rb.run(stream)
+            torch.cuda.synchronize()
+            ctx.timing_reset(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                rb.run(stream)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            kms = ctx.kernel_ms()
+            ctx.timing_reset(False)
+            d_out.fill_(0xA5)  # the pass that is verified writes into poison
+            torch.cuda.synchronize()
+            rb.run(stream)
+            torch.cuda.synchronize()
+            _, status, out_len = rb.download(want_out=False)
+            ok = bool((status == 0).all() and (out_len == exp_len).all())
+            ok = ok and bool(check(d_out, rb))
+            c_bytes, d_bytes = int(stats.compressed_bytes), int(exp_len.sum())
+            path_ms = kms.pop("path", None) or sum(v for v in kms.values() if v > 0)
+            achieved = (c_bytes + d_bytes) / (path_ms * 1e-3) / 1e9 if path_ms > 0 else None
+            ceil = None
+            try:
+                cms = ctx.measure_copy(c_bytes, d_bytes, 10)
+                ceil = round((c_bytes + d_bytes) / (cms * 1e-3) / 1e9, 1)
+            except Exception:  # noqa: BLE001
+                pass
+            out[name] = {"ms_per_step": round(ms, 4), "path_ms": round(path_ms, 4), "steps": steps, "frames": int(len(off)),
+                         "decompressed_bytes": d_bytes, "compressed_bytes": c_bytes,
+                         "decompressed_MBs": round(d_bytes / (ms * 1e-3) / 1e6, 1),
+                         "achieved_GBs": round(achieved, 1) if achieved else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "copy_ceiling_GBs": ceil, "frac_of_copy_ceiling": round(achieved / ceil, 4) if achieved and ceil else None,
+                         "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
+                         "bit_exact": ok, "poisoned_output": True, "wall_s": round(time.perf_counter() - t_all, 2)}
+            if note:
+                out[name]["note"] = note
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if rb is not None:
+                rb.free()
+            ctx.close()
+
+    def synth(name, config, frames, frame_bytes=131072, **kw):
+        t0 = time.perf_counter()
+        blob, off, ln, cks, _ = sb.make_batch(config, 0, frames, frame_bytes, threads=threads)
+        gen = time.perf_counter() - t0
+        measure(name, blob, off, ln, np.full(frames, frame_bytes, dtype=np.uint64),
+                lambda d_out, rb: verify_synth(torch, d_out, frames, frame_bytes, cks), **kw)
+        out[name]["generate_s"] = round(gen, 2)
+
+    synth("config2_4096_raw_rle_frames", 2, 4096, steps=20)
+    synth("config3_4096_huffman_only_frames", 3, 4096, steps=20)
+    synth("config3_65536_huffman_only_frames", 3, 65536, steps=5)
+    # the 8192-frame shard of configs[4]: what ONE of eight GPUs runs when the headline batch is split (its first 8192 frames)
+    blob, off, ln, cks = headline
+    n = min(8192, len(off))
+    end = int(off[n - 1] + ln[n - 1])
+    measure("config4_shard_8192_frames_of_8_gpus", np.ascontiguousarray(blob[:end]), off[:n], ln[:n], np.full(n, 131072, dtype=np.uint64),
+            lambda d_out, rb: verify_synth(torch, d_out, n, 131072, cks[:n]), steps=20)
+    corpus = load_corpus(1.0)
+    cb, co, cl, ce = corpus_batch(corpus, corpus["reps"])
+    measure("decodecorpus_1GiB_real_data", cb, co, cl, ce, lambda d_out, rb: verify_corpus(torch, d_out, rb, corpus, ce, len(co))[0], steps=5,
+            note=f"the reference's {len(corpus['names'])} golden frames x {corpus['reps']} replicas; sha256 of the first replica and one frame of every other")
+    synth("one_frame_256MiB_block_mode", 4, 1, 268435456, steps=3, warmup=1)
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -283,15 +429,7 @@ def main():
     assert frame_bytes % 256 == 0 and frame_bytes > 0
     corpus = None
     if a.workload == "corpus":
-        # the reference's own golden frames (tests/golden/decodecorpus, committed with their sha256 / length manifest):
-        # one REPLICA = the 100 frames in order; the batch is as many replicas as give --corpus-gib of output
-        gdir = os.path.join(ROOT, "tests", "golden", "decodecorpus")
-        manifest = json.load(open(os.path.join(gdir, "manifest.json")))
-        names = sorted(manifest)
-        cframes = [np.frombuffer(open(os.path.join(gdir, n + ".zst"), "rb").read(), dtype=np.uint8) for n in names]
-        clens = np.array([manifest[n]["length"] for n in names], dtype=np.uint64)
-        reps_total = max(world, int(a.corpus_gib * 2**30 / float(clens.sum()) + 0.5))
-        corpus = {"names": names, "sha": [manifest[n]["sha256"] for n in names], "lens": clens, "frames": cframes, "reps": reps_total}
+        corpus = load_corpus(a.corpus_gib, world)
         assert not a.frames_per_gpu, "--workload corpus sizes the batch with --corpus-gib"
     base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
     if corpus:
@@ -310,14 +448,8 @@ def main():
     t0 = time.perf_counter()
     gen_threads = a.gen_threads or max(1, usable_cores()[0] // max(1, world))
     if corpus:
-        one = np.concatenate(corpus["frames"])
-        o1 = np.concatenate([[0], np.cumsum([f.size for f in corpus["frames"]])[:-1]]).astype(np.uint64)
-        l1 = np.array([f.size for f in corpus["frames"]], dtype=np.uint64)
         reps = per
-        blob = np.tile(one, reps)
-        off = np.concatenate([o1 + np.uint64(r * one.size) for r in range(reps)])
-        ln = np.tile(l1, reps)
-        exp_len = np.tile(corpus["lens"], reps)
+        blob, off, ln, exp_len = corpus_batch(corpus, reps)
         cks, nseq, distinct = None, np.zeros(1), len(corpus["names"])
         per = reps * len(corpus["names"])  # frames of this rank from here on
     # calibrate, then generate as many DISTINCT frames as the time budget allows (normally all of them)
@@ -417,25 +549,11 @@ def main():
         _, status, out_len = rb.download(want_out=False)
         ok = bool((status == 0).all() and (out_len == exp_len).all())
     if not a.no_verify and corpus:
-        # every frame by status and length (above); by sha256 against the manifest: the whole first replica and one frame
-        # of every other replica (a different one each time), read back from their slabs in HBM
-        lay = rb.frame_layout()[0]
-        nf = len(corpus["names"])
-        sample = list(range(nf)) + [r * nf + (r * 37) % nf for r in range(1, per // nf)]
-        for i in sample:
-            o, n = int(lay[i]), int(exp_len[i])
-            got = d_out[o:o + n].cpu().numpy().tobytes()
-            ok = ok and hashlib.sha256(got).hexdigest() == corpus["sha"][i % nf]
-        corpus["sha_checked"] = len(sample)
+        # every frame by status and length (above); by sha256 against the manifest: a sample (verify_corpus)
+        okc, corpus["sha_checked"] = verify_corpus(torch, d_out, rb, corpus, exp_len, per)
+        ok = ok and okc
     if not a.no_verify and not corpus:
-        exp = torch.from_numpy(cks.view(np.int64)).cuda()
-        words = frame_bytes // 8
-        wts = (2 * torch.arange(words, dtype=torch.int64, device="cuda") + 1)
-        o64 = d_out[:per * frame_bytes].view(torch.int64).view(per, words)
-        chunk = 4096
-        for c in range(0, per, chunk):
-            got = (o64[c:c + chunk] * wts).sum(dim=1)
-            ok = ok and bool((got == exp[c:c + chunk]).all())
+        ok = ok and verify_synth(torch, d_out, per, frame_bytes, cks)
     if world > 1:
         t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -569,6 +687,16 @@ def main():
                         "huf_tables_built_on_device": int(stats.n_huf_built),
                         "k_fse_build_ms": round(float(stats.fse_build_ms), 3)},
         }
+        # (the plain default invocation only: the experiment and profiling scripts pass --cpu-seconds 0 --no-ceiling and get the
+        # headline alone, so a rocprofv3 run of theirs sees the headline's kernels and nothing else)
+        headline_default = (world == 1 and not corpus and a.config == 4 and not a.frames_per_gpu and frame_bytes == 131072 and
+                            not a.window_log and not a.verify_checksum and distinct == per and a.cpu_seconds > 0 and not a.no_ceiling and
+                            not a.exec_variant and not a.seq_variant and not a.huf_variant and not a.no_split)
+        if headline_default and not a.no_secondary:
+            rb.free()  # (the headline's scratch goes first: the secondary batches bring their own)
+            t0 = time.perf_counter()
+            line["secondary"] = secondary_workloads(z, sb, torch, local_rank, (blob, off, ln, cks))
+            line["secondary"]["wall_s_total"] = round(time.perf_counter() - t0, 1)
         print(json.dumps(line), flush=True)
     rb.free()
     ctx.close()

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 6
+#define MZD_ABI_VERSION 7
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -391,6 +391,17 @@ int mzd_debug_backbits(mzd_ctx *ctx, const uint8_t *stream, uint32_t len, const 
  * step of the walk, as it would if its siblings were not resident; the rescue launch then has to finish the frame.  0 (the
  * default) = off.  For the parity tests only: a decoded frame never depends on it. */
 int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step);
+
+/* Which kernels the batch's LAST mzd_batch_run took (the library chooses by the batch's shape; the parity tests assert that the
+ * path they mean to cover is the one that ran).  ABI 7. */
+enum {
+    MZD_PASS_REC4 = 1,       /* four-byte sequence records between k_seq_q4 and k_exec_c (no frame above 128 KiB) */
+    MZD_PASS_BLOCK_MODE = 2, /* the blocks of a frame side by side (mzd_exec_blk.hip) */
+    MZD_PASS_EXEC_C = 4,     /* k_exec_c executed the sequences */
+    MZD_PASS_EXEC_B = 8,     /* k_exec_b */
+    MZD_PASS_SPLIT = 16      /* the last round of the sequence stage ran beside the execution of the frames before it */
+};
+uint32_t mzd_batch_last_pass(const mzd_dbatch *db);
 
 /* ------------------------------------------------------------------ host planner
  * C++ restatement of the reference's host side, exposed in C so that tests, the

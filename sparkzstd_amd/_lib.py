@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 6
+MZD_ABI_VERSION = 7
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -25,7 +25,9 @@ EXPORTS = [
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
     "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
+    "mzd_batch_last_pass",
 ]
+MZD_PASS_REC4, MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT = 1, 2, 4, 8, 16
 
 MZD_DEBUG_LITERALS, MZD_DEBUG_RECORDS, MZD_DEBUG_TILES, MZD_DEBUG_BLOCKS = 0, 1, 2, 3
 
@@ -166,6 +168,7 @@ def load():
         "mzd_batch_debug_read": (i32, [vp, vp, i32, u64, vp, u64]),
         "mzd_debug_backbits": (i32, [vp, vp, u32, vp, u32, vp, vp]),
         "mzd_debug_force_fixup_bail": (i32, [vp, u32]),
+        "mzd_batch_last_pass": (u32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -1,6 +1,8 @@
 """Batch-level host API over the C-ABI: Plan (host planner), Context (one per GPU),
 ResidentBatch (a batch in HBM), decode_frames()."""
 import ctypes
+import functools
+import threading
 
 import numpy as np
 
@@ -15,6 +17,18 @@ _PyBytes_New.argtypes = [ctypes.c_char_p, ctypes.c_ssize_t]
 _PyBytes_AsString = ctypes.pythonapi.PyBytes_AsString
 _PyBytes_AsString.restype = ctypes.c_void_p
 _PyBytes_AsString.argtypes = [ctypes.py_object]
+
+
+def _ctx_locked(fn):
+    """A method of Context / ResidentBatch / Stream that enters the library with the context: one thread at a time per
+    mzd_ctx (its events, its second stream and its run counter are not thread-safe; ctypes drops the GIL around the call).
+    The Go shim holds x.mu around the same calls (shim/go/gpu/mzd.go)."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        ctx = self if isinstance(self, Context) else self.ctx
+        with ctx._mu:
+            return fn(self, *a, **kw)
+    return wrapper
 
 
 class MzdError(RuntimeError):
@@ -93,6 +107,7 @@ class ResidentBatch:
             self.frame_out_offset = self.frame_layout()[0]
         self._batch = batch
 
+    @_ctx_locked
     def frame_layout(self):
         """-> (out_offset uint64[n], out_capacity uint64[n]) of every frame's slab in the output blob"""
         off = np.zeros(self.n_frames, dtype=np.uint64)
@@ -103,11 +118,13 @@ class ResidentBatch:
             raise MzdError(rc, "mzd_batch_frame_layout")
         return off, cap
 
+    @_ctx_locked
     def run(self, stream=None):
         rc = self.ctx._L.mzd_batch_run(self.ctx._c, self._h, stream)
         if rc:
             raise MzdError(rc, "mzd_batch_run: " + self.ctx.last_error())
 
+    @_ctx_locked
     def download(self, want_out=True):
         """-> (out blob as np.uint8 array or None, status int32[n], out_len uint64[n])"""
         out = np.empty(self.out_size, dtype=np.uint8) if want_out else None
@@ -120,12 +137,14 @@ class ResidentBatch:
             raise MzdError(rc, "mzd_batch_download: " + self.ctx.last_error())
         return out, status, out_len
 
+    @_ctx_locked
     def read_out(self, offset: int, dst_addr: int, nbytes: int):
         """bytes [offset, offset + nbytes) of the output blob straight to host address `dst_addr` (mzd_batch_read_out)"""
         rc = self.ctx._L.mzd_batch_read_out(self.ctx._c, self._h, int(offset), dst_addr, int(nbytes))
         if rc:
             raise MzdError(rc, "mzd_batch_read_out: " + self.ctx.last_error())
 
+    @_ctx_locked
     def read_fse_table(self, table: int) -> np.ndarray:
         """Device decoding table `table` as uint32 cells (baseline | nbits << 16 | symbol << 24)."""
         out = np.empty(512, dtype=np.uint32)
@@ -134,6 +153,7 @@ class ResidentBatch:
             raise MzdError(-n, "mzd_batch_read_fse_table: " + self.ctx.last_error())
         return out[:n].copy()
 
+    @_ctx_locked
     def read_huf_table(self, table: int) -> np.ndarray:
         """Device Huffman decode table `table` as uint16 cells (symbol | nbits << 8)."""
         out = np.empty(2048, dtype=np.uint16)
@@ -142,6 +162,7 @@ class ResidentBatch:
             raise MzdError(-n, "mzd_batch_read_huf_table: " + self.ctx.last_error())
         return out[:n].copy()
 
+    @_ctx_locked
     def debug_read(self, what: int, dtype, offset_bytes: int, count: int) -> np.ndarray:
         """Scratch of the batch after run() (mzd_batch_debug_read): what = _lib.MZD_DEBUG_*; `count` items of
         `dtype` from byte offset `offset_bytes` (the library checks the range against the array's extent)."""
@@ -152,6 +173,7 @@ class ResidentBatch:
             raise MzdError(rc, "mzd_batch_debug_read: " + self.ctx.last_error())
         return out
 
+    @_ctx_locked
     def debug_blocks(self, n_blocks: int):
         """The device view of every block (mzd_debug_block): where its literals / records / tiles are."""
         arr = (_lib.DebugBlock * n_blocks)()
@@ -160,6 +182,10 @@ class ResidentBatch:
         if rc:
             raise MzdError(rc, "mzd_batch_debug_read: " + self.ctx.last_error())
         return arr
+
+    def last_pass(self) -> int:
+        """MZD_PASS_* flags of the kernels the last run() took (_lib.MZD_PASS_REC4 ...)"""
+        return int(self.ctx._L.mzd_batch_last_pass(self._h))
 
     def device_out_ptr(self):
         return self.ctx._L.mzd_batch_device_out(self._h)
@@ -175,6 +201,7 @@ class ResidentBatch:
         self.ctx._L.mzd_batch_get_stats(self._h, ctypes.byref(st))
         return st
 
+    @_ctx_locked
     def free(self):
         if self._h:
             self.ctx._L.mzd_batch_free(self.ctx._c, self._h)
@@ -194,6 +221,7 @@ class Context:
                  huf_min_lds: int = 0, no_split: bool = False, assume_cus: int = 0, verify_checksum: bool = False,
                  seq_window_kib: int = 0, huf_variant: int = 0, exec_variant: int = 0):
         self._L = _lib.load()
+        self._mu = threading.RLock()  # one thread at a time inside the library per context (see _ctx_locked)
         opt = Options()
         opt.seq_variant = seq_variant
         opt.exec_threads = exec_threads
@@ -213,6 +241,7 @@ class Context:
     def last_error(self) -> str:
         return self._L.mzd_last_error(self._c).decode()
 
+    @_ctx_locked
     def upload(self, batch: Batch, device_in_ptr=None, device_out_ptr=None) -> ResidentBatch:
         """device_in_ptr / device_out_ptr: raw device addresses (e.g. torch tensor .data_ptr())
         that replace batch.in / batch.out; the input must carry MZD_IN_PAD bytes of slack."""
@@ -230,6 +259,7 @@ class Context:
             raise MzdError(rc, "mzd_batch_upload: " + self.last_error())
         return ResidentBatch(self, h, batch)
 
+    @_ctx_locked
     def upload_frames(self, blob, frame_off, frame_len, device_in_ptr=None, device_out_ptr=None, device_out_size=0) -> ResidentBatch:
         """Planning on the device (mzd_batch_upload_frames): whole zstd frames in, no host
         planner.  blob: bytes-like / np.uint8 array (host), or pass device_in_ptr (with MZD_IN_PAD slack) and
@@ -253,6 +283,7 @@ class Context:
             raise MzdError(rc, "mzd_batch_upload_frames: " + self.last_error())
         return ResidentBatch(self, h, None, n_frames=off.size)
 
+    @_ctx_locked
     def measure_copy(self, read_bytes: int, write_bytes: int, iters: int = 10) -> float:
         """ms per launch of the plain streaming kernel that reads read_bytes and writes write_bytes (the copy
         ceiling roofline fractions are quoted against, mzd_measure_copy)."""
@@ -262,6 +293,7 @@ class Context:
             raise MzdError(rc, "mzd_measure_copy: " + self.last_error())
         return float(ms.value)
 
+    @_ctx_locked
     def backbits(self, stream: bytes, reads):
         """The device's backward bit reader on a raw stream (mzd_debug_backbits): -> (values, bits_still_in_stream)"""
         nb = np.asarray(reads, dtype=np.uint8)
@@ -274,14 +306,17 @@ class Context:
             raise MzdError(rc, "mzd_debug_backbits: " + self.last_error())
         return [int(v) for v in vals], [int(v) for v in left]
 
+    @_ctx_locked
     def sync(self):
         rc = self._L.mzd_sync(self._c)
         if rc:
             raise MzdError(rc, "mzd_sync: " + self.last_error())
 
+    @_ctx_locked
     def timing_reset(self, enable=True):
         self._L.mzd_timing_reset(self._c, 1 if enable else 0)
 
+    @_ctx_locked
     def kernel_ms(self):
         """average ms per kernel over the runs since timing_reset() (call after sync())"""
         names = (ctypes.c_char_p * 8)()
@@ -289,6 +324,7 @@ class Context:
         n = self._L.mzd_last_run_kernel_ms(self._c, names, ms, 8)
         return {names[i].decode(): ms[i] for i in range(n)}
 
+    @_ctx_locked
     def close(self):
         if self._c:
             self._L.mzd_destroy(self._c)
@@ -302,12 +338,14 @@ class Context:
 
 
 _default_ctx = {}
+_pool_mu = threading.Lock()  # guards _default_ctx and _device_pool (readers that batch create contexts from background threads)
 
 
 def default_context(device: int = 0) -> Context:
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    with _pool_mu:
+        if device not in _default_ctx:
+            _default_ctx[device] = Context(device)
+        return _default_ctx[device]
 
 
 def split_frames(blob):
@@ -361,6 +399,7 @@ class Stream:
             raise MzdError(err.value, "mzd_stream_create")
         self._keep = {}
 
+    @_ctx_locked
     def submit(self, blob: np.ndarray, frame_off, frame_len, out: np.ndarray) -> int:
         """blob / out: uint8 arrays (pinned for real overlap: PinnedBuffer(...).a).  -> ticket"""
         off = np.ascontiguousarray(frame_off, dtype=np.uint64)
@@ -374,6 +413,7 @@ class Stream:
         self._keep[t.value] = (blob, off, ln, out)
         return t.value
 
+    @_ctx_locked
     def wait(self, ticket: int):
         """-> (status int32[n], out_len uint64[n], out_offset uint64[n]) of the batch; its bytes are in `out`"""
         blob, off, ln, out = self._keep[ticket]
@@ -388,6 +428,7 @@ class Stream:
         del self._keep[ticket]
         return st, ol, oo
 
+    @_ctx_locked
     def close(self):
         if self._s:
             self.ctx._L.mzd_stream_destroy(self._s)
@@ -447,9 +488,10 @@ def device_contexts(devices):
             continue
         k = (int(d), seen.get(int(d), 0))
         seen[int(d)] = k[1] + 1
-        if k not in _device_pool:
-            _device_pool[k] = Context(int(d))
-        out.append(_device_pool[k])
+        with _pool_mu:
+            if k not in _device_pool:
+                _device_pool[k] = Context(int(d))
+            out.append(_device_pool[k])
     return out
 
 

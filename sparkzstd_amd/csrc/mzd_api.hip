@@ -100,6 +100,10 @@ struct mzd_dbatch {
     float fse_build_ms = 0;  // k_fse_build at upload (tables that came as normalised counts)
     uint16_t *d_huf_entries = nullptr;
     uint64_t *d_recs = nullptr;
+    uint32_t *d_recs4 = nullptr;  // the four-byte records (mzd_device.h), allocated by the first pass that takes them
+    uint64_t cap_recs4 = 0;       // ... records it has room for
+    bool last_rec4 = false;       // the last pass left its records there (mzd_batch_debug_read expands them)
+    uint32_t last_pass = 0;       // MZD_PASS_* of the last mzd_batch_run
     TileBase *d_tiles = nullptr;
     uint8_t *d_litbuf = nullptr;
     int32_t *d_status = nullptr;
@@ -364,6 +368,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_fse_entries);
     (void)hipFree(db->d_huf_entries);
     (void)hipFree(db->d_recs);
+    (void)hipFree(db->d_recs4);
     (void)hipFree(db->d_tiles);
     (void)hipFree(db->d_litbuf);
     (void)hipFree(db->d_status);
@@ -1390,7 +1395,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_pipe, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kPipeFixedLds + kPipeMaxChains * kSeqCellsPerChain * 2));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kQ4FixedLds + kQ4MaxChains * kSeqCellsPerChain * 2));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kQ4FixedLds + kQ4MaxChains * kSeqCellsPerChain * 2));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
@@ -1519,6 +1526,23 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             exec_c = ctx->opt.exec_variant == 0;
         }
     }
+    // Four-byte records (round 5, mzd_device.h): k_seq_q4 -> k_exec_c when no frame of the batch is larger than 128 KiB (an offset
+    // then fits 17 bits; BASELINE's configs) -- half the record bytes both kernels move.  Other batches, kernels and block mode
+    // keep the 8-byte records.
+    bool rec4 = q4 && exec_c && !blk && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_NO_REC4");
+    for (uint32_t f = 0; rec4 && f < db->n_frames; f++)
+        if (db->frame_out_cap[f] > kRec4OffLimit) rec4 = false;
+    if (rec4 && db->cap_recs4 < db->n_recs) {
+        if (db->d_recs4) (void)hipFree(db->d_recs4);
+        db->d_recs4 = nullptr;
+        db->cap_recs4 = 0;
+        if (hipMalloc((void **)&db->d_recs4, std::max<uint64_t>(db->n_recs, 1) * 4) == hipSuccess) db->cap_recs4 = db->n_recs;
+        else {
+            (void)hipGetLastError();
+            rec4 = false;
+        }
+    }
+    db->last_rec4 = rec4;
     const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
     // Heterogeneous batches: the Huffman kernel runs on the second stream BESIDE the sequence stage -- that stage is bound by
     // its longest chain there (real data: 42 k sequences = 5.9 ms of a 7.5 ms kernel with most CUs idle), the Huffman
@@ -1560,6 +1584,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
     }
     const bool split = fA < db->n_frames;
+    db->last_pass = (rec4 ? MZD_PASS_REC4 : 0u) | (blk ? MZD_PASS_BLOCK_MODE : 0u) | (exec_c ? MZD_PASS_EXEC_C : 0u) | (exec_b ? MZD_PASS_EXEC_B : 0u) |
+                    (split ? MZD_PASS_SPLIT : 0u);
 
     hipEvent_t *ev = nullptr;
     if (ctx->timing) {
@@ -1585,10 +1611,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1) * wg_per_cu;  // workgroups resident at a time
             const uint64_t rounds = (count + cus * nch - 1) / (cus * nch);
             const uint32_t per_wg = rounds > 1 || seq_pack ? nch : (uint32_t)std::min<uint64_t>(nch, (count + cus - 1) / cus);
-            if (q4)
-                k_seq_q4<<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
+            if (q4 && rec4)
+                k_seq_q4<true><<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,
-                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2]);
+                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2], db->d_recs4);
+            else if (q4)
+                k_seq_q4<false><<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
+                    db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,
+                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2], nullptr);
             else
                 k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base);
@@ -1744,8 +1774,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             return;
         }
         if (exec_c) {
-            k_exec_c<false><<<count, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf, db->d_status,
-                                           db->d_out_len, db->d_frame_order, first, XbBlk{});
+            size_t xc_extra_lds = 0;  // experiment: extra dynamic LDS per frame = fewer frames in flight per CU
+            if (const char *e = exp_env("MZD_EXP_XC_LDS")) xc_extra_lds = (size_t)std::max(0, atoi(e));
+            if (rec4)
+                k_exec_c<false, true><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{}, db->d_recs4);
+            else
+                k_exec_c<false><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                                                               db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
         if (exec_b) {
@@ -2128,9 +2164,19 @@ int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset
     if (offset > size || bytes > size - offset) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
+    if (db->last_rec4 && (what == MZD_DEBUG_RECORDS || what == MZD_DEBUG_TILES) && db->n_recs) {
+        // the last pass left four-byte records (and no tile bases, which only k_exec reads): what the caller sees are the 8-byte
+        // records they stand for, and the tile bases these give
+        k_rec4_expand<<<(uint32_t)((db->n_recs + 255) / 256), 256, 0, ctx->stream>>>(db->d_recs4, db->d_recs, db->n_recs);
+        if (db->n_blocks) k_tiles_from_recs<<<(db->n_blocks + 63) / 64, 64, 0, ctx->stream>>>(db->d_blocks, db->d_recs, db->d_tiles, db->n_blocks);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        db->last_rec4 = false;
+    }
     if (bytes) HIP_TRY(ctx, hipMemcpy(dst, (const uint8_t *)base + offset, bytes, hipMemcpyDeviceToHost));
     return MZD_OK;
 }
+
+uint32_t mzd_batch_last_pass(const mzd_dbatch *db) { return db ? db->last_pass : 0u; }
 
 int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step)
 {

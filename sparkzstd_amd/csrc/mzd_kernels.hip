@@ -43,6 +43,30 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { return ((const U64U *)p)->v; }
 
+// Loads / stores of data that is read (written) ONCE per pass, with the `nt` cache-policy bit: the line is served as usual but
+// is the first to leave L2 again, so that what the pass re-reads -- a frame's own recent output -- stays.  NT = false: plain.
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint64_t u64_u __attribute__((aligned(1)));
+template <bool NT>
+__device__ __forceinline__ U128U ld128u_once(const uint8_t *p)
+{
+    if (!NT) return *(const U128U *)p;
+    const u32x4 v = __builtin_nontemporal_load((const u32x4_u *)p);
+    return U128U{v.x, v.y, v.z, v.w};
+}
+template <bool NT>
+__device__ __forceinline__ uint64_t ld64u_once(const uint8_t *p)
+{
+    if (!NT) return ((const U64U *)p)->v;
+    return __builtin_nontemporal_load((const u64_u *)p);
+}
+template <bool NT>
+__device__ __forceinline__ uint64_t ld64_once(const uint64_t *p)
+{
+    if (!NT) return *p;
+    return __builtin_nontemporal_load(p);
+}
+
 // Touch a line: an ordinary load (it allocates in the CU's vL1D and in L2; a `volatile` access would
 // be emitted system-coherent, sc0 sc1, and bypass the vL1D) whose result is waited for and dropped.
 __device__ __forceinline__ void touch_line(const uint8_t *p)

@@ -114,11 +114,16 @@ __device__ __forceinline__ uint32_t q4_history_step(uint32_t hi, uint32_t &h0, u
     return rh;
 }
 
+// REC4 (round 5): the records leave as four-byte words (mzd_device.h) in `recs4`, the 8-byte record only of the sequences that do
+// not fit; the running sums move from stage C2 to the two stage-B wavefronts (which have the lengths in registers anyway; their
+// partial sums meet after the last barrier), tile bases are not written (k_exec_c does not read them): stage C2, which shares
+// its SIMD with a chain wavefront, is left with one 16-byte store per batch of four sequences.
+template <bool REC4>
 __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                                        uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                                        uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
                                                        BlockSum *sums, uint32_t nch, uint64_t in_base, uint32_t cells_ll,
-                                                       uint32_t cells_ml, uint32_t cells_of)
+                                                       uint32_t cells_ml, uint32_t cells_of, uint32_t *__restrict__ recs4)
 {
     // cells_ll / cells_ml / cells_of: the largest LL / ML / OF table of the batch (powers of two).  A chain's slot in LDS is
     // exactly that wide -- 1280 cells when the tables have the format's largest accuracy logs (9 / 9 / 8), 160 when they
@@ -315,11 +320,12 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             rem1 = from_spare(rem1);
         }
         uint32_t left = last_i;  // steps before the chain's last sequence
+        uint32_t W0 = (woff + 127u) & ~127u;  // the hot loop counts the cursor in bits below this offset (see Q4_STEP)
         auto park = [&]() {  // the whole quad: constant cell, cursor 0 (the readable front slack; the ring check is always true for it)
-            st = 1; cb = dummy_addr; nbK = 31; woff = 0; wk = 0; rem1 = 0x7FFFFFFFu; left = 0x7FFFFFFFu; live = false;
+            st = 1; cb = dummy_addr; nbK = 31; woff = 0; wk = 0; W0 = 0; rem1 = 0x7FFFFFFFu; left = 0x7FFFFFFFu; live = false;
         };
         if (!live) park();
-        const uint32_t ringl = 512u + (uint32_t)offsetof(Q4Shared, ring) + ch * (kPipeRing + 8);
+        const uint32_t ringl128 = 512u + (uint32_t)offsetof(Q4Shared, ring) + ch * (kPipeRing + 8) + (uint32_t)kPipeRing;
 
         auto full_cell = [&](int kind, uint32_t x, uint32_t idx, uint32_t toff, uint32_t size, uint32_t &next, uint32_t &ct) {
             next = x & 1023;
@@ -481,11 +487,15 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #else
 #define MZD_Q4_QWR(X) X
 #endif
+// (v70 = the window's byte offset, W0 - (c >> 3): the batch checks are its only users, Q4_OFF computes it)
+#define Q4_OFF                                                                                              \
+    "v_lshrrev_b32 v70, 3, %[c]\n\t"                                                                       \
+    "v_sub_u32 v70, %[w0], v70\n\t"
 #define Q4_RINGCHK(TAG)                                                                                     \
-    "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n"                                                      \
+    "ds_write_b32 %[chan4], v70 offset:%[o_prog]\n"                                                        \
     "L_q4_ring" TAG "_%=:\n\t"                                                                              \
     "ds_read_b32 v66, %[chan4] offset:%[o_rlow]\n\t"                                                       \
-    "v_add_u32 v67, -40, %[off]\n\t"                                                                       \
+    "v_add_u32 v67, -40, v70\n\t"                                                                          \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_cmp_gt_u32 vcc, v66, v67\n\t"                                                                      \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
@@ -510,59 +520,63 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "s_branch L_q4_poll" TAG "_%=\n"                                                                        \
     "L_q4_spc" TAG "_%=:\n\t"                                                                               \
     /* fast path: ring_low as read during the previous step (v89; it only ever decreases) */               \
-    "v_add_u32 v67, -40, %[off]\n\t"                                                                       \
+    Q4_OFF                                                                                                  \
+    "v_add_u32 v67, -40, v70\n\t"                                                                          \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
     "v_cmp_gt_u32 vcc, v89, v67\n\t"                                                                      \
-    "ds_write_b32 %[chan4], %[off] offset:%[o_prog]\n\t"                                                    \
+    "ds_write_b32 %[chan4], v70 offset:%[o_prog]\n\t"                                                       \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     Q4_RINGCHK(TAG)
-// On entry: this step's cell is on its way into v69 (requested by the step before, or the prologue), DMl/DMh get the
+// On entry: this step's cell is on its way into v69 (requested by the step before, or the prologue), DM gets the
 // 8 bytes at the cursor (read at the end of the step before), v85 holds the limit.  DL: where the next step's window
 // goes.  LIMIT: the instruction(s) that finish the next step's limit in v85 (from 64 - k).
-#define Q4_STEP(DMl, DMh, DL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                        \
+// Round 5 (39 -> 35 instructions): the cursor is ONE running bit count c (c >> 3 bytes below W0, a multiple of 128: the ring index
+// is 128 - ((c >> 3) & 127), the ring's 8 spare bytes making 128 as good as 0) instead of a byte offset and a bit count that are
+// normalised every step; the shifted window X is computed by the fourth lane alone, from the registers its LDS read filled, and ONE
+// DPP move hands its high dword to the quad (there were two to hand out the window itself); the cursor and the remaining-bits
+// count move by `total` unconditionally -- a chain that does not "go" leaves the loop with its wavefront right after this step
+// and the exit path takes the step back; the compare leaves the chains that do NOT go in vcc, so that the branch out reads it
+// as it is.  The bits that remain are R0 - c: part of the limit only in the loop variant for the chains' last steps (LIMIT) --
+// a chain that runs out of bits earlier (a damaged stream: its status is an error whatever it decodes) is caught when the
+// loop is left.
+#define Q4_STEP(DM, DL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                              \
     "L_q4_go" TAG "_%=:\n\t"                                                                                \
     MZD_Q4_W1                                       /* the cell (behind it: two queue writes, the ring read) */ \
-    "v_lshrrev_b32 v76, %[shr], v69\n\t"          /* code field */                                        \
     "v_and_b32 v77, 0x3ff, v69\n\t"               /* next */                                              \
-    "v_cndmask_b32_e64 v88, v69, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
+    "v_lshrrev_b32 v76, %[shr], v69\n\t"          /* code field */                                        \
     "v_ffbh_u32 v78, v77\n\t"                                                                             \
     "v_sub_u32_e64 v76, v76, %[Kc] clamp\n\t"     /* ex */                                                \
     "v_min_u32 v78, 0x4000000, v78\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
     "v_sub_u32 v78, v78, %[nbK]\n\t"              /* nb */                                                \
     "v_add_u32_dpp v79, v76, v76 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+    "v_cndmask_b32_e64 v88, v69, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
     MZD_Q4_W2                                       /* the window */                                        \
-    "v_mov_b32_dpp v72, " DMl " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
     "v_add_u32_dpp v80, v78, v78 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
     "v_add_u32_dpp v81, v79, v79 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
-    "v_mov_b32_dpp v73, " DMh " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"                        \
-    "v_add_u32_dpp v82, v78, v80 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
     "v_add_u32 v86, v81, %[k]\n\t"                /* k + o3 */                                            \
+    "v_add_u32_dpp v82, v78, v80 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
+    "v_lshlrev_b64 v[74:75], v86, " DM "\n\t"    /* X = W << (k + o3): the state fields from bit 63 (the fourth lane's is the real one) */ \
     "v_sub_u32 v83, 0, v82\n\t"                   /* -P */                                                \
-    "v_lshlrev_b64 v[74:75], v86, v[72:73]\n\t" /* X = W << (k + o3): the state fields from bit 63 */  \
     "v_add_u32_dpp v87, v82, v81 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
-    "v_bfe_u32 v84, v75, v83, v78\n\t"          /* the lane's state field */                            \
+    "v_mov_b32_dpp v84, v75 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t" /* the fourth lane's X, high dword */ \
+    "v_bfe_u32 v84, v84, v83, v78\n\t"          /* the lane's state field */                            \
     "v_lshl_add_u32 %[s" SB "], v77, v78, v84\n\t" /* new state, in the OTHER register set */            \
-    "v_cmp_lt_u32 vcc, v87, v85\n\t"              /* go (the same in the four lanes of a chain) */        \
+    "v_cmp_ge_u32 vcc, v87, v85\n\t"              /* NOT go: the chain needs the general step (the same in its four lanes) */ \
     "v_lshl_add_u32 v66, %[s" SB "], 1, %[cb]\n\t"                                                         \
     "ds_read_u16 v69, v66\n\t"                    /* the NEXT step's cell; the rest of the step runs behind it */ \
     MZD_Q4_QWR("ds_write_b16 %[qca], v88 offset:" QC "\n\t")                                               \
-    "v_cndmask_b32 v87, 0, v87, vcc\n\t"                                                                  \
-    "v_sub_u32 %[rem1], %[rem1], v87\n\t"                                                                  \
-    "v_add_u32 %[k], %[k], v87\n\t"                                                                        \
-    "v_lshrrev_b32 v70, 3, %[k]\n\t"               /* normalise the cursor for the next step */            \
-    "v_and_b32 %[k], 7, %[k]\n\t"                                                                           \
-    "v_sub_u32 %[off], %[off], v70\n\t"                                                                    \
+    "v_add_u32 %[c], %[c], v87\n\t"               /* (unconditionally: see above) */                      \
+    "v_and_b32 %[k], 7, %[c]\n\t"                                                                           \
+    "v_bfe_u32 v71, %[c], 3, 7\n\t"                                                                        \
     "v_sub_u32 v85, 64, %[k]\n\t"                                                                          \
-    "v_and_b32 v71, " MZD_Q4_RMASK ", %[off]\n\t"                                                          \
+    "v_sub_u32 v71, %[ringl], v71\n\t"            /* ring address of the next window: 128 - ((c >> 3) & 127) */ \
     LIMIT                                           /* the next limit = min(64 - k, rem + 1[, steps before the last]) */ \
-    "v_add_u32 v71, v71, %[ringl]\n\t"                                                                    \
-    "s_andn2_b64 %[smask], exec, vcc\n\t"           /* chains that need the general step; SCC = any */      \
     "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
-    MZD_Q4_QWR("ds_write_b64 %[qwa], v[72:73] offset:" QW "\n\t") /* this step's window for stage B */     \
+    MZD_Q4_QWR("ds_write_b64 %[qwa], " DM " offset:" QW "\n\t") /* this step's window for stage B */       \
     "ds_read_b64 " DL ", v71\n\t"                  /* the next step's window */                            \
     "s_mov_b64 exec, -1\n\t"                                                                                \
     RLOW                                                                                                    \
-    "s_cbranch_scc1 " OUT "\n\t"
+    "s_cbranch_vccnz " OUT "\n\t"
 #define Q4_PUBLISH(OUT)                                                                                     \
     "s_add_u32 %[i], %[i], 4\n\t"                                                                           \
     "v_mov_b32 v68, %[i]\n\t"                                                                              \
@@ -583,11 +597,13 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                        cursor BEFORE they are read (the very first entry: wave P may not have filled anything yet;      \
                        after a general step: the cursor has moved by more than a hot step). */                          \
                     "v_mov_b32 v89, -1\n\t"  /* no ring_low read ahead yet: the first batch check takes the slow path */ \
+                    Q4_OFF                                                                                              \
                     Q4_RINGCHK("e")                                                                                     \
                     "L_q4_goe_%=:\n\t"                                                                                  \
-                    "v_and_b32 v71, 127, %[off]\n\t"                                                               \
+                    "v_bfe_u32 v71, %[c], 3, 7\n\t"                                                                    \
+                    "v_and_b32 %[k], 7, %[c]\n\t"                                                                       \
+                    "v_sub_u32 v71, %[ringl], v71\n\t"                                                                \
                     "v_sub_u32 v85, 64, %[k]\n\t"                                                                      \
-                    "v_add_u32 v71, v71, %[ringl]\n\t"                                                                \
                     LIMIT                                                                                               \
                     "v_lshl_add_u32 v66, %[sa], 1, %[cb]\n\t"                                                          \
                     "ds_read_u16 v69, v66\n\t"                                                                        \
@@ -614,27 +630,27 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     "s_cbranch_scc1 L_q4_go6_%=\n\t"                                                                    \
                     "s_branch L_q4_go7_%=\n"                                                                            \
                     Q4_CHECK("0", "%[tail0]", "%[o_tail0]")                                                             \
-                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
-                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
-                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
-                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
                     Q4_PUBLISH(Q4_OUTO)                                                                                 \
                     Q4_CHECK("4", "%[tail1]", "%[o_tail1]")                                                             \
-                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
-                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
-                    Q4_STEP("v90", "v91", "v[92:93]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
-                    Q4_STEP("v92", "v93", "v[90:91]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
                     Q4_PUBLISH(Q4_OUTO)                                                                                 \
                     "s_branch L_q4_top0_%=\n"                                                                           \
                     /* a step that leaves: the counter moves past it; after the first / third step of a batch the new   \
-                       states are in set b, after the second / fourth in set a (vcc is still the step's "go") */         \
+                       states are in set b, after the second / fourth in set a (vcc still holds the chains that did not go) */ \
                     "L_q4_x1_%=:\n\t"                                                                                   \
                     "s_add_u32 %[i], %[i], 1\n\t"                                                                       \
                     "s_branch L_q4_oute_%=\n"                                                                           \
                     "L_q4_x3_%=:\n\t"                                                                                   \
                     "s_add_u32 %[i], %[i], 3\n"                                                                         \
                     "L_q4_oute_%=:\n\t"                                                                                 \
-                    "v_cndmask_b32 %[sa], %[sa], %[sb], vcc\n\t"                                                        \
+                    "v_cndmask_b32 %[sa], %[sb], %[sa], vcc\n\t"                                                        \
                     "s_branch L_q4_done_%=\n"                                                                           \
                     "L_q4_x2_%=:\n\t"                                                                                   \
                     "s_add_u32 %[i], %[i], 2\n\t"                                                                       \
@@ -642,12 +658,15 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     "L_q4_x4_%=:\n\t"                                                                                   \
                     "s_add_u32 %[i], %[i], 4\n"                                                                         \
                     "L_q4_outo_%=:\n\t"                                                                                 \
-                    "v_cndmask_b32 %[sa], %[sb], %[sa], vcc\n"                                                          \
+                    "v_cndmask_b32 %[sa], %[sa], %[sb], vcc\n"                                                          \
                     "L_q4_done_%=:\n\t"                                                                                 \
+                    "v_cndmask_b32_e64 v87, 0, v87, vcc\n\t" /* chains that did not go: the cursor back */            \
+                    "v_sub_u32 %[c], %[c], v87\n\t"                                                                    \
+                    "s_mov_b64 %[smask], vcc\n\t"                                                                      \
                     "s_waitcnt lgkmcnt(0)\n\t"  /* the speculative cell read and the ring read are still on their way */ \
-                    : [sa] "+v"(st), [sb] "+v"(stb), [k] "+v"(wk), [rem1] "+v"(rem1), [off] "+v"(woff), [i] "+s"(i),    \
+                    : [sa] "+v"(st), [sb] "+v"(stb), [k] "+v"(wk), [c] "+v"(cur), [i] "+s"(i),     \
                       [left] "+v"(left), [tail0] "+s"(tail0), [tail1] "+s"(tail1), [polls] "+s"(polls), [smask] "=&s"(smask)               \
-                    : [cb] "v"(cb), [shr] "v"(shr), [Kc] "v"(Kc), [nbK] "v"(nbK), [ringl] "v"(ringl), [qca] "v"(qca), [qwa] "v"(qwa), \
+                    : [cb] "v"(cb), [shr] "v"(shr), [Kc] "v"(Kc), [nbK] "v"(nbK), [ringl] "v"(ringl128), [w0] "v"(W0), [r0] "v"(R0), [qca] "v"(qca), [qwa] "v"(qwa), \
                       [chan4] "v"(chan4), [heada] "v"(heada), [vzero] "v"(vzero),                                       \
                       [nmax] "s"(BOUND), [spare] "s"(sparemask),                                                       \
                       [o_tail0] "n"(512 + offsetof(Q4Shared, tailB)), [o_tail1] "n"(512 + offsetof(Q4Shared, tailB) + 4), \
@@ -660,12 +679,24 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                       "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",                   \
                       "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",                           \
                       "v85", "v86", "v87", "v88", "v90", "v91", "v92", "v93", "v89")
+                // the asm block's cursor: bits consumed below W0 (a multiple of 128 at or above the window; 0 for a parked quad)
+                uint32_t cur = ((W0 - woff) << 3) + wk;
+                const uint32_t R0 = rem1 + cur;  // bits that remain + 1 = R0 - cur
                 if (i < ncom) {
-                    Q4_HOT_LOOP("v_min_u32 v85, v85, %[rem1]\n\t", ncom);
+                    Q4_HOT_LOOP("", ncom);
                 } else {
-                    Q4_HOT_LOOP("v_min3_u32 v85, v85, %[rem1], %[left]\n\tv_add_u32 %[left], -1, %[left]\n\t", nmax);
+                    Q4_HOT_LOOP("v_sub_u32 v67, %[r0], %[c]\n\tv_min3_u32 v85, v85, v67, %[left]\n\tv_add_u32 %[left], -1, %[left]\n\t", nmax);
                 }
+                woff = W0 - (cur >> 3);
+                wk = cur & 7u;
+                rem1 = R0 - cur;
+                // (the loop of the common steps does not look at the bits that remain: a chain that has read past the start of its
+                // stream has rem1 = remaining + 1 <= 0 from here on -- as an unsigned limit that never binds; the general step of its
+                // next escape, or of its last sequence at the latest, sees total > remaining and ends it with MZD_ERR_SEQ_BITS,
+                // sequences.go:197-204.  Wave P stops following a cursor more than 56 bytes below the stream: nothing is read
+                // outside the blob's front slack.)
 #undef Q4_HOT_LOOP
+#undef Q4_OFF
 #undef Q4_STEP
 #undef Q4_CHECK
 #undef Q4_RINGCHK
@@ -714,6 +745,8 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         const uint32_t par = (uint32_t)lw - 4u;
         const int col = min(lane, kQ4Cols - 1);  // lanes 56..63 have no column: they shadow the last one
         uint32_t head_seen = 0, tail_seen = 0;
+        const uint32_t my_n = has ? t.n_seq : 0u;
+        uint32_t litPos = 0, outPos = 0, err_size = 0;  // REC4: this wavefront's share of the block's running sums
 #ifdef MZD_Q4_PROF
         long long prof_in = 0, prof_out = 0, prof_t0 = clock64();
 #endif
@@ -763,10 +796,27 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 const uint32_t llx = __builtin_amdgcn_ubfe(Y, 32u - exM - exL, exL);
                 const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
                 const uint32_t llv = (cl & 0xFFFFFF) + llx;
-                const uint64_t v = (uint64_t)llv | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
-                                   ((uint64_t)q4_offset_code(ofv, llv) << kRecOffShift);
-                q[u] = (kk & 0x8000u) ? T[u] : v;
+                if (!REC4) {
+                    const uint64_t v = (uint64_t)llv | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                       ((uint64_t)q4_offset_code(ofv, llv) << kRecOffShift);
+                    q[u] = (kk & 0x8000u) ? T[u] : v;
+                } else {
+                    // the lengths and the offset code of the sequence, whichever kind of step made it
+                    const bool gen = (kk & 0x8000u) != 0;
+                    const uint32_t LL = gen ? (uint32_t)T[u] & kRecLlMask : llv;
+                    const uint32_t ML = gen ? (uint32_t)(T[u] >> kRecMlShift) & kRecMlMask : (cm & 0xFFFFFF) + mlx;
+                    const uint32_t code = gen ? (uint32_t)(T[u] >> kRecOffShift) : q4_offset_code(ofv, llv);
+                    const bool act = j0 + (uint32_t)u < my_n;  // (a chain that has ended hands on dummies)
+                    litPos += act ? LL : 0u;
+                    outPos += act ? LL + ML : 0u;
+                    // the low word: the lengths as the four-byte record has them, or 0 -- then the 8-byte record's low dword goes to
+                    // memory from here (stage C2 adds the high one, which stage C1 finishes)
+                    const bool fits = ((LL >> 7) | (ML >> 8)) == 0;
+                    if (act && !fits) ((uint32_t *)(recs + t.rec_off + j0 + u))[0] = LL | (ML << kRecMlShift);
+                    q[u] = (uint64_t)(fits ? LL | (ML << kRec4MlShift) : 0u) | ((uint64_t)((ML >> 15) | (code << 3)) << 32);
+                }
             }
+            if (REC4) err_size |= outPos > kBlockMax;  // (a PARTIAL sum beyond the limit: the whole is too; four steps add < 2^21: no wrap)
 #endif
 #ifdef MZD_Q4_PROF
             const long long w1 = clock64();
@@ -784,6 +834,11 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][col] = q[u];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->head2[par], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (REC4) {
+            // (the A -> B queue is idle: stage A has produced everything and this wavefront's slots -- [4 par, 4 par + 4) -- are read)
+            shs->q1w[4 * par][col] = (uint64_t)litPos | ((uint64_t)outPos << 32);
+            shs->q1c[4 * par][col][0] = (uint16_t)err_size;
         }
 #ifdef MZD_Q4_PROF
         if (blockIdx.x == 0 && lane == 0) printf("B%u: cycles %lld wait_in %lld wait_out %lld (steps %u)\n", par, clock64() - prof_t0, prof_in, prof_out, nmax);
@@ -882,6 +937,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         // record streams)
         const int col = min(lane, kQ4Cols - 1);
         uint64_t *myrec = recs + t.rec_off;
+        uint32_t *myrec4 = recs4 + t.rec_off;
         TileBase *mytile = tiles + t.tile_off;
         const uint32_t my_n = has ? t.n_seq : 0u;
         uint32_t litPos = 0, outPos = 0, err_size = 0;
@@ -909,6 +965,44 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef MZD_EXP_FAST_BC
+            if (REC4) {
+                // the four-byte records: lengths from stage B's low word, the offset stage C1 resolved (hi = ML bits 15..17 | offset
+                // << 3: off << 15 is hi << 12 when the lengths fit)
+                uint32_t w[kPipeBatch];
+                uint32_t lo_min = 0xFFFFFFFFu, hi_max = 0;
+#pragma unroll
+                for (int u = 0; u < kPipeBatch; u++) {
+                    const uint32_t lo = (uint32_t)rr[u], hi = (uint32_t)(rr[u] >> 32);
+                    w[u] = lo | (hi << (kRec4OffShift - 3));
+                    lo_min = min(lo_min, lo);
+                    hi_max = max(hi_max, hi);
+                }
+                if (lo_min == 0 || hi_max >= (kRec4OffLimit << 3)) {
+                    // a sequence of this batch does not fit: word 0, and the 8-byte record (stage B has stored the low dword of one
+                    // whose LENGTHS do not fit; one whose offset does not is written whole)
+#pragma unroll
+                    for (int u = 0; u < kPipeBatch; u++) {
+                        const uint32_t lo = (uint32_t)rr[u], hi = (uint32_t)(rr[u] >> 32);
+                        if (j0 + u >= my_n) continue;
+                        if (lo == 0) {
+                            ((uint32_t *)(myrec + j0 + u))[1] = hi;
+                            w[u] = 0;
+                        } else if (hi >= (kRec4OffLimit << 3)) {
+                            myrec[j0 + u] = (uint64_t)((lo & kRec4LlMax) | ((lo >> kRec4MlShift) << kRecMlShift)) | ((uint64_t)hi << 32);
+                            w[u] = 0;
+                        }
+                    }
+                }
+                if (j0 + (uint32_t)kPipeBatch <= my_n) {
+                    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+                    *(u32x4a *)(myrec4 + j0) = u32x4a{w[0], w[1], w[2], w[3]};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kPipeBatch; u++)
+                        if (j0 + u < my_n) myrec4[j0 + u] = w[u];
+                }
+                continue;
+            }
             if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
             if (j0 + (uint32_t)kPipeBatch <= my_n) {
 #pragma unroll
@@ -936,12 +1030,14 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_Q4_PROF
         if (blockIdx.x == 0 && lane == 0) printf("C2: cycles %lld wait_in %lld\n", clock64() - prof_t0, prof_in);
 #endif
-        if (has && t.n_seq > 0) {
-            BlockSum *bs = &sums[t.block];
-            bs->lit_total = litPos;
-            bs->out_total = outPos;
+        if (!REC4) {
+            if (has && t.n_seq > 0) {
+                BlockSum *bs = &sums[t.block];
+                bs->lit_total = litPos;
+                bs->out_total = outPos;
+            }
+            shs->stC2[lane] = err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
         }
-        shs->stC2[lane] = err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
     } else {
         // ================= wave P: the chains' bitstreams, ahead of stage A (as k_seq_pipe) =================
         const uint8_t *inb = in - MZD_IN_PAD;
@@ -1002,8 +1098,44 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     if (lw == 6 && has && t.n_seq > 0) {
         int st = shs->stA[lane];
         if (st == MZD_OK) st = shs->stC[lane];
+        if (REC4) {
+            // the block's totals: the two stage-B wavefronts' shares (lane = chain = their column)
+            const uint64_t p0 = shs->q1w[0][lane], p1 = shs->q1w[4][lane];
+            const uint32_t lit = (uint32_t)p0 + (uint32_t)p1, outp = (uint32_t)(p0 >> 32) + (uint32_t)(p1 >> 32);
+            const bool bad = shs->q1c[0][lane][0] != 0 || shs->q1c[4][lane][0] != 0 || outp > kBlockMax;
+            sums[t.block].lit_total = lit;
+            sums[t.block].out_total = outp;
+            shs->stC2[lane] = bad ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
+        }
         if (st == MZD_OK) st = shs->stC2[lane];
         if (st != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, st);
+    }
+}
+
+// ---- debugging / tests (mzd_batch_debug_read): the 8-byte records that the four-byte words of a pass stand for, and the tile bases
+// of a batch from its records (what stage C2 writes when the execution kernel is k_exec)
+__global__ void k_rec4_expand(const uint32_t *__restrict__ recs4, uint64_t *__restrict__ recs, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = recs4[i];
+    if (w)
+        recs[i] = (uint64_t)(w & kRec4LlMax) | ((uint64_t)((w >> kRec4MlShift) & kRec4MlMax) << kRecMlShift) |
+                  ((uint64_t)(w >> kRec4OffShift) << kRecOffShift);
+}
+__global__ void k_tiles_from_recs(const DBlock *__restrict__ blocks, const uint64_t *__restrict__ recs, TileBase *__restrict__ tiles, uint32_t n_blocks)
+{
+    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= n_blocks) return;
+    const DBlock b = blocks[bi];
+    if (b.type != MZD_BLOCK_COMPRESSED) return;
+    uint32_t lit = 0, outp = 0;
+    for (uint32_t j = 0; j < b.n_seq; j++) {
+        if ((j & 63) == 0) tiles[b.tile_off + (j >> 6)] = TileBase{lit, outp};
+        const uint64_t r = recs[b.rec_off + j];
+        const uint32_t LL = (uint32_t)r & kRecLlMask, ML = (uint32_t)(r >> kRecMlShift) & kRecMlMask;
+        lit += LL;
+        outp += LL + ML;
     }
 }
 

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
 
 def test_identity_and_errors():
     L = _lib.load()
-    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 6
+    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 7
     assert L.mzd_backend() == b"hip-gfx950"
     assert b"Magicnum" in L.mzd_strerror(2)
     assert L.mzd_device_count() >= 0
@@ -78,3 +78,48 @@ def test_release_library_reads_no_environment_variable():
     assert not hooks, hooks
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparkzstd_amd", "csrc", "mzd_api.hip")).read()
     assert "getenv(" not in src.replace("inline const char *exp_env(const char *name) { return getenv(name); }", "")
+
+
+def test_context_calls_are_serialised_per_context():
+    """BatchFrameReader decodes ahead on a background thread with the SAME context the consumer may be using; every
+    method that enters the library with a context holds that context's lock (ctypes drops the GIL around the call)."""
+    import threading
+    import time
+    from sparkzstd_amd import api
+
+    for cls, names in ((api.ResidentBatch, ("run", "download", "read_out", "free", "frame_layout", "debug_read")),
+                       (api.Context, ("upload", "upload_frames", "sync", "kernel_ms", "close", "measure_copy")),
+                       (api.Stream, ("submit", "wait", "close"))):
+        for n in names:
+            assert hasattr(getattr(cls, n), "__wrapped__"), f"{cls.__name__}.{n} enters the library without the context's lock"
+
+    class FakeCtx:
+        def __init__(self):
+            self._mu = threading.RLock()
+
+    class Fake:
+        inside = 0
+        worst = 0
+
+        def __init__(self, ctx):
+            self.ctx = ctx
+
+        @api._ctx_locked
+        def call(self):
+            Fake.inside += 1
+            Fake.worst = max(Fake.worst, Fake.inside)
+            time.sleep(0.002)
+            self.nested()  # (re-entrant: a method may call another one of the same context)
+            Fake.inside -= 1
+
+        @api._ctx_locked
+        def nested(self):
+            pass
+
+    ctx = FakeCtx()
+    ths = [threading.Thread(target=lambda: [Fake(ctx).call() for _ in range(5)]) for _ in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert Fake.worst == 1

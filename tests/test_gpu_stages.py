@@ -2,6 +2,7 @@
 reader against the reference's own bit-reader vectors, the BASELINE configs at their stated sizes, and the
 self-launching multi-rank bench.  Everything goes through the C-ABI."""
 import ctypes
+import hashlib
 import json
 import os
 import subprocess
@@ -106,6 +107,46 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
     resolved offset) (sequences.go:11-15 + sequence_execution.go:65-114) as the device holds them between its
     stages equal the oracle's trace, block by block -- not only the final bytes."""
     c = z.Context(0, seq_variant=seq_variant, huf_variant=huf_variant)
+    n = _check_stage_boundaries(c, corpus, oracle)
+    assert n["blocks"] > 1500 and n["seqs"] > 1000000 and n["lits"] > 2000000
+    assert n["symbolic"] > 0 or seq_variant == 1  # later blocks of a frame carry repeat offsets relative to the block start
+    assert not n["pass"] & _lib.MZD_PASS_REC4  # (the corpus has frames of up to 1 MiB: 8-byte records)
+
+
+def test_four_byte_records_equal_the_oracle_trace(corpus, oracle):
+    """Batches whose frames are all at most 128 KiB -- BASELINE's configs -- hand their sequences from k_seq_q4 to k_exec_c as
+    FOUR-byte records (LL:7 | ML:8 | offset:17; mzd_device.h), the few that do not fit as 8-byte ones.  The same check as above
+    on such a batch: the corpus's frames of up to 128 KiB (real data: literal runs of 128 and more, matches of 256 and more,
+    multi-block frames whose later blocks start with symbolic repeat offsets -- every way a sequence can fail to fit) beside
+    text-like synthetic frames; the records are compared AFTER expansion to the 8-byte form, value for value, and the frames'
+    bytes with the oracle's."""
+    from tools import synth_binding as sb
+    c = z.Context(0)
+    small = [it for it in corpus if it[2] <= 131072]
+    blob, off, ln, _, _ = sb.make_batch(4, 77, 6, 131072, threads=2)
+    synth = []
+    for i in range(len(off)):
+        comp = bytes(blob[int(off[i]):int(off[i]) + int(ln[i])])
+        rc, ref, _, _ = oracle.decode_frame(comp, cap=1 << 18)
+        assert rc == 0
+        synth.append((f"synth{i}", comp, len(ref), hashlib.sha256(ref).hexdigest(), ref))
+    # the planner's bound of a frame that declares no content size is its window or 128 KiB per block: keep what qualifies
+    plan = z.Plan(device_tables=True)
+    for _, comp, *_ in small:
+        assert plan.add_frame(comp)[0] == 0
+    b = plan.finalize()
+    items = [it for i, it in enumerate(small) if int(b.frames[i].out_capacity) <= 131072] + synth
+    plan.close()
+    assert len(items) > 40
+    n = _check_stage_boundaries(c, items, oracle)
+    assert n["pass"] & _lib.MZD_PASS_REC4 and n["pass"] & _lib.MZD_PASS_EXEC_C
+    assert n["seqs"] > 100000 and n["escapes"] > 100 and n["symbolic"] > 0, n
+
+
+def _check_stage_boundaries(c, corpus, oracle):
+    """one pass over the frames of `corpus` ((name, compressed, length, ...) items) on context `c` (closed here): literals,
+    sequence records and tile bases of every block against the oracle's trace, the frames' bytes against its output.
+    -> counts of what was seen"""
     frames = [comp for _, comp, *_ in corpus]
     plan = z.Plan(device_tables=True)
     for f in frames:
@@ -114,7 +155,8 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
     rb = c.upload(b)
     try:
         rb.run()
-        out_blob, status, _ = rb.download()
+        last_pass = rb.last_pass()
+        out_blob, status, out_len = rb.download()
         assert (status == 0).all()
         st = rb.stats()
         dblocks = rb.debug_blocks(b.n_blocks)
@@ -125,11 +167,12 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
         lits = rb.debug_read(_lib.MZD_DEBUG_LITERALS, np.uint8, 0, lit_bytes)
         tiles = rb.debug_read(_lib.MZD_DEBUG_TILES, np.uint32, 0, 2 * sum((int(d.n_seq) + 63) // 64 for d in dblocks))
         blob = bytes(np.ctypeslib.as_array(ctypes.cast(b.in_, ctypes.POINTER(ctypes.c_uint8)), shape=(b.in_size,)))
-        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = n_in_place = 0
+        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = n_in_place = n_escapes = 0
         for fi, f in enumerate(frames):
-            rc, _, _, tr = oracle.decode_frame(f, cap=corpus[fi][2] + 64, want_trace=True)
+            rc, ref, _, tr = oracle.decode_frame(f, cap=corpus[fi][2] + 64, want_trace=True)
             assert rc == 0
             fd = b.frames[fi]
+            assert out_blob[int(fd.out_offset):int(fd.out_offset) + int(out_len[fi])].tobytes() == ref, corpus[fi][0]
             assert fd.n_blocks == len(tr["blocks"])
             lit_at = seq_at = 0
             hist = [1, 4, 8]  # framedecompressor.go:48,59
@@ -169,6 +212,7 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
                         u = g_of & 0x0FFFFFFF
                         g_of = h0[u & 3] - (u >> 2)
                         n_symbolic += 1
+                    n_escapes += 1 if (ll > 127 or ml > 255 or g_of >= (1 << 17)) else 0  # would not fit a four-byte record
                     assert (g_ll, g_ml, g_of) == (ll, ml, resolved), (corpus[fi][0], k, j)
                     assert _next_offset(hist, raw, ll) == resolved  # the test's history agrees with the oracle's
                     if j % 64 == 0:
@@ -179,8 +223,8 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
                 seq_at += ns
                 n_seq_seen += ns
             assert lit_at == len(tr["literals"]) and seq_at == len(tr["seqs"])
-        assert n_blocks_seen > 1500 and n_seq_seen == n_rec > 1000000 and n_lit_seen > 2000000
-        assert n_symbolic > 0 or seq_variant == 1  # later blocks of a frame carry repeat offsets relative to the block start
+        assert n_seq_seen == n_rec
+        return {"blocks": n_blocks_seen, "seqs": n_seq_seen, "lits": n_lit_seen, "symbolic": n_symbolic, "escapes": n_escapes, "pass": last_pass}
     finally:
         rb.free()
         plan.close()
@@ -258,9 +302,11 @@ def test_huf_seg_reports_the_lane_kernels_status_on_damaged_streams(corpus, orac
     assert n_huf_err > 20  # the damage really reached the Huffman end conditions
     for f, o, s in list(zip(frames, res[2][0], res[2][1]))[::5]:
         rc, ref, _, _ = oracle.decode_frame(f, cap=4 << 20)
-        assert (rc == 0) == (s == 0) or s != 0  # the device may be stricter, never laxer
+        # the device fails exactly the frames the reference's algorithm fails; what it may add are the checks the reference does
+        # not make (a block of more than 128 KiB: 12; the declared content size: 15) and its documented limits (16)
+        assert (s == 0) == (rc == 0) or (rc == 0 and s in (12, 15, 16)), (s, rc)
         if s == 0:
-            assert rc == 0 and o == ref
+            assert o == ref
 
 
 # ---- BASELINE.json configs at their stated sizes: size-independent properties on every frame

@@ -2,12 +2,23 @@
 """GPU fuzz soak (not part of the test suite): corpus and synthetic frames with random byte flips /
 truncations, decoded in batches.  The device must never fault; a frame it reports as decoded must
 be one the oracle decodes to the same bytes; a frame the oracle rejects must carry a status.
+
+Two pools of base frames, batches alternate between them:
+  small   frames that regenerate at most 128 KiB (what BASELINE's configs are made of): the library's own choice for such a
+          batch is k_seq_q4 with FOUR-byte records into k_exec_c (round 5); contexts: the default, k_seq / k_seq_pipe with
+          k_exec_c's 8-byte records (exec_variant 5), k_exec_b, k_exec
+  mixed   everything, frames of up to 1.2 MiB in several blocks: 8-byte records, the serial walk and block mode (exec_variant
+          3, 4; 4 also with mzd_debug_force_fixup_bail: the rescue launch of the fix-up walk on damaged input)
+Both pools hold PERIODIC content too (runs that feed themselves at periods of 1 to 40 bytes: the in-pass resolver of
+k_exec_c -- ringbuffer.go:242-277, the overlap case -- and sequences with a literal length of 0 in front of repeat
+codes, sequence_execution.go:84-101).
 usage: python tools/fuzz_soak.py [n_mutations] [seed]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import sparkzstd_amd as z
+from sparkzstd_amd import _lib
 from tools import synth_binding as sb
 from tests.oracle_binding import load_oracle
 
@@ -15,38 +26,99 @@ n_mut = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 orc = load_oracle()
+L = _lib.load()
 golden = os.path.join(ROOT, "tests", "golden", "decodecorpus")
-names = sorted(json.load(open(os.path.join(golden, "manifest.json"))))
-base = [open(os.path.join(golden, n + ".zst"), "rb").read() for n in names]
-base = [b for b in base if 24 <= len(b) <= 200000]
+manifest = json.load(open(os.path.join(golden, "manifest.json")))
+names = sorted(manifest)
+
+
+def periodic(seed_, n):
+    """runs of a short period between stretches of text: matches with offset < length, repeat codes behind a zero literal length"""
+    r = np.random.default_rng(seed_)
+    out = bytearray()
+    text = sb.generate(sb.TEXT, seed_, n)
+    while len(out) < n:
+        p = int(r.integers(1, 41))
+        unit = bytes(r.integers(97, 123, size=p, dtype=np.uint8))
+        out += unit * int(r.integers(2, 400))
+        a = int(r.integers(0, max(1, n - 300)))
+        out += text[a:a + int(r.integers(0, 300))]
+    return bytes(out[:n])
+
+
+small, mixed = [], []
+for nm in names:
+    b = open(os.path.join(golden, nm + ".zst"), "rb").read()
+    if 24 <= len(b) <= 200000:
+        mixed.append(b)
+        if manifest[nm]["length"] <= 131072:
+            small.append(b)
 for i in range(40):
-    base.append(sb.compress(sb.generate(int(rng.choice([sb.TEXT, sb.EXP])), 900 + i, int(rng.integers(200, 150000))))[0])
+    f = sb.compress(sb.generate(int(rng.choice([sb.TEXT, sb.EXP])), 900 + i, int(rng.integers(200, 131072))))[0]
+    small.append(f)
+    mixed.append(f)
+for i in range(16):
+    f = sb.compress(periodic(2900 + i, int(rng.integers(2000, 131072))))[0]
+    small.append(f)
+    mixed.append(f)
 for i in range(12):  # multi-block frames: the scan / pattern passes / fix-up walk of block mode on damaged input
-    base.append(sb.compress(sb.generate(int(rng.choice([sb.TEXT, sb.EXP])), 1900 + i, int(rng.integers(300000, 1200000))))[0])
-ctxs = [z.Context(0, seq_variant=0, verify_checksum=True), z.Context(0, seq_variant=1), z.Context(0, seq_variant=3, huf_variant=2), z.Context(0, huf_variant=3),
-        z.Context(0, exec_variant=2), z.Context(0, exec_variant=3), z.Context(0, exec_variant=4, huf_variant=2)]
-bad = done = n_ok = 0
+    mixed.append(sb.compress(sb.generate(int(rng.choice([sb.TEXT, sb.EXP])), 1900 + i, int(rng.integers(300000, 1200000))))[0])
+for i in range(4):
+    mixed.append(sb.compress(periodic(3900 + i, int(rng.integers(300000, 900000))))[0])
+
+ctx_small = [("default", z.Context(0)), ("k_seq + k_exec_c", z.Context(0, seq_variant=1, exec_variant=5)),
+             ("k_seq_pipe + k_huf_seg + k_exec_c", z.Context(0, seq_variant=3, huf_variant=2, exec_variant=5)),
+             ("k_exec_b", z.Context(0, exec_variant=2)), ("k_exec + checksum", z.Context(0, exec_variant=1, verify_checksum=True))]
+ctx_mixed = [("default + checksum", z.Context(0, verify_checksum=True)), ("k_seq", z.Context(0, seq_variant=1)), ("k_huf first", z.Context(0, huf_variant=3)),
+             ("k_exec_c", z.Context(0, exec_variant=5)), ("k_exec_b", z.Context(0, exec_variant=2)), ("block mode", z.Context(0, exec_variant=3)),
+             ("block mode, jobs of four", z.Context(0, exec_variant=4, huf_variant=2)), ("block mode, fix-up rescue", z.Context(0, exec_variant=4))]
+bail_ctx = ctx_mixed[-1][1]
+
+
+def decode(frames, c):
+    """z.decode_frames, and which kernels the pass took (ResidentBatch.last_pass)"""
+    rb, lay, out_len, sts = z.api.decode_frames_resident(frames, c)
+    try:
+        lp = rb.last_pass()
+        out, _, _ = rb.download()
+    finally:
+        rb.free()
+    return [out[int(lay[i]):int(lay[i]) + int(out_len[i])].tobytes() if sts[i] == 0 else None for i in range(len(frames))], sts, lp
+
+
+n_pass = {"four-byte records": 0, "block mode": 0, "k_exec_c": 0, "k_exec_b": 0}
+bad = done = n_ok = n_batches = 0
 t0 = time.time()
 while done < n_mut:
+    pool, ctxs = (small, ctx_small) if n_batches % 2 == 0 else (mixed, ctx_mixed)
+    n_batches += 1
     frames = []
+    # (every other batch of the small pool leaves the frame headers alone: a damaged window descriptor or content size that
+    # declares a frame of more than 128 KiB takes the whole batch out of the four-byte-record path, which is to be soaked too)
+    lo = 14 if pool is small and n_batches % 4 == 1 else 5
     for _ in range(min(1000, n_mut - done)):
-        b = bytearray(base[int(rng.integers(len(base)))])
+        b = bytearray(pool[int(rng.integers(len(pool)))])
         r = rng.random()
         if r < 0.1:
             b = b[:int(rng.integers(1, len(b)))]
         else:
-            for pos in rng.integers(5, len(b), size=int(rng.integers(1, 4))):
+            for pos in rng.integers(min(lo, len(b) - 1), len(b), size=int(rng.integers(1, 4))):
                 b[int(pos)] ^= int(rng.integers(1, 256))
         frames.append(bytes(b))
-    for ci, c in enumerate(ctxs):
-        outs, sts = z.decode_frames(frames, c)
-        for f, o, s in zip(frames, outs, sts):
-            rc, want, _, _ = orc.decode_frame(f, cap=4 << 20)
+    want = [orc.decode_frame(f, cap=4 << 20) for f in frames]
+    for name, c in ctxs:
+        if c is bail_ctx:
+            assert L.mzd_debug_force_fixup_bail(c._c, int(rng.integers(1, 6))) == 0
+        outs, sts, lp = decode(frames, c)
+        for k, bit in (("four-byte records", _lib.MZD_PASS_REC4), ("block mode", _lib.MZD_PASS_BLOCK_MODE), ("k_exec_c", _lib.MZD_PASS_EXEC_C),
+                       ("k_exec_b", _lib.MZD_PASS_EXEC_B)):
+            n_pass[k] += 1 if lp & bit else 0
+        for f, o, s, (rc, ref, _, _) in zip(frames, outs, sts, want):
             if s == 0:
                 n_ok += 1
-                if rc != 0 or o != want:
+                if rc != 0 or o != ref:
                     bad += 1
-                    print("DISAGREE: device ok, oracle rc", rc, "len", len(f), flush=True)
+                    print(f"DISAGREE [{name}]: device ok, oracle rc", rc, "len", len(f), flush=True)
             elif rc != 0:
                 pass
             elif s == 12:
@@ -55,12 +127,13 @@ while done < n_mut:
                 _, _, _, tr = orc.decode_frame(f, cap=4 << 20, want_trace=True)
                 if max((b["out_end"] - b["out_begin"] for b in tr["blocks"]), default=0) <= 131072:
                     bad += 1
-                    print("DISAGREE: oracle ok, device status 12 without an oversized block, len", len(f), flush=True)
+                    print(f"DISAGREE [{name}]: oracle ok, device status 12 without an oversized block, len", len(f), flush=True)
             elif s not in (15, 16, 18):  # oracle accepts, device rejects: only the content-size / checksum checks the reference
                 # does not make (a corrupted Frame_Content_Size, MZD_ERR_DST_FULL) and the documented limits may do that
                 bad += 1
-                print("DISAGREE: oracle ok, device status", s, "len", len(f), flush=True)
+                print(f"DISAGREE [{name}]: oracle ok, device status", s, "len", len(f), flush=True)
     done += len(frames)
-    print(f"{done} mutations, {n_ok} decoded, {bad} bad, {time.time() - t0:.0f} s", flush=True)
-print("FUZZ SOAK", "OK" if bad == 0 else "FAILED")
-sys.exit(0 if bad == 0 else 1)
+    print(f"{done} mutations x {len(ctxs)} contexts ({'small' if pool is small else 'mixed'} pool), {n_ok} decoded, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+print("passes by kernel choice:", n_pass)
+print("FUZZ SOAK", "OK" if bad == 0 and min(n_pass.values()) > 0 else "FAILED")
+sys.exit(0 if bad == 0 and min(n_pass.values()) > 0 else 1)
