@@ -310,6 +310,13 @@ int mzd_batch_download(mzd_ctx *ctx, mzd_dbatch *db, uint8_t *out_host, int32_t 
  * in HBM and every Read moves exactly the bytes it hands out, once, without a host copy of the whole output in between.
  * MZD_ERR_INVALID_ARG when the range leaves the blob. */
 int mzd_batch_read_out(mzd_ctx *ctx, mzd_dbatch *db, uint64_t offset, uint8_t *dst, uint64_t nbytes);
+
+/* A reader that keeps a decoded frame in HBM while its consumer drains it (mzd_batch_read_out) needs the OUTPUT only: this frees
+ * everything else the batch holds on the device -- the compressed input copy, descriptors, tables, sequence records, literal
+ * scratch, block mode's planes (three times the output for a large frame) -- after waiting for the batch's last pass.  The
+ * batch can then be read (mzd_batch_read_out, mzd_batch_download, mzd_batch_frame_layout) and freed, not run again
+ * (MZD_ERR_INVALID_ARG).  ABI 7. */
+int mzd_batch_trim(mzd_ctx *ctx, mzd_dbatch *db);
 /* Device pointers of the resident batch (for callers that keep results in HBM). */
 void *mzd_batch_device_out(mzd_dbatch *db);
 void *mzd_batch_device_status(mzd_dbatch *db);
@@ -395,7 +402,6 @@ int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step);
 /* Which kernels the batch's LAST mzd_batch_run took (the library chooses by the batch's shape; the parity tests assert that the
  * path they mean to cover is the one that ran).  ABI 7. */
 enum {
-    MZD_PASS_REC4 = 1,       /* four-byte sequence records between k_seq_q4 and k_exec_c (no frame above 128 KiB) */
     MZD_PASS_BLOCK_MODE = 2, /* the blocks of a frame side by side (mzd_exec_blk.hip) */
     MZD_PASS_EXEC_C = 4,     /* k_exec_c executed the sequences */
     MZD_PASS_EXEC_B = 8,     /* k_exec_b */

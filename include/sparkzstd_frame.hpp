@@ -362,6 +362,7 @@ class FrameReader {
             if (rc == MZD_OK) rc = mzd_batch_run(ctx_, db_, nullptr);
             if (rc == MZD_OK) rc = mzd_batch_download(ctx_, db_, nullptr, &dst, &len);
             if (rc == MZD_OK) rc = mzd_batch_frame_layout(db_, &off_, nullptr);
+            if (rc == MZD_OK) rc = mzd_batch_trim(ctx_, db_);  // the frame's bytes stay in HBM until they are read, nothing else does
         } else {
             mzd_plan *plan = mzd_plan_create();
             mzd_plan_set_device_tables(plan, 1);
@@ -371,6 +372,7 @@ class FrameReader {
             if (rc == MZD_OK) rc = mzd_batch_run(ctx_, db_, nullptr);
             if (rc == MZD_OK) rc = mzd_batch_download(ctx_, db_, nullptr, &dst, &len);
             if (rc == MZD_OK) off_ = b->frames[0].out_offset;
+            if (rc == MZD_OK) rc = mzd_batch_trim(ctx_, db_);
             mzd_plan_destroy(plan);
         }
         if (rc != MZD_OK) {

@@ -164,6 +164,11 @@ func (x *Context) DecodeFrameResident(frame []byte) (*ResidentFrame, error) {
 	if rc == C.MZD_OK {
 		rc = C.mzd_batch_frame_layout(db, &slab, nil)
 	}
+	if rc == C.MZD_OK {
+		// the frame's bytes stay in HBM until the reader has handed them out; the input copy, the sequence records and block
+		// mode's planes (three times the output) do not
+		rc = C.mzd_batch_trim(x.c, db)
+	}
 	runtime.KeepAlive(frame)
 	if rc != C.MZD_OK {
 		C.mzd_batch_free(x.c, db)

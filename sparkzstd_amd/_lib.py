@@ -25,9 +25,9 @@ EXPORTS = [
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
     "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
-    "mzd_batch_last_pass",
+    "mzd_batch_last_pass", "mzd_batch_trim",
 ]
-MZD_PASS_REC4, MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT = 1, 2, 4, 8, 16
+MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT = 2, 4, 8, 16
 
 MZD_DEBUG_LITERALS, MZD_DEBUG_RECORDS, MZD_DEBUG_TILES, MZD_DEBUG_BLOCKS = 0, 1, 2, 3
 
@@ -169,6 +169,7 @@ def load():
         "mzd_debug_backbits": (i32, [vp, vp, u32, vp, u32, vp, vp]),
         "mzd_debug_force_fixup_bail": (i32, [vp, u32]),
         "mzd_batch_last_pass": (u32, [vp]),
+        "mzd_batch_trim": (i32, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -183,8 +183,15 @@ class ResidentBatch:
             raise MzdError(rc, "mzd_batch_debug_read: " + self.ctx.last_error())
         return arr
 
+    @_ctx_locked
+    def trim(self):
+        """keeps the output, the statuses and the layout; frees every other device allocation of the batch (mzd_batch_trim)"""
+        rc = self.ctx._L.mzd_batch_trim(self.ctx._c, self._h)
+        if rc:
+            raise MzdError(rc, "mzd_batch_trim: " + self.ctx.last_error())
+
     def last_pass(self) -> int:
-        """MZD_PASS_* flags of the kernels the last run() took (_lib.MZD_PASS_REC4 ...)"""
+        """MZD_PASS_* flags of the kernels the last run() took (_lib.MZD_PASS_EXEC_C ...)"""
         return int(self.ctx._L.mzd_batch_last_pass(self._h))
 
     def device_out_ptr(self):
@@ -566,7 +573,7 @@ def decode_frames(frames, ctx: Context = None, device_tables: bool = True, devic
     return outs, sts
 
 
-def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False):
+def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = True, device_plan: bool = False, trim: bool = True):
     """Decodes `frames` and LEAVES the output in HBM: -> (ResidentBatch, slab offset of every frame, out_len of every frame,
     statuses).  The caller reads what it wants with ResidentBatch.read_out and frees the batch -- what a reader does whose
     consumer takes the frame piece by piece (decompression.FrameReader: every Read moves its own bytes over PCIe, once)."""
@@ -584,10 +591,13 @@ def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = Tr
         rb = ctx.upload_frames(blob, off, ln)
         try:
             rb.run()
+            rb.pass_flags = rb.last_pass()
             _, status, out_len = rb.download(want_out=False)
         except Exception:
             rb.free()
             raise
+        if trim:
+            rb.trim()
         return rb, np.asarray(rb.frame_out_offset, dtype=np.uint64), out_len, [int(x) for x in status]
     plan = Plan(device_tables=device_tables)
     try:
@@ -600,10 +610,14 @@ def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = Tr
         rb = ctx.upload(batch)
         try:
             rb.run()
+            last_pass = rb.last_pass()
             _, status, out_len = rb.download(want_out=False)
+            if trim:
+                rb.trim()  # (a slow consumer then pins the frame's bytes in HBM and nothing else: ADVICE r4)
         except Exception:
             rb.free()
             raise
+        rb.pass_flags = last_pass
         rb._batch = None  # (the planner's arrays go with the plan; the resident batch no longer needs them)
         return rb, lay, out_len, [plan_status[i] or int(status[i]) for i in range(n)]
     finally:

@@ -100,10 +100,10 @@ struct mzd_dbatch {
     float fse_build_ms = 0;  // k_fse_build at upload (tables that came as normalised counts)
     uint16_t *d_huf_entries = nullptr;
     uint64_t *d_recs = nullptr;
-    uint32_t *d_recs4 = nullptr;  // the four-byte records (mzd_device.h), allocated by the first pass that takes them
-    uint64_t cap_recs4 = 0;       // ... records it has room for
-    bool last_rec4 = false;       // the last pass left its records there (mzd_batch_debug_read expands them)
     uint32_t last_pass = 0;       // MZD_PASS_* of the last mzd_batch_run
+    hipStream_t run_stream = nullptr;  // ... the stream it ended on, and whether anybody has waited for it since
+    bool run_pending = false;
+    bool trimmed = false;         // mzd_batch_trim: only the output, the statuses and the layout are left
     TileBase *d_tiles = nullptr;
     uint8_t *d_litbuf = nullptr;
     int32_t *d_status = nullptr;
@@ -368,7 +368,6 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_fse_entries);
     (void)hipFree(db->d_huf_entries);
     (void)hipFree(db->d_recs);
-    (void)hipFree(db->d_recs4);
     (void)hipFree(db->d_tiles);
     (void)hipFree(db->d_litbuf);
     (void)hipFree(db->d_status);
@@ -1378,6 +1377,12 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     if (!ctx || !db) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    if (db->trimmed) {
+        ctx->last_error = "mzd_batch_run on a batch that mzd_batch_trim has reduced to its output";
+        return MZD_ERR_INVALID_ARG;
+    }
+    db->run_stream = s;
+    db->run_pending = true;
     const uint32_t exec_threads = ctx->opt.exec_threads ? ctx->opt.exec_threads : 128;
     if (exec_threads % 64 || exec_threads > MZD_EXEC_MAX_THREADS) return MZD_ERR_INVALID_ARG;
     // LDS chunk of the execution kernel: default 8 KiB (up to 16 workgroups per CU); multiple of 1024
@@ -1395,9 +1400,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_pipe, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kPipeFixedLds + kPipeMaxChains * kSeqCellsPerChain * 2));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kQ4FixedLds + kQ4MaxChains * kSeqCellsPerChain * 2));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kQ4FixedLds + kQ4MaxChains * kSeqCellsPerChain * 2));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
@@ -1440,9 +1443,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // 3.60; 8 192 x 1 MiB 25.7 against 27.8 / 28.0; 131 072 x 4 KiB 1.92 against 2.38 / 2.06; the corpus 17.3 against 18.6 / 17.2.
     // k_exec stays for frames of 4 GiB and more and (variant 1) for the parity tests; k_exec_b for block mode and (2) the tests.
     bool exec_c = ctx->opt.exec_variant == 5 || (ctx->opt.exec_variant == 0 && db->n_seq_tasks > 0);
-    for (uint32_t f = 0; exec_c && f < db->n_frames; f++)
-        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_c = false;
     bool exec_b = ctx->opt.exec_variant >= 2 && ctx->opt.exec_variant <= 4;
+    // (both keep frame positions in 32 bits: a frame of 4 GiB or more -- also under a forced variant -- takes k_exec)
+    for (uint32_t f = 0; (exec_c || exec_b) && f < db->n_frames; f++)
+        if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_c = exec_b = false;
     const bool exec_b_serial = exec_b;  // the choice without block mode
     // k_exec_b takes opt.exec_chunk as EXTRA dynamic LDS on top of its 7.7 KiB (a residency cap), k_exec as its LDS chunk: a value that
     // suits k_exec (up to 128 KiB) must not make the k_exec_b launch fail -- clamped to what the default 64 KiB limit leaves
@@ -1526,23 +1530,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             exec_c = ctx->opt.exec_variant == 0;
         }
     }
-    // Four-byte records (round 5, mzd_device.h): k_seq_q4 -> k_exec_c when no frame of the batch is larger than 128 KiB (an offset
-    // then fits 17 bits; BASELINE's configs) -- half the record bytes both kernels move.  Other batches, kernels and block mode
-    // keep the 8-byte records.
-    bool rec4 = q4 && exec_c && !blk && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_NO_REC4");
-    for (uint32_t f = 0; rec4 && f < db->n_frames; f++)
-        if (db->frame_out_cap[f] > kRec4OffLimit) rec4 = false;
-    if (rec4 && db->cap_recs4 < db->n_recs) {
-        if (db->d_recs4) (void)hipFree(db->d_recs4);
-        db->d_recs4 = nullptr;
-        db->cap_recs4 = 0;
-        if (hipMalloc((void **)&db->d_recs4, std::max<uint64_t>(db->n_recs, 1) * 4) == hipSuccess) db->cap_recs4 = db->n_recs;
-        else {
-            (void)hipGetLastError();
-            rec4 = false;
-        }
-    }
-    db->last_rec4 = rec4;
     const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
     // Heterogeneous batches: the Huffman kernel runs on the second stream BESIDE the sequence stage -- that stage is bound by
     // its longest chain there (real data: 42 k sequences = 5.9 ms of a 7.5 ms kernel with most CUs idle), the Huffman
@@ -1584,7 +1571,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         }
     }
     const bool split = fA < db->n_frames;
-    db->last_pass = (rec4 ? MZD_PASS_REC4 : 0u) | (blk ? MZD_PASS_BLOCK_MODE : 0u) | (exec_c ? MZD_PASS_EXEC_C : 0u) | (exec_b ? MZD_PASS_EXEC_B : 0u) |
+    db->last_pass = (blk ? MZD_PASS_BLOCK_MODE : 0u) | (exec_c ? MZD_PASS_EXEC_C : 0u) | (exec_b ? MZD_PASS_EXEC_B : 0u) |
                     (split ? MZD_PASS_SPLIT : 0u);
 
     hipEvent_t *ev = nullptr;
@@ -1611,14 +1598,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             const uint64_t cus = (uint64_t)std::max(ctx->num_cus, 1) * wg_per_cu;  // workgroups resident at a time
             const uint64_t rounds = (count + cus * nch - 1) / (cus * nch);
             const uint32_t per_wg = rounds > 1 || seq_pack ? nch : (uint32_t)std::min<uint64_t>(nch, (count + cus - 1) / cus);
-            if (q4 && rec4)
-                k_seq_q4<true><<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
+            if (q4)
+                k_seq_q4<<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,
-                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2], db->d_recs4);
-            else if (q4)
-                k_seq_q4<false><<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
-                    db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,
-                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2], nullptr);
+                    db->seq_cells[0], db->seq_cells[1], db->seq_cells[2]);
             else
                 k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base);
@@ -1776,11 +1759,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (exec_c) {
             size_t xc_extra_lds = 0;  // experiment: extra dynamic LDS per frame = fewer frames in flight per CU
             if (const char *e = exp_env("MZD_EXP_XC_LDS")) xc_extra_lds = (size_t)std::max(0, atoi(e));
-            if (rec4)
-                k_exec_c<false, true><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
-                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{}, db->d_recs4);
-            else
-                k_exec_c<false><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+            k_exec_c<false><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
                                                                db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
@@ -2037,8 +2016,63 @@ int mzd_batch_read_out(mzd_ctx *ctx, mzd_dbatch *db, uint64_t offset, uint8_t *d
 {
     if (!ctx || !db || (nbytes && !dst) || offset > db->out_size || nbytes > db->out_size - offset) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    if (nbytes) HIP_TRY(ctx, hipMemcpy(dst, db->d_out + offset, nbytes, hipMemcpyDeviceToHost));
+    // (the batch's own pass, once -- not the device: a reader that drains a frame in many Reads must not stall the other
+    // contexts and threads of the process with every one of them; ADVICE r4.  The pass ends on the stream it was given: the
+    // library's second stream joins it.)
+    if (db->run_pending) {
+        HIP_TRY(ctx, hipStreamSynchronize(db->run_stream));
+        db->run_pending = false;
+    }
+    if (nbytes) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, db->d_out + offset, nbytes, hipMemcpyDeviceToHost, ctx->stream2));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    }
+    return MZD_OK;
+}
+
+int mzd_batch_trim(mzd_ctx *ctx, mzd_dbatch *db)
+{
+    if (!ctx || !db) return MZD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (db->run_pending) {
+        HIP_TRY(ctx, hipStreamSynchronize(db->run_stream));
+        db->run_pending = false;
+    }
+    auto drop = [](auto *&p) {
+        (void)hipFree((void *)p);
+        p = nullptr;
+    };
+    drop(db->d_in_alloc);
+    db->d_in = nullptr;
+    drop(db->d_blocks);
+    drop(db->d_sums);
+    drop(db->d_huf_tasks);
+    drop(db->d_seq_tasks);
+    drop(db->d_fse_entries);
+    drop(db->d_huf_entries);
+    drop(db->d_recs);
+    drop(db->d_tiles);
+    drop(db->d_litbuf);
+    drop(db->d_frame_order);
+    drop(db->d_jobs);
+    drop(db->d_heads);
+    drop(db->d_bframes);
+    drop(db->d_fixdone);
+    drop(db->d_walk);
+    drop(db->d_planes);
+    drop(db->d_pat);
+    {
+        DevCaps keep{};
+        keep.out = db->cap.out;
+        keep.frames = db->cap.frames;
+        keep.status = db->cap.status;
+        keep.out_len = db->cap.out_len;
+        db->cap = keep;
+    }
+    db->cap_jobs = db->cap_heads = db->cap_bframes = db->cap_planes = db->cap_pat = db->cap_fixdone = db->cap_walk = 0;
+    db->n_recs = db->n_tiles = db->lit_bytes = 0;
+    free_parse_temps(db->tmp);
+    db->trimmed = true;
     return MZD_OK;
 }
 
@@ -2161,17 +2195,9 @@ int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset
     case MZD_DEBUG_BLOCKS: base = db->d_blocks; size = (uint64_t)db->n_blocks * sizeof(DBlock); break;
     default: return MZD_ERR_INVALID_ARG;
     }
-    if (offset > size || bytes > size - offset) return MZD_ERR_INVALID_ARG;
+    if (db->trimmed || offset > size || bytes > size - offset) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
-    if (db->last_rec4 && (what == MZD_DEBUG_RECORDS || what == MZD_DEBUG_TILES) && db->n_recs) {
-        // the last pass left four-byte records (and no tile bases, which only k_exec reads): what the caller sees are the 8-byte
-        // records they stand for, and the tile bases these give
-        k_rec4_expand<<<(uint32_t)((db->n_recs + 255) / 256), 256, 0, ctx->stream>>>(db->d_recs4, db->d_recs, db->n_recs);
-        if (db->n_blocks) k_tiles_from_recs<<<(db->n_blocks + 63) / 64, 64, 0, ctx->stream>>>(db->d_blocks, db->d_recs, db->d_tiles, db->n_blocks);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        db->last_rec4 = false;
-    }
     if (bytes) HIP_TRY(ctx, hipMemcpy(dst, (const uint8_t *)base + offset, bytes, hipMemcpyDeviceToHost));
     return MZD_OK;
 }

@@ -171,15 +171,12 @@ __device__ __noinline__ uint2 xc_resolve_in_pass(uint32_t va, uint32_t vb, int r
 // with sequences, from a block flagged kBjHead to the next; a Raw / RLE / literal-only block is a job of its own), `out_blob` is
 // the plane of this pass, and whatever lies before the segment's start S is read from the pass's pattern `bk.pat`: the ring is
 // preloaded with it, staged and far reads below S go to it.
-// REC4 (round 5): the records are the four-byte words of `recs4` (mzd_device.h; what k_seq_q4<true> leaves for batches of frames
-// of at most 128 KiB): half the record bytes of a tile; the rare sequence that does not fit (word 0) is read from `recs`.
-template <bool BM, bool REC4 = false>
+template <bool BM>
 __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
                                                   int32_t *frame_status, uint64_t *frame_out_len,
-                                                  const uint32_t *__restrict__ order, uint32_t first, XbBlk bk,
-                                                  const uint32_t *__restrict__ recs4 = nullptr)
+                                                  const uint32_t *__restrict__ order, uint32_t first, XbBlk bk)
 {
     __shared__ __attribute__((aligned(128))) XcLds sh;
     const uint8_t *const lds = (const uint8_t *)&sh;
@@ -301,7 +298,6 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
         const uint32_t nps = b.n_seq + (rest ? 1u : 0u);
         const uint32_t ntiles = (nps + 63) >> 6;
         const uint64_t *brec = recs + b.rec_off;
-        const uint32_t *brec4 = recs4 + b.rec_off;
 
         struct Tile {
             uint32_t LL, ML, lstart, mstart, lsrc;
@@ -320,20 +316,10 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
         auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
         auto load_recs = [&](uint32_t tile) -> uint64_t {
             const uint32_t si = min(tile * 64 + (uint32_t)lane, b.n_seq - 1);  // (clamped: no exec mask around the load; n_seq > 0)
-            if (REC4) return (uint64_t)brec4[si];
             return ld64_once<kXcNtRec>(brec + si);
         };
         // tile t from its records; false: an offset beyond the produced data (ringbuffer.go:206-214)
         auto load_tile = [&](Tile &T, uint64_t rec, uint32_t t, uint32_t tileStart, uint32_t litRun) -> bool {
-            if (REC4) {
-                // the four-byte word; 0: the sequence's 8-byte record is in the other array (rare: this load is waited for here)
-                const uint32_t w = (uint32_t)rec;
-                rec = (uint64_t)(w & kRec4LlMax) | ((uint64_t)((w >> kRec4MlShift) & kRec4MlMax) << kRecMlShift) |
-                      ((uint64_t)(w >> kRec4OffShift) << kRecOffShift);
-                if (wave_any(w == 0)) {
-                    if (w == 0) rec = brec[min(t * 64 + (uint32_t)lane, b.n_seq - 1)];
-                }
-            }
             uint32_t LL = (uint32_t)rec & kRecLlMask;
             uint32_t ML = (uint32_t)(rec >> kRecMlShift) & kRecMlMask;
             uint32_t offf = (uint32_t)(rec >> kRecOffShift) & kRecOffMask;
@@ -413,19 +399,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             // all 64 lanes loading, idle ones from one hot line, TA_TA_BUSY went from 46 % to 81 % of the kernel's time)
             N.sv = N.sv2 = U128U{0, 0, 0, 0};
 #ifndef MZD_ABL_XC_NOSTAGE
-#ifdef MZD_XC_ST8
-            // (a match of up to 8 bytes is staged with an 8-byte load: what a staged match costs is the 32-byte sectors its load
-            // touches -- 1.22 on average for 8 bytes at a random address, 1.47 for 16 -- and 58 % of the far matches of text are that short)
-            const bool st8 = stg && T.ML <= 8;
-            if (st8) {
-                const uint64_t v = ld64u_once<kXcNtStage>(rb + q0);
-                N.sv.x = (uint32_t)v;
-                N.sv.y = (uint32_t)(v >> 32);
-            }
-            if (stg && !st8) N.sv = ld128u_once<kXcNtStage>(rb + q0);
-#else
             if (stg) N.sv = ld128u_once<kXcNtStage>(rb + q0);
-#endif
             if (stg && T.ML > 16) N.sv2 = ld128u_once<kXcNtStage>(rb + q0 + 16);
 #endif
             // the stretch's literals: [la, lb) of the block's literals (lb <= lit_regen)

@@ -114,16 +114,11 @@ __device__ __forceinline__ uint32_t q4_history_step(uint32_t hi, uint32_t &h0, u
     return rh;
 }
 
-// REC4 (round 5): the records leave as four-byte words (mzd_device.h) in `recs4`, the 8-byte record only of the sequences that do
-// not fit; the running sums move from stage C2 to the two stage-B wavefronts (which have the lengths in registers anyway; their
-// partial sums meet after the last barrier), tile bases are not written (k_exec_c does not read them): stage C2, which shares
-// its SIMD with a chain wavefront, is left with one 16-byte store per batch of four sequences.
-template <bool REC4>
 __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                                        uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                                        uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
                                                        BlockSum *sums, uint32_t nch, uint64_t in_base, uint32_t cells_ll,
-                                                       uint32_t cells_ml, uint32_t cells_of, uint32_t *__restrict__ recs4)
+                                                       uint32_t cells_ml, uint32_t cells_of)
 {
     // cells_ll / cells_ml / cells_of: the largest LL / ML / OF table of the batch (powers of two).  A chain's slot in LDS is
     // exactly that wide -- 1280 cells when the tables have the format's largest accuracy logs (9 / 9 / 8), 160 when they
@@ -745,8 +740,6 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         const uint32_t par = (uint32_t)lw - 4u;
         const int col = min(lane, kQ4Cols - 1);  // lanes 56..63 have no column: they shadow the last one
         uint32_t head_seen = 0, tail_seen = 0;
-        const uint32_t my_n = has ? t.n_seq : 0u;
-        uint32_t litPos = 0, outPos = 0, err_size = 0;  // REC4: this wavefront's share of the block's running sums
 #ifdef MZD_Q4_PROF
         long long prof_in = 0, prof_out = 0, prof_t0 = clock64();
 #endif
@@ -796,27 +789,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 const uint32_t llx = __builtin_amdgcn_ubfe(Y, 32u - exM - exL, exL);
                 const uint32_t ofv = min((1u << exO) + ofx, kRecOffSymbolic);  // exO <= 31: no wrap
                 const uint32_t llv = (cl & 0xFFFFFF) + llx;
-                if (!REC4) {
-                    const uint64_t v = (uint64_t)llv | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
-                                       ((uint64_t)q4_offset_code(ofv, llv) << kRecOffShift);
-                    q[u] = (kk & 0x8000u) ? T[u] : v;
-                } else {
-                    // the lengths and the offset code of the sequence, whichever kind of step made it
-                    const bool gen = (kk & 0x8000u) != 0;
-                    const uint32_t LL = gen ? (uint32_t)T[u] & kRecLlMask : llv;
-                    const uint32_t ML = gen ? (uint32_t)(T[u] >> kRecMlShift) & kRecMlMask : (cm & 0xFFFFFF) + mlx;
-                    const uint32_t code = gen ? (uint32_t)(T[u] >> kRecOffShift) : q4_offset_code(ofv, llv);
-                    const bool act = j0 + (uint32_t)u < my_n;  // (a chain that has ended hands on dummies)
-                    litPos += act ? LL : 0u;
-                    outPos += act ? LL + ML : 0u;
-                    // the low word: the lengths as the four-byte record has them, or 0 -- then the 8-byte record's low dword goes to
-                    // memory from here (stage C2 adds the high one, which stage C1 finishes)
-                    const bool fits = ((LL >> 7) | (ML >> 8)) == 0;
-                    if (act && !fits) ((uint32_t *)(recs + t.rec_off + j0 + u))[0] = LL | (ML << kRecMlShift);
-                    q[u] = (uint64_t)(fits ? LL | (ML << kRec4MlShift) : 0u) | ((uint64_t)((ML >> 15) | (code << 3)) << 32);
-                }
+                const uint64_t v = (uint64_t)llv | ((uint64_t)((cm & 0xFFFFFF) + mlx) << kRecMlShift) |
+                                   ((uint64_t)q4_offset_code(ofv, llv) << kRecOffShift);
+                q[u] = (kk & 0x8000u) ? T[u] : v;
             }
-            if (REC4) err_size |= outPos > kBlockMax;  // (a PARTIAL sum beyond the limit: the whole is too; four steps add < 2^21: no wrap)
 #endif
 #ifdef MZD_Q4_PROF
             const long long w1 = clock64();
@@ -834,11 +810,6 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             for (int u = 0; u < kPipeBatch; u++) shs->q2[(j0 + u) % kPipeDepth][col] = q[u];
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->head2[par], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (REC4) {
-            // (the A -> B queue is idle: stage A has produced everything and this wavefront's slots -- [4 par, 4 par + 4) -- are read)
-            shs->q1w[4 * par][col] = (uint64_t)litPos | ((uint64_t)outPos << 32);
-            shs->q1c[4 * par][col][0] = (uint16_t)err_size;
         }
 #ifdef MZD_Q4_PROF
         if (blockIdx.x == 0 && lane == 0) printf("B%u: cycles %lld wait_in %lld wait_out %lld (steps %u)\n", par, clock64() - prof_t0, prof_in, prof_out, nmax);
@@ -937,7 +908,6 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         // record streams)
         const int col = min(lane, kQ4Cols - 1);
         uint64_t *myrec = recs + t.rec_off;
-        uint32_t *myrec4 = recs4 + t.rec_off;
         TileBase *mytile = tiles + t.tile_off;
         const uint32_t my_n = has ? t.n_seq : 0u;
         uint32_t litPos = 0, outPos = 0, err_size = 0;
@@ -965,44 +935,6 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             asm volatile("" ::: "memory");
             __hip_atomic_store(&shs->tail2, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef MZD_EXP_FAST_BC
-            if (REC4) {
-                // the four-byte records: lengths from stage B's low word, the offset stage C1 resolved (hi = ML bits 15..17 | offset
-                // << 3: off << 15 is hi << 12 when the lengths fit)
-                uint32_t w[kPipeBatch];
-                uint32_t lo_min = 0xFFFFFFFFu, hi_max = 0;
-#pragma unroll
-                for (int u = 0; u < kPipeBatch; u++) {
-                    const uint32_t lo = (uint32_t)rr[u], hi = (uint32_t)(rr[u] >> 32);
-                    w[u] = lo | (hi << (kRec4OffShift - 3));
-                    lo_min = min(lo_min, lo);
-                    hi_max = max(hi_max, hi);
-                }
-                if (lo_min == 0 || hi_max >= (kRec4OffLimit << 3)) {
-                    // a sequence of this batch does not fit: word 0, and the 8-byte record (stage B has stored the low dword of one
-                    // whose LENGTHS do not fit; one whose offset does not is written whole)
-#pragma unroll
-                    for (int u = 0; u < kPipeBatch; u++) {
-                        const uint32_t lo = (uint32_t)rr[u], hi = (uint32_t)(rr[u] >> 32);
-                        if (j0 + u >= my_n) continue;
-                        if (lo == 0) {
-                            ((uint32_t *)(myrec + j0 + u))[1] = hi;
-                            w[u] = 0;
-                        } else if (hi >= (kRec4OffLimit << 3)) {
-                            myrec[j0 + u] = (uint64_t)((lo & kRec4LlMax) | ((lo >> kRec4MlShift) << kRecMlShift)) | ((uint64_t)hi << 32);
-                            w[u] = 0;
-                        }
-                    }
-                }
-                if (j0 + (uint32_t)kPipeBatch <= my_n) {
-                    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-                    *(u32x4a *)(myrec4 + j0) = u32x4a{w[0], w[1], w[2], w[3]};
-                } else {
-#pragma unroll
-                    for (int u = 0; u < kPipeBatch; u++)
-                        if (j0 + u < my_n) myrec4[j0 + u] = w[u];
-                }
-                continue;
-            }
             if ((j0 & 63) == 0 && j0 < my_n) mytile[j0 >> 6] = TileBase{litPos, outPos};
             if (j0 + (uint32_t)kPipeBatch <= my_n) {
 #pragma unroll
@@ -1030,14 +962,12 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_Q4_PROF
         if (blockIdx.x == 0 && lane == 0) printf("C2: cycles %lld wait_in %lld\n", clock64() - prof_t0, prof_in);
 #endif
-        if (!REC4) {
-            if (has && t.n_seq > 0) {
-                BlockSum *bs = &sums[t.block];
-                bs->lit_total = litPos;
-                bs->out_total = outPos;
-            }
-            shs->stC2[lane] = err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
+        if (has && t.n_seq > 0) {
+            BlockSum *bs = &sums[t.block];
+            bs->lit_total = litPos;
+            bs->out_total = outPos;
         }
+        shs->stC2[lane] = err_size ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
     } else {
         // ================= wave P: the chains' bitstreams, ahead of stage A (as k_seq_pipe) =================
         const uint8_t *inb = in - MZD_IN_PAD;
@@ -1098,44 +1028,8 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     if (lw == 6 && has && t.n_seq > 0) {
         int st = shs->stA[lane];
         if (st == MZD_OK) st = shs->stC[lane];
-        if (REC4) {
-            // the block's totals: the two stage-B wavefronts' shares (lane = chain = their column)
-            const uint64_t p0 = shs->q1w[0][lane], p1 = shs->q1w[4][lane];
-            const uint32_t lit = (uint32_t)p0 + (uint32_t)p1, outp = (uint32_t)(p0 >> 32) + (uint32_t)(p1 >> 32);
-            const bool bad = shs->q1c[0][lane][0] != 0 || shs->q1c[4][lane][0] != 0 || outp > kBlockMax;
-            sums[t.block].lit_total = lit;
-            sums[t.block].out_total = outp;
-            shs->stC2[lane] = bad ? MZD_ERR_CORRUPT_SIZES : MZD_OK;
-        }
         if (st == MZD_OK) st = shs->stC2[lane];
         if (st != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, st);
-    }
-}
-
-// ---- debugging / tests (mzd_batch_debug_read): the 8-byte records that the four-byte words of a pass stand for, and the tile bases
-// of a batch from its records (what stage C2 writes when the execution kernel is k_exec)
-__global__ void k_rec4_expand(const uint32_t *__restrict__ recs4, uint64_t *__restrict__ recs, uint64_t n)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t w = recs4[i];
-    if (w)
-        recs[i] = (uint64_t)(w & kRec4LlMax) | ((uint64_t)((w >> kRec4MlShift) & kRec4MlMax) << kRecMlShift) |
-                  ((uint64_t)(w >> kRec4OffShift) << kRecOffShift);
-}
-__global__ void k_tiles_from_recs(const DBlock *__restrict__ blocks, const uint64_t *__restrict__ recs, TileBase *__restrict__ tiles, uint32_t n_blocks)
-{
-    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bi >= n_blocks) return;
-    const DBlock b = blocks[bi];
-    if (b.type != MZD_BLOCK_COMPRESSED) return;
-    uint32_t lit = 0, outp = 0;
-    for (uint32_t j = 0; j < b.n_seq; j++) {
-        if ((j & 63) == 0) tiles[b.tile_off + (j >> 6)] = TileBase{lit, outp};
-        const uint64_t r = recs[b.rec_off + j];
-        const uint32_t LL = (uint32_t)r & kRecLlMask, ML = (uint32_t)(r >> kRecMlShift) & kRecMlMask;
-        lit += LL;
-        outp += LL + ML;
     }
 }
 

@@ -110,16 +110,12 @@ def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle,
     n = _check_stage_boundaries(c, corpus, oracle)
     assert n["blocks"] > 1500 and n["seqs"] > 1000000 and n["lits"] > 2000000
     assert n["symbolic"] > 0 or seq_variant == 1  # later blocks of a frame carry repeat offsets relative to the block start
-    assert not n["pass"] & _lib.MZD_PASS_REC4  # (the corpus has frames of up to 1 MiB: 8-byte records)
 
 
-def test_four_byte_records_equal_the_oracle_trace(corpus, oracle):
-    """Batches whose frames are all at most 128 KiB -- BASELINE's configs -- hand their sequences from k_seq_q4 to k_exec_c as
-    FOUR-byte records (LL:7 | ML:8 | offset:17; mzd_device.h), the few that do not fit as 8-byte ones.  The same check as above
-    on such a batch: the corpus's frames of up to 128 KiB (real data: literal runs of 128 and more, matches of 256 and more,
-    multi-block frames whose later blocks start with symbolic repeat offsets -- every way a sequence can fail to fit) beside
-    text-like synthetic frames; the records are compared AFTER expansion to the 8-byte form, value for value, and the frames'
-    bytes with the oracle's."""
+def test_stage_boundaries_of_a_batch_of_small_frames(corpus, oracle):
+    """The same check on a batch shaped like BASELINE's configs -- no frame above 128 KiB, so the library's own choices are the
+    split pass's (k_huf first, k_seq_q4, k_exec_c): the corpus's frames of up to 128 KiB (real data: long literal runs, long
+    matches, multi-block frames whose later blocks start with symbolic repeat offsets) beside text-like synthetic frames."""
     from tools import synth_binding as sb
     c = z.Context(0)
     small = [it for it in corpus if it[2] <= 131072]
@@ -139,8 +135,8 @@ def test_four_byte_records_equal_the_oracle_trace(corpus, oracle):
     plan.close()
     assert len(items) > 40
     n = _check_stage_boundaries(c, items, oracle)
-    assert n["pass"] & _lib.MZD_PASS_REC4 and n["pass"] & _lib.MZD_PASS_EXEC_C
-    assert n["seqs"] > 100000 and n["escapes"] > 100 and n["symbolic"] > 0, n
+    assert n["pass"] & _lib.MZD_PASS_EXEC_C and not n["pass"] & _lib.MZD_PASS_BLOCK_MODE
+    assert n["seqs"] > 100000 and n["long"] > 100 and n["symbolic"] > 0, n
 
 
 def _check_stage_boundaries(c, corpus, oracle):
@@ -167,7 +163,7 @@ def _check_stage_boundaries(c, corpus, oracle):
         lits = rb.debug_read(_lib.MZD_DEBUG_LITERALS, np.uint8, 0, lit_bytes)
         tiles = rb.debug_read(_lib.MZD_DEBUG_TILES, np.uint32, 0, 2 * sum((int(d.n_seq) + 63) // 64 for d in dblocks))
         blob = bytes(np.ctypeslib.as_array(ctypes.cast(b.in_, ctypes.POINTER(ctypes.c_uint8)), shape=(b.in_size,)))
-        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = n_in_place = n_escapes = 0
+        n_blocks_seen = n_seq_seen = n_lit_seen = n_symbolic = n_in_place = n_long = 0
         for fi, f in enumerate(frames):
             rc, ref, _, tr = oracle.decode_frame(f, cap=corpus[fi][2] + 64, want_trace=True)
             assert rc == 0
@@ -212,7 +208,7 @@ def _check_stage_boundaries(c, corpus, oracle):
                         u = g_of & 0x0FFFFFFF
                         g_of = h0[u & 3] - (u >> 2)
                         n_symbolic += 1
-                    n_escapes += 1 if (ll > 127 or ml > 255 or g_of >= (1 << 17)) else 0  # would not fit a four-byte record
+                    n_long += 1 if (ll > 127 or ml > 255 or g_of >= (1 << 17)) else 0  # long literal runs / matches, far offsets
                     assert (g_ll, g_ml, g_of) == (ll, ml, resolved), (corpus[fi][0], k, j)
                     assert _next_offset(hist, raw, ll) == resolved  # the test's history agrees with the oracle's
                     if j % 64 == 0:
@@ -224,7 +220,7 @@ def _check_stage_boundaries(c, corpus, oracle):
                 n_seq_seen += ns
             assert lit_at == len(tr["literals"]) and seq_at == len(tr["seqs"])
         assert n_seq_seen == n_rec
-        return {"blocks": n_blocks_seen, "seqs": n_seq_seen, "lits": n_lit_seen, "symbolic": n_symbolic, "escapes": n_escapes, "pass": last_pass}
+        return {"blocks": n_blocks_seen, "seqs": n_seq_seen, "lits": n_lit_seen, "symbolic": n_symbolic, "long": n_long, "pass": last_pass}
     finally:
         rb.free()
         plan.close()

@@ -5,8 +5,8 @@ be one the oracle decodes to the same bytes; a frame the oracle rejects must car
 
 Two pools of base frames, batches alternate between them:
   small   frames that regenerate at most 128 KiB (what BASELINE's configs are made of): the library's own choice for such a
-          batch is k_seq_q4 with FOUR-byte records into k_exec_c (round 5); contexts: the default, k_seq / k_seq_pipe with
-          k_exec_c's 8-byte records (exec_variant 5), k_exec_b, k_exec
+          batch is k_huf first, k_seq_q4, k_exec_c; contexts: the default, k_seq / k_seq_pipe with k_exec_c (exec_variant 5),
+          k_exec_b, k_exec
   mixed   everything, frames of up to 1.2 MiB in several blocks: 8-byte records, the serial walk and block mode (exec_variant
           3, 4; 4 also with mzd_debug_force_fixup_bail: the rescue launch of the fix-up walk on damaged input)
 Both pools hold PERIODIC content too (runs that feed themselves at periods of 1 to 40 bytes: the in-pass resolver of
@@ -79,23 +79,21 @@ def decode(frames, c):
     """z.decode_frames, and which kernels the pass took (ResidentBatch.last_pass)"""
     rb, lay, out_len, sts = z.api.decode_frames_resident(frames, c)
     try:
-        lp = rb.last_pass()
+        lp = rb.pass_flags
         out, _, _ = rb.download()
     finally:
         rb.free()
     return [out[int(lay[i]):int(lay[i]) + int(out_len[i])].tobytes() if sts[i] == 0 else None for i in range(len(frames))], sts, lp
 
 
-n_pass = {"four-byte records": 0, "block mode": 0, "k_exec_c": 0, "k_exec_b": 0}
+n_pass = {"block mode": 0, "k_exec_c": 0, "k_exec_b": 0}
 bad = done = n_ok = n_batches = 0
 t0 = time.time()
 while done < n_mut:
     pool, ctxs = (small, ctx_small) if n_batches % 2 == 0 else (mixed, ctx_mixed)
     n_batches += 1
     frames = []
-    # (every other batch of the small pool leaves the frame headers alone: a damaged window descriptor or content size that
-    # declares a frame of more than 128 KiB takes the whole batch out of the four-byte-record path, which is to be soaked too)
-    lo = 14 if pool is small and n_batches % 4 == 1 else 5
+    lo = 5
     for _ in range(min(1000, n_mut - done)):
         b = bytearray(pool[int(rng.integers(len(pool)))])
         r = rng.random()
@@ -110,8 +108,7 @@ while done < n_mut:
         if c is bail_ctx:
             assert L.mzd_debug_force_fixup_bail(c._c, int(rng.integers(1, 6))) == 0
         outs, sts, lp = decode(frames, c)
-        for k, bit in (("four-byte records", _lib.MZD_PASS_REC4), ("block mode", _lib.MZD_PASS_BLOCK_MODE), ("k_exec_c", _lib.MZD_PASS_EXEC_C),
-                       ("k_exec_b", _lib.MZD_PASS_EXEC_B)):
+        for k, bit in (("block mode", _lib.MZD_PASS_BLOCK_MODE), ("k_exec_c", _lib.MZD_PASS_EXEC_C), ("k_exec_b", _lib.MZD_PASS_EXEC_B)):
             n_pass[k] += 1 if lp & bit else 0
         for f, o, s, (rc, ref, _, _) in zip(frames, outs, sts, want):
             if s == 0:
