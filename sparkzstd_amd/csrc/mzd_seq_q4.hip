@@ -25,7 +25,11 @@ namespace mzd {
 
 constexpr int kQ4ChainsPerWave = 14;  // quads 14 and 15 of a chain wavefront are parked
 constexpr int kQ4ChainWaves = 4;
-constexpr int kQ4Threads = 64 * (kQ4ChainWaves + 5);  // + stage B (two wavefronts, alternate batches), C1, C2, P
+#ifndef MZD_Q4_BWAVES
+#define MZD_Q4_BWAVES 3
+#endif
+constexpr int kQ4BWaves = MZD_Q4_BWAVES;  // stage-B wavefronts: they take the batches of four steps in turn
+constexpr int kQ4Threads = 64 * (kQ4ChainWaves + 3 + kQ4BWaves);  // + stage B, C1, C2, P
 constexpr int kQ4Cols = 57;  // queue columns: one per chain (<= 56) + the column parked quads write to (56)
 
 struct Q4Shared {
@@ -140,10 +144,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     // share the queue), so the busiest SIMD sets everybody's step.  Measured per step: P beside chain wavefront 0 and C2 as
     // the third wavefront of that SIMD, B / B / C1 beside the others: 307 cycles; in the order of the stages: 316.
 #ifndef MZD_Q4_ROLES
-#define MZD_Q4_ROLES {8, 4, 5, 6, 7}
+#define MZD_Q4_ROLES {8, 4, 5, 6, 7, 9}
 #endif
     const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4..8: the stages, see above
-    constexpr int kRoles[5] = MZD_Q4_ROLES;
+    constexpr int kRoles[6] = MZD_Q4_ROLES;  // (9: the third stage-B wavefront, when there is one)
     const int lw = wave < kQ4ChainWaves ? wave : kRoles[wave - kQ4ChainWaves];
     const bool chainw = wave < kQ4ChainWaves;
     // the chain this lane works for: chain wavefronts 4 lanes per chain, the others one lane per chain
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #ifdef MZD_ABL_Q4_NOW2
 #define MZD_Q4_W2 "s_nop 0\n\t"
 #else
-#define MZD_Q4_W2 "s_waitcnt lgkmcnt(0)\n\t"
+#define MZD_Q4_W2 "s_waitcnt lgkmcnt(2)\n\t"
 #endif
 #ifdef MZD_ABL_Q4_ALIGNED  /* ablations: timing experiments only, wrong results */
 #define MZD_Q4_RMASK "120"
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     "ds_write_b32 %[chan4], v70 offset:%[o_prog]\n\t"                                                       \
     "s_cbranch_vccz L_q4_go" TAG "_%=\n\t"                                                                  \
     Q4_RINGCHK(TAG)
-// On entry: this step's cell is on its way into v69 (requested by the step before, or the prologue), DM gets the
+// On entry: this step's cell is on its way into CELL (requested by the step before, or the prologue), DM gets the
 // 8 bytes at the cursor (read at the end of the step before), v85 holds the limit.  DL: where the next step's window
 // goes.  LIMIT: the instruction(s) that finish the next step's limit in v85 (from 64 - k).
 // Round 5 (39 -> 35 instructions): the cursor is ONE running bit count c (c >> 3 bytes below W0, a multiple of 128: the ring index
@@ -534,42 +538,46 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 // as it is.  The bits that remain are R0 - c: part of the limit only in the loop variant for the chains' last steps (LIMIT) --
 // a chain that runs out of bits earlier (a damaged stream: its status is an error whatever it decodes) is caught when the
 // loop is left.
-#define Q4_STEP(DM, DL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                              \
+#define Q4_STEP(DM, DL, CELL, NCELL, SA, SB, TAG, QC, QW, OUT, RLOW, LIMIT)                                 \
     "L_q4_go" TAG "_%=:\n\t"                                                                                \
-    MZD_Q4_W1                                       /* the cell (behind it: two queue writes, the ring read) */ \
-    "v_and_b32 v77, 0x3ff, v69\n\t"               /* next */                                              \
-    "v_lshrrev_b32 v76, %[shr], v69\n\t"          /* code field */                                        \
-    "v_ffbh_u32 v78, v77\n\t"                                                                             \
+    MZD_Q4_W1                                       /* the cell (behind it: the ring read, two queue writes) */ \
+    /* What a step costs is what stands between a cell's arrival and the request for the next one (round 5: 20 -> 17 instructions;  \
+       whatever can wait -- the total, the go test, the queue entry, the cursor -- runs behind that read), in an order that   \
+       gives every DPP read its two instructions' distance from the write of its source without fillers. */                 \
+    "v_lshrrev_b32 v76, %[shr], " CELL "\n\t"      /* code field */                                        \
     "v_sub_u32_e64 v76, v76, %[Kc] clamp\n\t"     /* ex */                                                \
+    "v_and_b32 v77, 0x3ff, " CELL "\n\t"           /* next */                                              \
+    "v_ffbh_u32 v78, v77\n\t"                                                                             \
+    "v_add_u32_dpp v79, v76, v76 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
     "v_min_u32 v78, 0x4000000, v78\n\t"           /* escape (next = 0): capped, the sums cannot wrap */   \
     "v_sub_u32 v78, v78, %[nbK]\n\t"              /* nb */                                                \
-    "v_add_u32_dpp v79, v76, v76 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
-    "v_cndmask_b32_e64 v88, v69, %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k */  \
-    MZD_Q4_W2                                       /* the window */                                        \
-    "v_add_u32_dpp v80, v78, v78 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
     "v_add_u32_dpp v81, v79, v79 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" /* o3 */            \
     "v_add_u32 v86, v81, %[k]\n\t"                /* k + o3 */                                            \
-    "v_add_u32_dpp v82, v78, v80 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
+    MZD_Q4_W2                                       /* the window */                                        \
     "v_lshlrev_b64 v[74:75], v86, " DM "\n\t"    /* X = W << (k + o3): the state fields from bit 63 (the fourth lane's is the real one) */ \
-    "v_sub_u32 v83, 0, v82\n\t"                   /* -P */                                                \
-    "v_add_u32_dpp v87, v82, v81 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
+    "v_add_u32_dpp v80, v78, v78 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" /* nb + nb[lane - 1] */ \
+    "v_add_u32_dpp v82, v78, v80 quad_perm:[3,3,0,3] row_mask:0xf bank_mask:0xf\n\t" /* P: running sum of nb */ \
     "v_mov_b32_dpp v84, v75 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t" /* the fourth lane's X, high dword */ \
+    "v_sub_u32 v83, 0, v82\n\t"                   /* -P */                                                \
     "v_bfe_u32 v84, v84, v83, v78\n\t"          /* the lane's state field */                            \
     "v_lshl_add_u32 %[s" SB "], v77, v78, v84\n\t" /* new state, in the OTHER register set */            \
-    "v_cmp_ge_u32 vcc, v87, v85\n\t"              /* NOT go: the chain needs the general step (the same in its four lanes) */ \
     "v_lshl_add_u32 v66, %[s" SB "], 1, %[cb]\n\t"                                                         \
-    "ds_read_u16 v69, v66\n\t"                    /* the NEXT step's cell; the rest of the step runs behind it */ \
-    MZD_Q4_QWR("ds_write_b16 %[qca], v88 offset:" QC "\n\t")                                               \
+    "ds_read_u16 " NCELL ", v66\n\t"              /* the NEXT step's cell (the cells alternate between two registers: this step's is   \
+                                                       still read below); the rest of the step runs behind the read */ \
+    "v_add_u32_dpp v87, v82, v81 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" /* total */         \
+    "v_cmp_ge_u32 vcc, v87, v85\n\t"              /* NOT go: the chain needs the general step (the same in its four lanes) */ \
     "v_add_u32 %[c], %[c], v87\n\t"               /* (unconditionally: see above) */                      \
-    "v_and_b32 %[k], 7, %[c]\n\t"                                                                           \
     "v_bfe_u32 v71, %[c], 3, 7\n\t"                                                                        \
-    "v_sub_u32 v85, 64, %[k]\n\t"                                                                          \
+    "v_cndmask_b32_e64 v88, " CELL ", %[k], %[spare]\n\t" /* queue entry: the cell, or the fourth lane's k (this step's) */ \
     "v_sub_u32 v71, %[ringl], v71\n\t"            /* ring address of the next window: 128 - ((c >> 3) & 127) */ \
-    LIMIT                                           /* the next limit = min(64 - k, rem + 1[, steps before the last]) */ \
     "s_mov_b64 exec, %[spare]\n\t"                  /* the fourth lanes only */                             \
+    "ds_read_b64 " DL ", v71\n\t"                  /* the next step's window: as early as the cursor allows, it is needed ten instructions into that step */ \
     MZD_Q4_QWR("ds_write_b64 %[qwa], " DM " offset:" QW "\n\t") /* this step's window for stage B */       \
-    "ds_read_b64 " DL ", v71\n\t"                  /* the next step's window */                            \
     "s_mov_b64 exec, -1\n\t"                                                                                \
+    MZD_Q4_QWR("ds_write_b16 %[qca], v88 offset:" QC "\n\t")                                               \
+    "v_and_b32 %[k], 7, %[c]\n\t"                                                                           \
+    "v_sub_u32 v85, 64, %[k]\n\t"                                                                          \
+    LIMIT                                           /* the next limit = min(64 - k, rem + 1[, steps before the last]) */ \
     RLOW                                                                                                    \
     "s_cbranch_vccnz " OUT "\n\t"
 #define Q4_PUBLISH(OUT)                                                                                     \
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     LIMIT                                                                                               \
                     "v_lshl_add_u32 v66, %[sa], 1, %[cb]\n\t"                                                          \
                     "ds_read_u16 v69, v66\n\t"                                                                        \
+                    "ds_read_u16 v68, v66\n\t"  /* (the cells alternate between v69 and v68 like the windows: the entry step's is either) */ \
                     "s_mov_b64 exec, %[spare]\n\t"                                                                      \
                     "ds_read_b64 v[90:91], v71\n\t"                                                                  \
                     "ds_read_b64 v[92:93], v71\n\t"                                                                  \
@@ -625,16 +634,16 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                     "s_cbranch_scc1 L_q4_go6_%=\n\t"                                                                    \
                     "s_branch L_q4_go7_%=\n"                                                                            \
                     Q4_CHECK("0", "%[tail0]", "%[o_tail0]")                                                             \
-                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
-                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
-                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
-                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_STEP("v[90:91]", "v[92:93]", "v69", "v68", "a", "b", "0", "%[qc0]", "%[qw0]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "v68", "v69", "b", "a", "1", "%[qc1]", "%[qw1]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v[90:91]", "v[92:93]", "v69", "v68", "a", "b", "2", "%[qc2]", "%[qw2]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "v68", "v69", "b", "a", "3", "%[qc3]", "%[qw3]", Q4_X4, Q4_RLOW, LIMIT)     \
                     Q4_PUBLISH(Q4_OUTO)                                                                                 \
                     Q4_CHECK("4", "%[tail1]", "%[o_tail1]")                                                             \
-                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
-                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
-                    Q4_STEP("v[90:91]", "v[92:93]", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
-                    Q4_STEP("v[92:93]", "v[90:91]", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
+                    Q4_STEP("v[90:91]", "v[92:93]", "v69", "v68", "a", "b", "4", "%[qc4]", "%[qw4]", Q4_X1, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "v68", "v69", "b", "a", "5", "%[qc5]", "%[qw5]", Q4_X2, "", LIMIT)          \
+                    Q4_STEP("v[90:91]", "v[92:93]", "v69", "v68", "a", "b", "6", "%[qc6]", "%[qw6]", Q4_X3, "", LIMIT)          \
+                    Q4_STEP("v[92:93]", "v[90:91]", "v68", "v69", "b", "a", "7", "%[qc7]", "%[qw7]", Q4_X4, Q4_RLOW, LIMIT)     \
                     Q4_PUBLISH(Q4_OUTO)                                                                                 \
                     "s_branch L_q4_top0_%=\n"                                                                           \
                     /* a step that leaves: the counter moves past it; after the first / third step of a batch the new   \
@@ -733,17 +742,25 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #endif
         (void)polls;
         if (spare && has && t.n_seq > 0) shs->stA[ch] = status;
-    } else if (lw == 4 || lw == 5) {
+    } else if (lw == 4 || lw == 5 || lw == 9) {
         // ================= stage B: field extraction and values, four steps at a time.  TWO wavefronts: wave 4 takes the
         // even batches (queue slots 0..3), wave 5 the odd ones (slots 4..7) -- a wavefront issues an instruction every ~6
         // cycles, and the ~55 of a stage-B step would otherwise be longer than stage A's step.
-        const uint32_t par = (uint32_t)lw - 4u;
+        // Round 5: THREE of them.  Stage A may run two batches ahead of the READ of a batch (the queue is two batches deep), and
+        // with two wavefronts at 70 % duty the one whose turn it is was still computing its batch before most of the time: the
+        // chain wavefronts polled for queue space 0.6-0.7 times per batch (302 cycles per step against 290 with stages B and C
+        // compiled to no-ops).  A third wavefront does not add work, it adds slack: whose turn it is has been idle for a while.
+        // Slots, and the two counters per slot parity that stages A and C1 watch, go by the BATCH (batch b: slots 4 (b & 1) ...):
+        // a batch's slots are refilled only after the batch two before it has been read / stored, so each counter still only
+        // ever moves forward, whichever wavefront writes it.
+        const uint32_t bid = lw == 9 ? 2u : (uint32_t)lw - 4u;
         const int col = min(lane, kQ4Cols - 1);  // lanes 56..63 have no column: they shadow the last one
         uint32_t head_seen = 0, tail_seen = 0;
 #ifdef MZD_Q4_PROF
         long long prof_in = 0, prof_out = 0, prof_t0 = clock64();
 #endif
-        for (uint32_t j0 = par * kPipeBatch; j0 < nmax; j0 += 2 * kPipeBatch) {
+        for (uint32_t j0 = bid * kPipeBatch; j0 < nmax; j0 += (uint32_t)kQ4BWaves * kPipeBatch) {
+            const uint32_t par = (j0 / kPipeBatch) & 1u;
             const uint32_t need = min(j0 + (uint32_t)kPipeBatch, nmax);
 #ifdef MZD_Q4_PROF
             const long long w0 = clock64();
@@ -812,7 +829,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             __hip_atomic_store(&shs->head2[par], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 #ifdef MZD_Q4_PROF
-        if (blockIdx.x == 0 && lane == 0) printf("B%u: cycles %lld wait_in %lld wait_out %lld (steps %u)\n", par, clock64() - prof_t0, prof_in, prof_out, nmax);
+        if (blockIdx.x == 0 && lane == 0) printf("B%u: cycles %lld wait_in %lld wait_out %lld (steps %u)\n", bid, clock64() - prof_t0, prof_in, prof_out, nmax);
 #endif
     } else if (lw == 6) {
         // ================= stage C1: repeat-offset history (sequence_execution.go:65-114), record packing =================
@@ -1005,10 +1022,26 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             }
             {
                 const int target = inside ? max(cur - kAhead, 0) : low;
+#ifdef MZD_Q4_TOUCH_WAIT
                 for (int g = 0; g < MZD_PIPE_TOUCHES && has && low > target && (iter & MZD_PIPE_TOUCH_EVERY) == 0; g++) {
                     low = max(low - kLine, 0);
                     touch_line(sbase + (low & ~3));
                 }
+#else
+                // (all of an iteration's touches in flight together, ONE wait: waited for one by one, eight misses in a row kept
+                // this wavefront from its rings for eight memory latencies and the chain wavefronts polled for them)
+                if ((iter & MZD_PIPE_TOUCH_EVERY) == 0) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int g = 0; g < MZD_PIPE_TOUCHES; g++) {
+                        if (has && low > target) {
+                            low = max(low - kLine, 0);
+                            acc += *(const uint32_t *)(sbase + (low & ~3));
+                        }
+                    }
+                    asm volatile("" ::"v"(acc));
+                }
+#endif
             }
             if (hd >= nmax) break;
             iter++;

@@ -1,7 +1,7 @@
-# k_seq_q4's step (round 5: one bit cursor, X by the fourth lane, the step taken back on the way out): the sequence-related GPU tests
-# on the shipped library, then same-box A/B against the library built from HEAD (tmp_ab/libmzd_head.so), cycles per step of both.
+# k_seq_q4's step: the sequence-related GPU tests on the shipped library, then same-box A/B of libraries under tmp_ab, then cycles
+# per step (tools/q4_stats.py) of the -DMZD_Q4_STATS builds named in STATS_LIBS
 cd ${GRAFT_REPO_ROOT:-$PWD}
-timeout 900 python3 -m pytest tests -m gpu -x -q -k "decodecorpus_bit_exact_on_gpu or oracle_trace or fuzzed_frames or escape_codes or randomized or synthetic_configs or multi_block or window_by_window or corrupt or truncat or fuzz" 2>&1 | tail -4
+timeout 900 python3 -m pytest tests -m gpu -x -q -k "decodecorpus_bit_exact_on_gpu or oracle_trace or stage_boundaries or fuzzed_frames or escape_codes or randomized or synthetic_configs or multi_block or window_by_window or corrupt or truncat or fuzz" 2>&1 | tail -4
 pick() { python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['roofline']['kernel_ms'], d['bit_exact'])" "$1"; }
 for rep in 1 2; do
   for l in "$@"; do
@@ -10,4 +10,4 @@ for rep in 1 2; do
     timeout 600 python3 bench.py --cpu-seconds 0 --no-ceiling --steps 8 2>/dev/null | pick "$l split"
   done
 done
-for l in libmzd_q4stats_head.so libmzd_q4stats.so; do echo $l; MZD_LIB=$PWD/tmp_ab/$l timeout 100 python3 tools/q4_stats.py 13824; done
+for l in ${STATS_LIBS:-libmzd_q4stats.so}; do echo $l; MZD_LIB=$PWD/tmp_ab/$l timeout 100 python3 tools/q4_stats.py 13824; done
