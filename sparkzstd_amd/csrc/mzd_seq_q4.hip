@@ -144,10 +144,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     // share the queue), so the busiest SIMD sets everybody's step.  Measured per step: P beside chain wavefront 0 and C2 as
     // the third wavefront of that SIMD, B / B / C1 beside the others: 307 cycles; in the order of the stages: 316.
 #ifndef MZD_Q4_ROLES
-#define MZD_Q4_ROLES {8, 4, 5, 6, 7, 9}
+#define MZD_Q4_ROLES {8, 4, 5, 6, 7, 9, 10}
 #endif
     const int wave = threadIdx.x >> 6;  // 0..3: chain wavefronts; 4..8: the stages, see above
-    constexpr int kRoles[6] = MZD_Q4_ROLES;  // (9: the third stage-B wavefront, when there is one)
+    constexpr int kRoles[7] = MZD_Q4_ROLES;  // (9, 10: the third and fourth stage-B wavefronts, when there are such; four: no better than three)
     const int lw = wave < kQ4ChainWaves ? wave : kRoles[wave - kQ4ChainWaves];
     const bool chainw = wave < kQ4ChainWaves;
     // the chain this lane works for: chain wavefronts 4 lanes per chain, the others one lane per chain
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #endif
         (void)polls;
         if (spare && has && t.n_seq > 0) shs->stA[ch] = status;
-    } else if (lw == 4 || lw == 5 || lw == 9) {
+    } else if (lw == 4 || lw == 5 || lw >= 9) {
         // ================= stage B: field extraction and values, four steps at a time.  TWO wavefronts: wave 4 takes the
         // even batches (queue slots 0..3), wave 5 the odd ones (slots 4..7) -- a wavefront issues an instruction every ~6
         // cycles, and the ~55 of a stage-B step would otherwise be longer than stage A's step.
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         // Slots, and the two counters per slot parity that stages A and C1 watch, go by the BATCH (batch b: slots 4 (b & 1) ...):
         // a batch's slots are refilled only after the batch two before it has been read / stored, so each counter still only
         // ever moves forward, whichever wavefront writes it.
-        const uint32_t bid = lw == 9 ? 2u : (uint32_t)lw - 4u;
+        const uint32_t bid = lw >= 9 ? (uint32_t)lw - 7u : (uint32_t)lw - 4u;
         const int col = min(lane, kQ4Cols - 1);  // lanes 56..63 have no column: they shadow the last one
         uint32_t head_seen = 0, tail_seen = 0;
 #ifdef MZD_Q4_PROF
@@ -1030,10 +1030,15 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
 #else
                 // (all of an iteration's touches in flight together, ONE wait: waited for one by one, eight misses in a row kept
                 // this wavefront from its rings for eight memory latencies and the chain wavefronts polled for them)
-                if ((iter & MZD_PIPE_TOUCH_EVERY) == 0) {
+                // (two lines every other iteration: 8.53 ms; eight every eighth, k_seq_pipe's rhythm: 8.58; sixteen-iteration rhythms: worse)
+#ifndef MZD_Q4_TOUCH_EVERY
+#define MZD_Q4_TOUCH_EVERY 1
+#define MZD_Q4_TOUCHES 2
+#endif
+                if ((iter & MZD_Q4_TOUCH_EVERY) == 0) {
                     uint32_t acc = 0;
 #pragma unroll
-                    for (int g = 0; g < MZD_PIPE_TOUCHES; g++) {
+                    for (int g = 0; g < MZD_Q4_TOUCHES; g++) {
                         if (has && low > target) {
                             low = max(low - kLine, 0);
                             acc += *(const uint32_t *)(sbase + (low & ~3));
@@ -1045,7 +1050,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             }
             if (hd >= nmax) break;
             iter++;
-            __builtin_amdgcn_s_sleep(2);
+#ifndef MZD_Q4_PSLEEP
+#define MZD_Q4_PSLEEP 1  // (2 -> 1: 8.65 -> 8.55 ms; 0: the same)
+#endif
+            __builtin_amdgcn_s_sleep(MZD_Q4_PSLEEP);
         }
     }
     __syncthreads();
