@@ -694,7 +694,11 @@ def main():
                             not a.window_log and not a.verify_checksum and distinct == per and a.cpu_seconds > 0 and not a.no_ceiling and
                             not a.exec_variant and not a.seq_variant and not a.huf_variant and not a.no_split)
         if headline_default and not a.no_secondary:
-            rb.free()  # (the headline's scratch goes first: the secondary batches bring their own)
+            # (the headline's batch and CONTEXT go first: the runtime deals a process's streams to four hardware queues, and a fifth
+            # stream -- a second context's second stream -- shares one: the Huffman kernel then no longer runs beside the sequence
+            # stage, real data 10.9 -> 13.9 ms; `tools/experiments/r5_sec_only.py`)
+            rb.free()
+            ctx.close()
             t0 = time.perf_counter()
             line["secondary"] = secondary_workloads(z, sb, torch, local_rank, (blob, off, ln, cks))
             line["secondary"]["wall_s_total"] = round(time.perf_counter() - t0, 1)

@@ -1,0 +1,39 @@
+import sys, os, json, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+import bench
+import sparkzstd_amd as z
+from tools import synth_binding as sb
+which = sys.argv[1] if len(sys.argv) > 1 else "corpus"
+out = {}
+# replicate secondary_workloads' measure for the corpus alone, optionally after a config-4 batch has run in the same process
+if which == "after4":
+    blob, off, ln, cks, _ = sb.make_batch(4, 0, 65536, 131072, threads=16)
+    ctx = z.Context(0)
+    plan = z.Plan(device_tables=True); plan.add_frames(blob, off, ln, threads=16); b = plan.finalize()
+    d_in = torch.zeros(blob.size + 128, dtype=torch.uint8, device="cuda"); d_in[64:64 + blob.size].copy_(torch.from_numpy(blob))
+    d_out = torch.zeros(b.out_size, dtype=torch.uint8, device="cuda")
+    rb = ctx.upload(b, device_in_ptr=d_in.data_ptr() + 64, device_out_ptr=d_out.data_ptr())
+    for _ in range(5): rb.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize(); rb.free()
+    if len(sys.argv) > 2 and sys.argv[2] == "close": ctx.close()
+    headline = (blob, off, ln, cks)
+else:
+    headline = None
+import types
+res = {}
+def fake(*a, **k): pass
+corpus = bench.load_corpus(1.0)
+cb, co, cl, ce = bench.corpus_batch(corpus, corpus["reps"])
+ctx2 = z.Context(0)
+plan = z.Plan(device_tables=True); assert plan.add_frames(cb, co, cl, threads=16) == 0; batch = plan.finalize()
+d_in2 = torch.zeros(cb.size + 128, dtype=torch.uint8, device="cuda"); d_in2[64:64 + cb.size].copy_(torch.from_numpy(cb))
+d_out2 = torch.zeros(batch.out_size, dtype=torch.uint8, device="cuda")
+rb2 = ctx2.upload(batch, device_in_ptr=d_in2.data_ptr() + 64, device_out_ptr=d_out2.data_ptr())
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(2): rb2.run(st)
+torch.cuda.synchronize(); ctx2.timing_reset(True)
+t0 = time.perf_counter()
+for _ in range(5): rb2.run(st)
+torch.cuda.synchronize()
+print(which, "ms", (time.perf_counter() - t0) / 5 * 1e3, ctx2.kernel_ms(), "flags", rb2.last_pass())
