@@ -399,6 +399,11 @@ int mzd_debug_backbits(mzd_ctx *ctx, const uint8_t *stream, uint32_t len, const 
  * default) = off.  For the parity tests only: a decoded frame never depends on it. */
 int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step);
 
+/* Test hook of the device planner (mzd_parse.hip): mzd_batch_upload_frames parses a frame of `frame_bytes` compressed bytes and
+ * more block by block -- a lane per block after a serial walk of the block headers -- instead of in one lane; 0 (the default) =
+ * the library's own threshold (1 MiB).  For the parity tests: small frames through the large-frame path.  ABI 7. */
+int mzd_debug_plan_unit_bytes(mzd_ctx *ctx, uint64_t frame_bytes);
+
 /* Which kernels the batch's LAST mzd_batch_run took (the library chooses by the batch's shape; the parity tests assert that the
  * path they mean to cover is the one that ran).  ABI 7. */
 enum {

@@ -25,7 +25,7 @@ EXPORTS = [
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
     "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
-    "mzd_batch_last_pass", "mzd_batch_trim",
+    "mzd_batch_last_pass", "mzd_batch_trim", "mzd_debug_plan_unit_bytes",
 ]
 MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT = 2, 4, 8, 16
 
@@ -170,6 +170,7 @@ def load():
         "mzd_debug_force_fixup_bail": (i32, [vp, u32]),
         "mzd_batch_last_pass": (u32, [vp]),
         "mzd_batch_trim": (i32, [vp, vp]),
+        "mzd_debug_plan_unit_bytes": (i32, [vp, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -39,6 +39,7 @@ struct mzd_ctx {
     bool timing = true;
     bool attr_set = false;
     uint32_t test_fixup_bail = 0;  // mzd_debug_force_fixup_bail: workgroup 1 of every frame gives up at this step of the fix-up walk
+    uint64_t test_large_frame = 0; // mzd_debug_plan_unit_bytes: frames of this many bytes and more are planned block by block (0: the default)
 };
 
 // temporaries of the device-side planning pass (kept by a streaming slot, freed at once otherwise)
@@ -53,6 +54,10 @@ struct ParseTemps {
     uint16_t *d_huf_src = nullptr;
     uint32_t *d_keys = nullptr, *d_perm = nullptr;  // ordering of heterogeneous work lists: keys out, permutation in
     uint8_t *d_sorted = nullptr;                    // the list being gathered
+    mzd::ParseUnit *d_units = nullptr;              // what the lanes of k_parse walk: whole frames, or the blocks of a large frame
+    uint64_t *d_starts = nullptr;                   // k_parse_index: block starts of the large frames
+    uint32_t *d_capoff = nullptr, *d_nfound = nullptr;
+    size_t cap_units = 0, cap_starts = 0, cap_capoff = 0, cap_nfound = 0;
     size_t cap_foff = 0, cap_flen = 0, cap_scratch = 0, cap_counts = 0, cap_bases = 0, cap_fse_tabs = 0, cap_fse_src = 0,
            cap_huf_tabs = 0, cap_huf_src = 0, cap_keys = 0, cap_perm = 0, cap_sorted = 0;
 };
@@ -70,6 +75,10 @@ static void free_parse_temps(ParseTemps &t)
     (void)hipFree(t.d_keys);
     (void)hipFree(t.d_perm);
     (void)hipFree(t.d_sorted);
+    (void)hipFree(t.d_units);
+    (void)hipFree(t.d_starts);
+    (void)hipFree(t.d_capoff);
+    (void)hipFree(t.d_nfound);
     t = ParseTemps();
 }
 struct DevCaps {  // bytes allocated behind the pointers of a recycled batch (0 = exact / unknown)
@@ -919,28 +928,110 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     db->in_size = in_size;
     db->n_frames = n_frames;
     const size_t nf1 = std::max<size_t>(n_frames, 1);
-    ENSURE(tp.d_foff, tp.cap_foff, nf1 * 8);
-    ENSURE(tp.d_flen, tp.cap_flen, nf1 * 8);
-    if (n_frames) {
-        HIP_OR_FAIL(hipMemcpyAsync(tp.d_foff, frame_off, (size_t)n_frames * 8, hipMemcpyHostToDevice, s));
-        HIP_OR_FAIL(hipMemcpyAsync(tp.d_flen, frame_len, (size_t)n_frames * 8, hipMemcpyHostToDevice, s));
+    // ---- the units of the walk (mzd_parse.hip): a frame, or -- a LARGE frame -- each of its blocks.  A lane per frame is right for
+    // batches of many frames (65 536 frames in 1 ms) and hopeless for one large frame (0.29 ms per block: 599 ms for 256 MiB):
+    // k_parse_index walks the block headers of the frames of kLargeFrame bytes and more (one lane each, the serial part: a
+    // dependent load per block), their blocks are then parsed side by side.
+    const uint64_t kLargeFrame = ctx->test_large_frame ? ctx->test_large_frame : 1ull << 20;
+    std::vector<ParseUnit> units;
+    units.reserve(n_frames);
+    std::vector<uint32_t> unit0(n_frames + 1, 0);  // first unit of every frame
+    {
+        std::vector<uint32_t> large;
+        for (uint32_t f = 0; f < n_frames; f++)
+            if (frame_len[f] >= kLargeFrame && frame_off[f] <= in_size && frame_len[f] <= in_size - frame_off[f]) large.push_back(f);
+        std::vector<uint32_t> nfound;
+        std::vector<uint64_t> starts;
+        std::vector<uint32_t> capoff(large.size() + 1, 0);
+        if (!large.empty()) {
+            // (room for a block start per 64 bytes of frame; a frame with more blocks than that stays one lane's)
+            std::vector<uint64_t> lo(large.size()), ll(large.size());
+            uint64_t total = 0;
+            for (size_t j = 0; j < large.size(); j++) {
+                lo[j] = frame_off[large[j]];
+                ll[j] = frame_len[large[j]];
+                total += ll[j] / 64 + 16;
+                if (total > 0xFFFFFFFFull) total = 0xFFFFFFFFull;
+                capoff[j + 1] = (uint32_t)total;
+            }
+            ENSURE(tp.d_foff, tp.cap_foff, large.size() * 8);
+            ENSURE(tp.d_flen, tp.cap_flen, large.size() * 8);
+            ENSURE(tp.d_capoff, tp.cap_capoff, capoff.size() * 4);
+            ENSURE(tp.d_nfound, tp.cap_nfound, large.size() * 4);
+            ENSURE(tp.d_starts, tp.cap_starts, (size_t)total * 8);
+            HIP_OR_FAIL(hipMemcpyAsync(tp.d_foff, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, s));
+            HIP_OR_FAIL(hipMemcpyAsync(tp.d_flen, ll.data(), ll.size() * 8, hipMemcpyHostToDevice, s));
+            HIP_OR_FAIL(hipMemcpyAsync(tp.d_capoff, capoff.data(), capoff.size() * 4, hipMemcpyHostToDevice, s));
+            k_parse_index<<<(uint32_t)((large.size() + 63) / 64), 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, tp.d_capoff, (uint32_t)large.size(),
+                                                                             tp.d_starts, tp.d_nfound);
+            nfound.resize(large.size());
+            HIP_OR_FAIL(hipMemcpyAsync(nfound.data(), tp.d_nfound, large.size() * 4, hipMemcpyDeviceToHost, s));
+            HIP_OR_FAIL(hipStreamSynchronize(s));
+            uint64_t used = 0;
+            for (size_t j = 0; j < large.size(); j++)
+                if (nfound[j] != 0xFFFFFFFFu) used = std::max<uint64_t>(used, (uint64_t)capoff[j] + nfound[j]);
+            starts.resize(used);
+            if (used) HIP_OR_FAIL(hipMemcpyAsync(starts.data(), tp.d_starts, used * 8, hipMemcpyDeviceToHost, s));
+            HIP_OR_FAIL(hipStreamSynchronize(s));
+        }
+        size_t j = 0;
+        for (uint32_t f = 0; f < n_frames; f++) {
+            unit0[f] = (uint32_t)units.size();
+            const uint64_t b = frame_off[f], e = frame_off[f] + frame_len[f];  // (out of the blob: k_parse reports it as truncated)
+            const bool is_large = j < large.size() && large[j] == f;
+            const uint32_t nb = is_large ? nfound[j] : 0u;
+            if (!is_large || nb == 0 || nb == 0xFFFFFFFFu) {
+                units.push_back(ParseUnit{b, frame_len[f] > ~0ull - b ? ~0ull : e, f, kUnitFirst | kUnitFinal, 0xFFFFFFFFu, 0});
+            } else {
+                units.push_back(ParseUnit{b, e, f, kUnitFirst, 1u, 0});
+                for (uint32_t k = 0; k < nb; k++) units.push_back(ParseUnit{starts[capoff[j] + k], e, f, 0u, 1u, 0});
+                units.back().flags |= kUnitFinal;  // (it runs to the frame's end: a frame that stops short of a last block is its to report)
+                units.back().max_blocks = 0xFFFFFFFFu;
+            }
+            if (is_large) j++;
+        }
+        unit0[n_frames] = (uint32_t)units.size();
     }
-    // one lane per frame, grid-stride; every lane owns a ParseScratch
+    const uint32_t n_units = (uint32_t)units.size();
+    const size_t nu1 = std::max<size_t>(n_units, 1);
+    ENSURE(tp.d_units, tp.cap_units, nu1 * sizeof(ParseUnit));
+    if (n_units) HIP_OR_FAIL(hipMemcpyAsync(tp.d_units, units.data(), (size_t)n_units * sizeof(ParseUnit), hipMemcpyHostToDevice, s));
+    // one lane per unit, grid-stride; every lane owns a ParseScratch
     const uint32_t max_wg = (uint32_t)std::max(ctx->num_cus, 1) * 2;
-    const uint32_t n_wg = std::max<uint32_t>(1, std::min<uint32_t>((n_frames + 63) / 64, max_wg));
+    const uint32_t n_wg = std::max<uint32_t>(1, std::min<uint32_t>((n_units + 63) / 64, max_wg));
     ENSURE(tp.d_scratch, tp.cap_scratch, (size_t)n_wg * 64 * sizeof(ParseScratch));
-    ENSURE(tp.d_counts, tp.cap_counts, nf1 * sizeof(FrameCount));
-    ENSURE(tp.d_bases, tp.cap_bases, nf1 * sizeof(FrameBase));
+    ENSURE(tp.d_counts, tp.cap_counts, nu1 * sizeof(FrameCount));
+    ENSURE(tp.d_bases, tp.cap_bases, nu1 * sizeof(FrameBase));
     ParseOut po{};
-    // ---- pass 0: what does every frame need?
+    // ---- pass 0: what does every unit need?
     HIP_OR_FAIL(hipEventRecord(t0, s));
-    if (n_frames)
-        k_parse<0><<<n_wg, 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, n_frames, tp.d_scratch, tp.d_counts, tp.d_bases, po);
+    if (n_units)
+        k_parse<0><<<n_wg, 64, 0, s>>>(db->d_in, in_size, tp.d_units, n_units, tp.d_scratch, tp.d_counts, tp.d_bases, po);
     HIP_OR_FAIL(hipEventRecord(t1, s));
-    std::vector<FrameCount> counts(n_frames);
-    if (n_frames)
-        HIP_OR_FAIL(hipMemcpyAsync(counts.data(), tp.d_counts, (size_t)n_frames * sizeof(FrameCount), hipMemcpyDeviceToHost, s));
+    std::vector<FrameCount> counts(n_units);
+    if (n_units)
+        HIP_OR_FAIL(hipMemcpyAsync(counts.data(), tp.d_counts, (size_t)n_units * sizeof(FrameCount), hipMemcpyDeviceToHost, s));
     HIP_OR_FAIL(hipStreamSynchronize(s));
+    // ---- the status of every frame: its first unit (in block order) that failed, or that needs a table no unit before it left
+    // (literals.go:247-252, sequences.go:275-366 with nothing to repeat), or a frame whose blocks end without a last one
+    std::vector<int32_t> frame_status(n_frames, MZD_OK);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        uint8_t have[4] = {0, 0, 0, 0};
+        for (uint32_t u = unit0[f]; u < unit0[f + 1] && frame_status[f] == MZD_OK; u++) {
+            const FrameCount &c = counts[u];
+            for (int k = 0; k < 4; k++)
+                if (((c.need >> k) & 1) && !have[k]) frame_status[f] = MZD_ERR_NO_PREV_TABLE;
+            if (frame_status[f] == MZD_OK && c.status != MZD_OK) frame_status[f] = c.status;
+            for (int k = 0; k < 4; k++) have[k] |= c.carry[k].src != 0;
+        }
+        if (frame_status[f] != MZD_OK)  // (as a frame that fails in one lane: it contributes nothing)
+            for (uint32_t u = unit0[f]; u < unit0[f + 1]; u++) {
+                FrameCount z{};
+                z.status = frame_status[f];
+                z.content_size = MZD_UNKNOWN_SIZE;
+                counts[u] = z;
+            }
+    }
     // ---- offsets (exclusive prefix sums).  Tables 0..2 are the predefined ones (predefined.go), kept as
     // their normalised counts and built by k_fse_build like every other table.
     static const int16_t kDef[3][53] = {
@@ -949,8 +1040,10 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1,  1,  1,  1,  1,  1,  1,  1,  1,  1, 1,
          1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1}};
     static const int kDefN[3] = {36, 29, 53}, kDefLog[3] = {6, 5, 6};  // by MZD_FSE_*: LL, OF, ML
-    std::vector<FrameBase> bases(n_frames);
+    std::vector<FrameBase> bases(n_units);
     std::vector<uint32_t> frame_seq_task(n_frames + 1, 0);
+    std::vector<DFrame> host_frames;       // the DFrames of the frames of several units (written here, not by a lane)
+    std::vector<uint32_t> host_frame_idx;
     db->frame_out_off.assign(n_frames, 0);
     db->frame_out_cap.assign(n_frames, 0);
     db->max_frame_serial_ms = 0;  // (no per-block sequence counts on the host: the bound-based estimate)
@@ -970,52 +1063,91 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     uint32_t seq_logs[3] = {0, 0, 0};  // largest LL / ML / OF accuracy log among the sequence tasks
     mzd_batch_stats st{};
     for (uint32_t f = 0; f < n_frames; f++) {
-        const FrameCount &c = counts[f];
-        FrameBase &fb = bases[f];
-        fb.block0 = (uint32_t)n_blocks;
-        fb.seq0 = (uint32_t)n_seq;
-        fb.hufb0 = (uint32_t)n_hufb;
-        fb.fse_tab0 = (uint32_t)n_fse_tab;
-        fb.fse_src0 = (uint32_t)n_fse_src;
-        fb.fse_dev0 = (uint32_t)n_fse_dev;
-        fb.huf_tab0 = (uint32_t)n_huf_tab;
-        fb.huf_src0 = (uint32_t)n_huf_src;
-        fb.huf_dev0 = (uint32_t)n_huf_dev;
-        fb.tile0 = (uint32_t)n_tile;
-        fb.rec0 = n_rec;
-        fb.lit0 = lit_total;
-        fb.out_off = out_at;
-        fb.out_cap = c.status == MZD_OK ? c.out_bound : 0;
+        const uint32_t u0 = unit0[f], u1 = unit0[f + 1];
+        // the frame: the sums of its units
+        uint64_t f_bound = 0, f_blocks = 0, f_seq = 0;
+        for (uint32_t u = u0; u < u1; u++) {
+            f_bound += counts[u].out_bound;
+            f_blocks += counts[u].n_blocks;
+            f_seq += counts[u].n_seq;
+        }
+        const uint64_t f_content = counts[u0].content_size;
+        if (u1 - u0 > 1 && f_content != MZD_UNKNOWN_SIZE) f_bound = std::min(f_bound, f_content);  // (a frame in one unit: its lane did)
+        const uint64_t f_cap = frame_status[f] == MZD_OK ? f_bound : 0;
         frame_seq_task[f] = (uint32_t)n_seq;
-        db->n_multi += c.n_blocks > 1 ? 1u : 0u;
-        if (c.n_seq && frame_off[f] <= in_size && frame_len[f] <= in_size - frame_off[f]) {
+        db->n_multi += f_blocks > 1 ? 1u : 0u;
+        if (f_seq && frame_off[f] <= in_size && frame_len[f] <= in_size - frame_off[f]) {
             db->frame_in_lo[f] = frame_off[f];
             db->frame_in_hi[f] = frame_off[f] + frame_len[f];
         }
-        db->frame_out_off[f] = fb.out_off;
-        db->frame_out_cap[f] = fb.out_cap;
-        out_at += (fb.out_cap + 255) & ~255ull;
-        n_blocks += c.n_blocks;
-        n_seq += c.n_seq;
-        n_hufb += c.n_hufb;
-        n_fse_tab += c.n_fse_tab;
-        n_fse_src += c.n_fse_src;
-        n_fse_dev += c.n_fse_dev;
-        n_huf_tab += c.n_huf_tab;
-        n_huf_src += c.n_huf_src;
-        n_huf_dev += c.n_huf_dev;
-        n_tile += c.n_tile;
-        n_rec += c.n_rec;
-        lit_total += c.lit_bytes;
-        max_huf_bits = std::max(max_huf_bits, c.max_huf_bits);
-        for (int k = 0; k < 3; k++) seq_logs[k] = std::max<uint32_t>(seq_logs[k], (c.max_seq_logs >> (8 * k)) & 0xFF);
-        st.compressed_bytes += c.comp_bytes;
-        st.out_capacity_bytes += fb.out_cap;
-        st.n_sequences += c.n_rec;
-        st.n_huf_streams += c.n_huf_streams;
-        st.n_blocks[0] += c.n_raw;
-        st.n_blocks[1] += c.n_rle;
-        st.n_blocks[2] += c.n_comp;
+        db->frame_out_off[f] = out_at;
+        db->frame_out_cap[f] = f_cap;
+        st.out_capacity_bytes += f_cap;
+        PCarry cur[4] = {};  // what the units so far leave to the next: absolute table references (src 3) or the predefined table (2)
+        uint32_t seen_seq = 0;
+        const uint32_t frame_block0 = (uint32_t)n_blocks;
+        for (uint32_t u = u0; u < u1; u++) {
+            const FrameCount &c = counts[u];
+            FrameBase &fb = bases[u];
+            fb.block0 = (uint32_t)n_blocks;
+            fb.seq0 = (uint32_t)n_seq;
+            fb.hufb0 = (uint32_t)n_hufb;
+            fb.fse_tab0 = (uint32_t)n_fse_tab;
+            fb.fse_src0 = (uint32_t)n_fse_src;
+            fb.fse_dev0 = (uint32_t)n_fse_dev;
+            fb.huf_tab0 = (uint32_t)n_huf_tab;
+            fb.huf_src0 = (uint32_t)n_huf_src;
+            fb.huf_dev0 = (uint32_t)n_huf_dev;
+            fb.tile0 = (uint32_t)n_tile;
+            fb.rec0 = n_rec;
+            fb.lit0 = lit_total;
+            fb.out_off = out_at;
+            fb.out_cap = f_cap;
+            for (int k = 0; k < 4; k++) fb.in[k] = cur[k];
+            fb.seen_seq = seen_seq;
+            fb.frame_blocks = (uint32_t)f_blocks;
+            fb.frame_block0 = frame_block0;
+            fb.pad = (uint32_t)frame_status[f];
+            for (int k = 0; k < 4; k++) {
+                if (c.carry[k].src == 1) cur[k] = PCarry{(k == 0 ? fb.huf_dev0 : fb.fse_dev0) + c.carry[k].off, c.carry[k].log, 3, {0, 0}};
+                else if (c.carry[k].src == 2) cur[k] = PCarry{0, c.carry[k].log, 2, {0, 0}};
+            }
+            seen_seq |= c.n_seq ? 1u : 0u;
+            n_blocks += c.n_blocks;
+            n_seq += c.n_seq;
+            n_hufb += c.n_hufb;
+            n_fse_tab += c.n_fse_tab;
+            n_fse_src += c.n_fse_src;
+            n_fse_dev += c.n_fse_dev;
+            n_huf_tab += c.n_huf_tab;
+            n_huf_src += c.n_huf_src;
+            n_huf_dev += c.n_huf_dev;
+            n_tile += c.n_tile;
+            n_rec += c.n_rec;
+            lit_total += c.lit_bytes;
+            max_huf_bits = std::max(max_huf_bits, c.max_huf_bits);
+            for (int k = 0; k < 3; k++) seq_logs[k] = std::max<uint32_t>(seq_logs[k], (c.max_seq_logs >> (8 * k)) & 0xFF);
+            st.compressed_bytes += c.comp_bytes;
+            st.n_sequences += c.n_rec;
+            st.n_huf_streams += c.n_huf_streams;
+            st.n_blocks[0] += c.n_raw;
+            st.n_blocks[1] += c.n_rle;
+            st.n_blocks[2] += c.n_comp;
+        }
+        if (u1 - u0 > 1 && frame_status[f] == MZD_OK) {
+            DFrame df{};
+            df.out_offset = out_at;
+            df.out_capacity = f_cap;
+            df.content_size = f_content;
+            df.first_block = frame_block0;
+            df.n_blocks = (uint32_t)f_blocks;
+            df.plan_status = MZD_OK;
+            df.has_checksum = (counts[u0].flags & 0x80000000u) ? 1 : 0;
+            df.checksum = df.has_checksum ? counts[u1 - 1].checksum : 0;
+            host_frames.push_back(df);
+            host_frame_idx.push_back(f);
+        }
+        out_at += (f_cap + 255) & ~255ull;
     }
     out_at += 256;  // tail slack: the execution kernel's 16-byte source loads may run past the last slab
     frame_seq_task[n_frames] = (uint32_t)n_seq;
@@ -1077,7 +1209,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     }
     HIP_OR_FAIL(hipMemcpyAsync(tp.d_fse_tabs, pd, sizeof pd, hipMemcpyHostToDevice, s));
     HIP_OR_FAIL(hipMemcpyAsync(tp.d_fse_src, psrc.data(), psrc.size() * 4, hipMemcpyHostToDevice, s));
-    if (n_frames) HIP_OR_FAIL(hipMemcpyAsync(tp.d_bases, bases.data(), (size_t)n_frames * sizeof(FrameBase), hipMemcpyHostToDevice, s));
+    if (n_units) HIP_OR_FAIL(hipMemcpyAsync(tp.d_bases, bases.data(), (size_t)n_units * sizeof(FrameBase), hipMemcpyHostToDevice, s));
     po.frames = db->d_frames;
     po.blocks = db->d_blocks;
     po.huf_tasks = db->d_huf_tasks;
@@ -1088,8 +1220,10 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     po.huf_src = tp.d_huf_src;
     // ---- pass 1: write the work lists and the table build descriptors; then build the tables
     HIP_OR_FAIL(hipEventRecord(t2, s));
-    if (n_frames)
-        k_parse<1><<<n_wg, 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, n_frames, tp.d_scratch, tp.d_counts, tp.d_bases, po);
+    if (n_units)
+        k_parse<1><<<n_wg, 64, 0, s>>>(db->d_in, in_size, tp.d_units, n_units, tp.d_scratch, tp.d_counts, tp.d_bases, po);
+    for (size_t i = 0; i < host_frames.size(); i++)  // (the frames of several units; host_frames lives until the synchronisation below)
+        HIP_OR_FAIL(hipMemcpyAsync(db->d_frames + host_frame_idx[i], &host_frames[i], sizeof(DFrame), hipMemcpyHostToDevice, s));
     HIP_OR_FAIL(hipEventRecord(t3, s));
     k_fse_build<<<(uint32_t)((n_fse_tab + 63) / 64), 64, 0, s>>>(tp.d_fse_tabs, (uint32_t)n_fse_tab, tp.d_fse_src, db->d_fse_entries);
     HIP_OR_FAIL(hipEventRecord(t4, s));
@@ -1171,44 +1305,8 @@ int mzd_batch_upload_frames(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size, u
         (flags & ~(uint32_t)(MZD_BATCH_IN_ON_DEVICE | MZD_BATCH_OUT_ON_DEVICE)) || ((flags & MZD_BATCH_OUT_ON_DEVICE) && !out_dev))
         return MZD_ERR_INVALID_ARG;
     *out = nullptr;
-    // k_parse gives a FRAME one lane: right for batches of many frames (65 536 frames in 1 ms), hopeless for one large frame -- its
-    // blocks are walked one by one, 0.29 ms each (a 256 MiB frame: 599 ms), where the host planner goes through 64 MiB of frame
-    // per millisecond on one thread (frames in parallel on all of them).  A batch with a frame of kHostPlanFrameBytes or more is
-    // therefore planned by the host planner here too (a blob that is resident on the device is copied back once for it): same
-    // descriptors, same statuses (the two planners agree frame for frame: tests/test_gpu_corpus.py::test_device_planner_*),
-    // same layout calls afterwards.
-    constexpr uint64_t kHostPlanFrameBytes = 4ull << 20;
-    uint64_t longest = 0;
-    for (uint32_t i = 0; i < n_frames; i++) longest = std::max(longest, frame_len[i]);
-    if (longest >= kHostPlanFrameBytes) {
-        for (uint32_t i = 0; i < n_frames; i++)
-            if (frame_off[i] > in_size || frame_len[i] > in_size - frame_off[i]) return MZD_ERR_INVALID_ARG;
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        std::vector<uint8_t> back;
-        const uint8_t *host = in;
-        if (flags & MZD_BATCH_IN_ON_DEVICE) {
-            back.resize(in_size);
-            HIP_TRY(ctx, hipMemcpy(back.data(), in, in_size, hipMemcpyDeviceToHost));
-            host = back.data();
-        }
-        mzd_plan *plan = mzd_plan_create();
-        mzd_plan_set_device_tables(plan, 1);
-        (void)mzd_plan_add_frames(plan, host, frame_off, frame_len, n_frames, 0);  // (per-frame statuses travel in the descriptors)
-        mzd_batch run = *mzd_plan_finalize(plan);
-        if (flags & MZD_BATCH_IN_ON_DEVICE) {
-            run.in = in;
-            run.flags |= MZD_BATCH_IN_ON_DEVICE;
-        }
-        int rc = MZD_OK;
-        if (flags & MZD_BATCH_OUT_ON_DEVICE) {
-            if (out_dev_size < run.out_size) rc = MZD_ERR_DST_FULL;
-            run.out = out_dev;
-            run.flags |= MZD_BATCH_OUT_ON_DEVICE;
-        }
-        if (rc == MZD_OK) rc = mzd_batch_upload(ctx, &run, out);
-        mzd_plan_destroy(plan);
-        return rc;
-    }
+    // (round 5: a large frame's blocks are parsed side by side on the device -- the units of mzd_parse.hip --, so a batch with such a
+    // frame no longer goes back to the host planner, and a blob that is resident on the device stays there)
     return upload_frames_impl(ctx, in, in_size, flags, frame_off, frame_len, n_frames, out_dev, out_dev_size, nullptr, ctx->stream, out);
 }
 
@@ -2203,6 +2301,13 @@ int mzd_batch_debug_read(mzd_ctx *ctx, mzd_dbatch *db, int what, uint64_t offset
 }
 
 uint32_t mzd_batch_last_pass(const mzd_dbatch *db) { return db ? db->last_pass : 0u; }
+
+int mzd_debug_plan_unit_bytes(mzd_ctx *ctx, uint64_t frame_bytes)
+{
+    if (!ctx) return MZD_ERR_INVALID_ARG;
+    ctx->test_large_frame = frame_bytes;
+    return MZD_OK;
+}
 
 int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step)
 {

@@ -9,6 +9,13 @@
 //   sequences header  structure/sequences.go:228-269,371-433
 //   table selection   structure/sequences.go:275-366, carry-over framedecompressor.go:283-294
 //   FSE description   fse/fse.go:28-130
+// Round 5: the unit of the walk is a UNIT, not a frame -- a whole frame (the many-frames case: a lane per frame), or, for a LARGE
+// frame, one of its blocks: k_parse_index walks such a frame's 3-byte block headers (one lane, the only serial part) and lists
+// where every block starts; the blocks are then parsed side by side, a lane each.  What a block inherits from the blocks before
+// it -- the Huffman table and the three FSE tables a Treeless / Repeat_Mode section reuses, and whether an earlier block had
+// sequences (framedecompressor.go:283-294, literals.go:247-252, sequences.go:275-366) -- is not known to its lane in pass 0: the
+// lane notes that it NEEDS it (UnitCount::need) and what it leaves behind (UnitCount::carry); the host, which turns the counts
+// into offsets anyway, walks the units of the frame in order and hands every unit its inheritance for pass 1 (UnitBase::in).
 // Two passes over the same walk: PASS 0 counts what every frame contributes (blocks, tasks, table
 // cells, scratch, output bound) and finds parse errors; the host turns the counts into offsets;
 // PASS 1 walks again and writes DFrame / DBlock / HufTask / SeqTask and the table build
@@ -26,6 +33,12 @@ struct ParseScratch {  // per lane, in global memory
     uint8_t sym[512];
 };
 
+// a table a later section may reuse: src 0 = none, 1 = made by this unit (off = offset among the unit's own device cells),
+// 2 = the predefined table of its kind, 3 (pass 1 only) = absolute (off = device cell offset)
+struct PCarry {
+    uint32_t off;
+    uint8_t log, src, pad[2];
+};
 struct FrameCount {
     int32_t status;
     uint32_t n_blocks, n_seq, n_hufb, n_fse_tab, n_fse_src, n_fse_dev, n_huf_tab, n_huf_src, n_huf_dev, n_tile;
@@ -33,10 +46,29 @@ struct FrameCount {
     uint32_t max_seq_logs;  // largest accuracy logs of the frame's sequence tables: LL | ML << 8 | OF << 16
     uint32_t n_raw, n_rle, n_comp, n_huf_streams;
     uint64_t n_rec, lit_bytes, out_bound, content_size, comp_bytes;
+    // units of a large frame: what a later unit may reuse of this one's, which inheritance this unit could not do without
+    // (bit k: carry kind k), whether its walk saw the frame's last block
+    PCarry carry[4];
+    uint32_t need, saw_last;
 };
 struct FrameBase {
     uint32_t block0, seq0, hufb0, fse_tab0, fse_src0, fse_dev0, huf_tab0, huf_src0, huf_dev0, tile0;
     uint64_t rec0, lit0, out_off, out_cap;
+    // units of a large frame (pass 1): what the unit inherits -- [0] Huffman, [1 + MZD_FSE_*] the sequence tables --, whether an
+    // earlier block of the frame had sequences, and for the frame's FIRST unit the totals of the frame it writes the DFrame from
+    PCarry in[4];
+    uint32_t seen_seq, frame_blocks, frame_block0;
+    uint32_t pad;  // MZD_* status of the unit's frame (pass 1 skips the units of a frame that failed)
+};
+// one unit of the walk: a whole frame, or one block of a large frame
+constexpr uint32_t kUnitFirst = 1;   // starts at the frame's magic number (parses the frame header)
+constexpr uint32_t kUnitFinal = 2;   // runs to the frame's last block (and reads the checksum behind it)
+struct ParseUnit {
+    uint64_t begin, end;   // bytes of the blob: where the unit starts, where its frame ends
+    uint32_t frame;        // index of its frame in the batch
+    uint32_t flags;        // kUnit*
+    uint32_t max_blocks;   // blocks this unit walks at most (a unit that is not final stops there)
+    uint32_t pad;
 };
 struct ParseOut {
     DFrame *frames;
@@ -228,49 +260,64 @@ struct PTabRef {  // "previous" table of one kind (framedecompressor.go:283-294)
     bool valid;
 };
 
-// Walks one frame.  PASS 0: fills `cnt` (status + counts).  PASS 1: `fb` holds the frame's offsets,
-// descriptors are written through `po` (`cnt` is not touched).
+// Walks one unit: a frame, or -- units of a large frame -- its blocks from `begin` on, `max_blocks` of them at most.  PASS 0: fills
+// `cnt` (status + counts, and for the units of a large frame what the unit needs from / leaves to its neighbours).  PASS 1: `fb`
+// holds the unit's offsets (and its inheritance), descriptors are written through `po` (`cnt` is not touched).
 template <int PASS>
 __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, ParseScratch &sc, FrameCount &cnt,
-                             const FrameBase &fb, const ParseOut &po)
+                             const FrameBase &fb, const ParseOut &po, uint32_t uflags = kUnitFirst | kUnitFinal,
+                             uint32_t max_blocks = 0xFFFFFFFFu)
 {
     const int kPMaxSym[3] = {35, 31, 52}, kPMaxLog[3] = {9, 8, 9}, kPDefLog[3] = {6, 5, 6};  // by MZD_FSE_*: LL, OF, ML
     FrameCount c{};
     c.content_size = MZD_UNKNOWN_SIZE;
     uint64_t p = begin;
+    const bool first_unit = (uflags & kUnitFirst) != 0;
 #define P_FAIL(code)                               \
     do {                                           \
         if (PASS == 0) {                           \
             FrameCount z_{};                       \
             z_.status = (code);                    \
             z_.content_size = MZD_UNKNOWN_SIZE;    \
+            z_.need = c.need;                      \
             cnt = z_;                              \
         }                                          \
         return;                                    \
     } while (0)
-    // ---- magic + frame header
-    if (end - p < 5) P_FAIL(MZD_ERR_TRUNCATED);
-    if (!(base[p] == 0x28 && base[p + 1] == 0xB5 && base[p + 2] == 0x2F && base[p + 3] == 0xFD)) P_FAIL(MZD_ERR_MAGIC);
-    const uint8_t fhd = base[p + 4];
-    p += 5;
-    const bool single = (fhd >> 5) & 1;
-    const int dict_bytes = (fhd & 3) == 3 ? 4 : (fhd & 3);
-    const int fcs_flag = fhd >> 6;
-    const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
-    if (end - p < (uint64_t)(!single) + dict_bytes + fcs_bytes) P_FAIL(MZD_ERR_TRUNCATED);
-    if (!single) p++;  // window descriptor (frame.go:28-36): informational
-    p += dict_bytes;   // dictionary id is read and ignored (no dictionary support: Readme.md:59-62)
-    if (fcs_bytes) {
-        uint64_t v = 0;
-        for (int i = 0; i < fcs_bytes; i++) v |= (uint64_t)base[p + i] << (8 * i);
-        if (fcs_bytes == 2) v += 256;  // frame.go:58-60
-        c.content_size = v;
-        p += fcs_bytes;
+    uint8_t fhd = 0;
+    if (first_unit) {
+        // ---- magic + frame header
+        if (end - p < 5) P_FAIL(MZD_ERR_TRUNCATED);
+        if (!(base[p] == 0x28 && base[p + 1] == 0xB5 && base[p + 2] == 0x2F && base[p + 3] == 0xFD)) P_FAIL(MZD_ERR_MAGIC);
+        fhd = base[p + 4];
+        p += 5;
+        const bool single = (fhd >> 5) & 1;
+        const int dict_bytes = (fhd & 3) == 3 ? 4 : (fhd & 3);
+        const int fcs_flag = fhd >> 6;
+        const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
+        if (end - p < (uint64_t)(!single) + dict_bytes + fcs_bytes) P_FAIL(MZD_ERR_TRUNCATED);
+        if (!single) p++;  // window descriptor (frame.go:28-36): informational
+        p += dict_bytes;   // dictionary id is read and ignored (no dictionary support: Readme.md:59-62)
+        if (fcs_bytes) {
+            uint64_t v = 0;
+            for (int i = 0; i < fcs_bytes; i++) v |= (uint64_t)base[p + i] << (8 * i);
+            if (fcs_bytes == 2) v += 256;  // frame.go:58-60
+            c.content_size = v;
+            p += fcs_bytes;
+        }
+        c.flags |= ((fhd >> 2) & 1) ? 0x80000000u : 0u;  // (the checksum flag, for the unit that reaches the frame's end)
     }
     PTabRef prev_huf{0, 0, false}, prev_t[3] = {{0, 0, false}, {0, 0, false}, {0, 0, false}};
     bool last = false, seen_seq = false;
+    if (!first_unit && PASS == 1) {
+        // a later unit of a large frame: what it inherits (the host resolved it from the units before: UnitBase::in)
+        seen_seq = fb.seen_seq != 0;
+        if (fb.in[0].src) prev_huf = PTabRef{fb.in[0].off, fb.in[0].log, true};
+        for (int k = 0; k < 3; k++)
+            if (fb.in[1 + k].src) prev_t[k] = PTabRef{fb.in[1 + k].src == 2 ? po.predef_off[k] : fb.in[1 + k].off, fb.in[1 + k].log, true};
+    }
     // ---- blocks (block.go:33-55, framedecompressor.go:198-303)
-    while (!last) {
+    while (!last && c.n_blocks < max_blocks) {
         if (end - p < 3) P_FAIL(MZD_ERR_TRUNCATED);
         const uint32_t h = base[p] | ((uint32_t)base[p + 1] << 8) | ((uint32_t)base[p + 2] << 16);
         p += 3;
@@ -346,7 +393,11 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                 if (q + csize > lim) P_FAIL(MZD_ERR_TRUNCATED);
                 const uint64_t lit_end = q + csize;
                 if (ltype == 3) {  // Treeless: literals.go:247-252
-                    if (!prev_huf.valid) P_FAIL(MZD_ERR_NO_PREV_TABLE);
+                    if (!prev_huf.valid) {
+                        if (first_unit || PASS == 1) P_FAIL(MZD_ERR_NO_PREV_TABLE);
+                        c.need |= 1u;  // (a later unit in pass 0: the table is an earlier unit's -- or nobody's: the host decides)
+                        prev_huf.valid = true;
+                    }
                 } else {           // literals.go:254-267
                     int nw = 0;
                     const int used = p_read_huffman_weights(base + q, lit_end - q, sc, nw);
@@ -368,6 +419,7 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                                 (uint16_t)(sc.w[2 * i] | ((2 * i + 1 < (uint32_t)nw ? sc.w[2 * i + 1] : 0) << 8));
                     }
                     prev_huf = PTabRef{fb.huf_dev0 + c.n_huf_dev, (uint32_t)mb, true};
+                    c.carry[0] = PCarry{c.n_huf_dev, (uint8_t)mb, 1, {0, 0}};
                     c.n_huf_tab++;
                     c.n_huf_src += ncell;
                     c.n_huf_dev += 1u << mb;
@@ -443,6 +495,7 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                     const int mode = (modes >> (6 - 2 * kidx)) & 3;
                     if (mode == 0) {  // Predefined
                         prev_t[kind] = PTabRef{po.predef_off[kind], (uint32_t)kPDefLog[kind], true};
+                        c.carry[1 + kind] = PCarry{0, (uint8_t)kPDefLog[kind], 2, {0, 0}};
                     } else if (mode == 1) {  // RLE: one byte = the code (sequences.go:282-289,315-323,343-351)
                         if (q >= lim) P_FAIL(MZD_ERR_TRUNCATED);
                         const uint8_t code = base[q];
@@ -458,12 +511,17 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                             po.fse_src[fd.src_off] = (uint32_t)code << 24;
                         }
                         prev_t[kind] = PTabRef{fb.fse_dev0 + c.n_fse_dev, 0, true};
+                        c.carry[1 + kind] = PCarry{c.n_fse_dev, 0, 1, {0, 0}};
                         c.n_fse_tab++;
                         c.n_fse_src += 1;
                         c.n_fse_dev += 1;
                         q += 1;
                     } else if (mode == 3) {  // Repeat
-                        if (!prev_t[kind].valid) P_FAIL(MZD_ERR_NO_PREV_TABLE);
+                        if (!prev_t[kind].valid) {
+                            if (first_unit || PASS == 1) P_FAIL(MZD_ERR_NO_PREV_TABLE);
+                            c.need |= 2u << kind;
+                            prev_t[kind].valid = true;
+                        }
                     } else {  // Compressed
                         int nsym = 0, al = 0;
                         const int used = p_read_fse_description(base + q, lim - q, sc.prob, nsym, al);
@@ -484,6 +542,7 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                                                              ((2 * i + 1 < (uint32_t)nsym ? (uint32_t)(uint16_t)sc.prob[2 * i + 1] : 0u) << 16);
                         }
                         prev_t[kind] = PTabRef{fb.fse_dev0 + c.n_fse_dev, (uint32_t)al, true};
+                        c.carry[1 + kind] = PCarry{c.n_fse_dev, (uint8_t)al, 1, {0, 0}};
                         c.n_fse_tab++;
                         c.n_fse_src += ncell;
                         c.n_fse_dev += 1u << al;
@@ -527,17 +586,20 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
         if (PASS == 1) po.blocks[bi] = d;
         c.n_blocks++;
     }
+    c.saw_last = last ? 1u : 0u;
     // the content checksum is not part of what the reference consumes (framereader.go:84-94)
-    if (((fhd >> 2) & 1) && end - p >= 4) {
+    // (a later unit of a large frame does not know the frame header's flag: it reports the four bytes behind the last block, the
+    // host keeps them if the first unit saw the flag)
+    if (last && (((fhd >> 2) & 1) || !first_unit) && end - p >= 4) {
         c.checksum = base[p] | ((uint32_t)base[p + 1] << 8) | ((uint32_t)base[p + 2] << 16) | ((uint32_t)base[p + 3] << 24);
-        c.flags |= MZD_FRAME_HAS_CHECKSUM;
+        if (first_unit) c.flags |= MZD_FRAME_HAS_CHECKSUM;
     }
     // never more than the blocks can regenerate: a (corrupt) header may declare any content size
-    if (c.content_size != MZD_UNKNOWN_SIZE) c.out_bound = min(c.out_bound, c.content_size);
+    if (c.content_size != MZD_UNKNOWN_SIZE && (uflags & kUnitFinal)) c.out_bound = min(c.out_bound, c.content_size);
     if (PASS == 0) {
         c.status = MZD_OK;
         cnt = c;
-    } else {
+    } else if ((uflags & kUnitFirst) && (uflags & kUnitFinal)) {  // (the frame of several units: the host writes its DFrame)
         DFrame df{};
         df.out_offset = fb.out_off;
         df.out_capacity = fb.out_cap;
@@ -553,37 +615,86 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
 }
 
 template <int PASS>
-__global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in, uint64_t in_size,
-                                              const uint64_t *__restrict__ frame_off, const uint64_t *__restrict__ frame_len,
-                                              uint32_t n_frames, ParseScratch *scratch, FrameCount *counts,
+__global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in, uint64_t in_size, const ParseUnit *__restrict__ units,
+                                              uint32_t n_units, ParseScratch *scratch, FrameCount *counts,
                                               const FrameBase *__restrict__ bases, ParseOut po)
 {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthr = gridDim.x * 64;
     ParseScratch &sc = scratch[tid];
-    for (uint32_t f = tid; f < n_frames; f += nthr) {
-        uint64_t off = frame_off[f], len = frame_len[f];
-        if (off > in_size || len > in_size - off) { off = 0; len = 0; }  // out of the blob: reported as truncated
+    for (uint32_t u = tid; u < n_units; u += nthr) {
+        const ParseUnit un = units[u];
+        uint64_t off = un.begin, end = un.end;
+        if (off > in_size || end > in_size || end < off) { off = 0; end = 0; }  // out of the blob: reported as truncated
         if (PASS == 0) {
             FrameCount c{};
-            p_walk_frame<0>(in, off, off + len, sc, c, FrameBase{}, po);
-            counts[f] = c;
+            p_walk_frame<0>(in, off, end, sc, c, FrameBase{}, po, un.flags, un.max_blocks);
+            counts[u] = c;
         } else {
-            const FrameBase fb = bases[f];
+            const FrameBase fb = bases[u];
             ParseOut pf = po;
-            pf.frames = po.frames + f;
-            if (counts[f].status != MZD_OK) {
-                DFrame df{};
-                df.out_offset = fb.out_off;
-                df.content_size = MZD_UNKNOWN_SIZE;
-                df.first_block = fb.block0;
-                df.plan_status = counts[f].status;
-                pf.frames[0] = df;
+            pf.frames = po.frames + un.frame;
+            if (fb.pad != MZD_OK) {  // the status of the unit's FRAME as the host found it (a later unit's error fails the first one's too)
+                if (un.flags & kUnitFirst) {
+                    DFrame df{};
+                    df.out_offset = fb.out_off;
+                    df.content_size = MZD_UNKNOWN_SIZE;
+                    df.first_block = fb.block0;
+                    df.plan_status = (int32_t)fb.pad;
+                    pf.frames[0] = df;
+                }
             } else {
                 FrameCount dummy;
-                p_walk_frame<1>(in, off, off + len, sc, dummy, fb, pf);
+                p_walk_frame<1>(in, off, end, sc, dummy, fb, pf, un.flags, un.max_blocks);
             }
         }
     }
+}
+
+// Large frames: where does every block start?  One lane per listed frame walks the 3-byte block headers (block.go:33-55) -- a chain
+// of dependent loads, a block apart; the only serial part of planning such a frame -- and writes the offset of every block AFTER
+// the first into starts[cap_off[j] ...] (room for cap_off[j + 1] - cap_off[j] of them; a frame with more is left to one lane:
+// n_found = ~0).  It stops at the last block, or where a header cannot be followed (truncated input, a reserved block type, a
+// size above the limit): the unit that starts at the last offset found meets that header again and reports it.
+__global__ __launch_bounds__(64) void k_parse_index(const uint8_t *__restrict__ in, uint64_t in_size, const uint64_t *__restrict__ frame_off,
+                                                    const uint64_t *__restrict__ frame_len, const uint32_t *__restrict__ cap_off,
+                                                    uint32_t n_large, uint64_t *__restrict__ starts, uint32_t *__restrict__ n_found)
+{
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_large) return;
+    uint64_t p = frame_off[j], end = frame_off[j] + frame_len[j];
+    uint32_t n = 0;
+    const uint32_t cap = cap_off[j + 1] - cap_off[j];
+    uint64_t *out = starts + cap_off[j];
+    if (p > in_size || end > in_size || end - p < 5) {
+        n_found[j] = 0;
+        return;
+    }
+    {
+        const uint8_t fhd = in[p + 4];
+        const bool single = (fhd >> 5) & 1;
+        const int dict_bytes = (fhd & 3) == 3 ? 4 : (fhd & 3);
+        const int fcs_flag = fhd >> 6;
+        p += 5 + (single ? 0 : 1) + dict_bytes + (fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag));
+    }
+    bool first = true;
+    while (p + 3 <= end) {
+        if (!first) {
+            if (n >= cap) {
+                n = 0xFFFFFFFFu;
+                break;
+            }
+            out[n++] = p;
+        }
+        first = false;
+        const uint32_t h = in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
+        const int type = (h >> 1) & 3;
+        const uint32_t size = h >> 3;
+        if ((h & 1) || type == 3 || size > kBlockMax) break;
+        const uint64_t adv = 3 + (type == MZD_BLOCK_RLE ? 1ull : (uint64_t)size);
+        if (end - p < adv) break;
+        p += adv;
+    }
+    n_found[j] = n;
 }
 
 }  // namespace mzd

@@ -767,6 +767,94 @@ def test_device_planner_fuzz_agrees_with_host_planner(corpus, seed):
     c.close()
 
 
+def _plan_by_blocks(ctx, on=True):
+    """frames of 16 bytes and more are planned block by block (mzd_debug_plan_unit_bytes) / the library's own threshold again"""
+    from sparkzstd_amd import _lib
+    assert _lib.load().mzd_debug_plan_unit_bytes(ctx._c, 16 if on else 0) == 0
+
+
+def test_device_planner_block_by_block_corpus_and_fuzz(corpus, oracle):
+    """A LARGE frame is planned on the device block by block: one lane walks its 3-byte block headers (k_parse_index), then a
+    lane per block parses literal / sequence section headers, Huffman weights and FSE descriptions side by side, and what a
+    block inherits -- the table a Treeless literals section or a Repeat_Mode sequence table reuses (literals.go:247-252,
+    sequences.go:275-366, framedecompressor.go:283-294), whether an earlier block had sequences -- is resolved between the two
+    passes from what every block says it needs and leaves.  With the threshold forced down to 16 bytes the whole corpus and
+    its mutations go that way: same bytes as the manifest, and frame for frame the statuses and bytes of the host planner."""
+    c = z.Context(0)
+    try:
+        _plan_by_blocks(c)
+        outs, sts = z.decode_frames([comp for _, comp, *_ in corpus], c, device_plan=True)
+        assert all(s == 0 for s in sts), [(corpus[i][0], s) for i, s in enumerate(sts) if s]
+        for (name, comp, length, sha, exp), got in zip(corpus, outs):
+            check_expected(name, got, length, sha, exp)
+        rng = np.random.default_rng(4242)
+        frames = []
+        for _, comp, *_ in corpus:
+            for k in range(8):
+                b = bytearray(comp)
+                if k == 6:
+                    b = b[:int(rng.integers(0, len(b)))]  # truncated anywhere, header included
+                elif k == 7:
+                    b[int(rng.integers(0, min(len(b), 12)))] ^= int(rng.integers(1, 256))  # header damage
+                else:
+                    for pos in rng.integers(4, len(b), size=1 + k % 3):
+                        b[int(pos)] ^= int(rng.integers(1, 256))
+                frames.append(bytes(b))
+        outs_d, sts_d = z.decode_frames(frames, c, device_plan=True)
+        _plan_by_blocks(c, False)
+        outs_h, sts_h = z.decode_frames(frames, c)
+        diff = [(i, sts_h[i], sts_d[i]) for i in range(len(frames)) if sts_h[i] != sts_d[i]]
+        assert not diff, diff[:20]
+        assert outs_h == outs_d
+        assert 0 < sum(1 for s in sts_d if s == 0) < len(frames)
+        # a frame whose blocks end without a last block, cut exactly behind a block: the unit that runs to the frame's end reports it
+        name, comp, *_ = max(corpus, key=lambda it: it[2])
+        rc, _, _, tr = oracle.decode_frame(comp, cap=2 << 20, want_trace=True)
+        assert rc == 0 and len(tr["blocks"]) > 2
+        _plan_by_blocks(c)
+        for cut in range(len(comp) - 40, len(comp) - 4):
+            (_,), (sd,) = z.decode_frames([comp[:cut]], c, device_plan=True)
+            (_,), (sh,) = z.decode_frames([comp[:cut]], c)
+            assert sd == sh != 0, (cut, sd, sh)
+    finally:
+        c.close()
+
+
+def test_device_planner_large_frames_stay_on_the_device(oracle):
+    """Frames of 9 and 20 MiB (72 and 160 blocks; the library's own threshold) beside small ones, the compressed blob resident
+    on the device: mzd_batch_upload_frames plans them there -- no copy back to the host planner -- and the frames decode to the
+    oracle's bytes; the layout is the host planner's."""
+    import torch
+    from tools import synth_binding as sb
+    datas = [sb.generate(sb.TEXT, 71, (9 << 20) + 12345), sb.generate(sb.EXP, 72, 20 << 20), sb.generate(sb.TEXT, 73, 70000), b""]
+    frames = [sb.compress(d, sb.MODE_FULL)[0] for d in datas]
+    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+    lens = np.array([len(f) for f in frames], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    c = z.Context(0)
+    d_in = torch.zeros(blob.size + 128, dtype=torch.uint8, device="cuda")
+    d_in[64:64 + blob.size].copy_(torch.from_numpy(blob))
+    rb = c.upload_frames(int(blob.size), offs, lens, device_in_ptr=d_in.data_ptr() + 64)
+    try:
+        p = z.Plan(device_tables=True)
+        for f in frames:
+            assert p.add_frame(f)[0] == 0
+        b = p.finalize()
+        lo, lc = rb.frame_layout()
+        assert [int(x) for x in lo] == [int(b.frames[i].out_offset) for i in range(b.n_frames)]
+        assert [int(x) for x in lc] == [int(b.frames[i].out_capacity) for i in range(b.n_frames)]
+        assert rb.out_size == b.out_size
+        rb.run()
+        out, st, ln = rb.download()
+        assert (st == 0).all() and [int(x) for x in ln] == [len(d) for d in datas]
+        for i, d in enumerate(datas):
+            assert out[int(lo[i]):int(lo[i]) + len(d)].tobytes() == d, i
+        p.close()
+    finally:
+        rb.free()
+        c.close()
+
+
 def test_device_planner_edge_batches(ctx):
     """Empty batch, empty frame, frame range outside the blob."""
     rb = ctx.upload_frames(b"", [], [])
