@@ -86,10 +86,10 @@ def parse():
                     "(128 KiB), large frames are: block mode spells an origin with three passes instead of four when offsets stay below 8 MiB")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--traffic-from", default="", help="JSON written by tools/profile_round.sh in the same gpurun "
-                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: profiles/r4_traffic_<workload>.json. "
+                    "(FETCH_SIZE / WRITE_SIZE per kernel from separate --pmc passes); default: the newest profiles/r<N>_traffic_<workload>.json. "
                     "Quoted only if its kernel_src_sha16 and workload match this run")
     ap.add_argument("--issue-from", default="", help="JSON written by tools/profile_counters.sh (SQ counters per kernel); default: "
-                    "profiles/r4_issue_<workload>.json; quoted under the same condition")
+                    "the newest profiles/r<N>_issue_<workload>.json; quoted under the same condition")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured copy ceiling (mzd_measure_copy)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (the other BASELINE configs, real data, the "
                     "8192-frame shard and one large frame, measured in the same process after the headline; only the default headline "
@@ -627,15 +627,23 @@ def main():
                        f"same device sources ({j.get('kernel_src_sha16')}) and workload")
 
         traffic = None
-        tj, traffic_note = stamped(a.traffic_from or os.path.join(ROOT, "profiles", f"r4_traffic_{wl_tag}.json"), "traffic")
+        def newest(kind):
+            """profiles/r<N>_<kind>_<workload>.json of the latest round that has one"""
+            import glob
+            import re
+            found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}_{wl_tag}.json")),
+                           key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)) if re.match(r"r(\d+)_", os.path.basename(p)) else -1)
+            return found[-1] if found else os.path.join(ROOT, "profiles", f"r5_{kind}_{wl_tag}.json")
+
+        tj, traffic_note = stamped(a.traffic_from or newest("traffic"), "traffic")
         if tj:
             traffic = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in tj["kernels"].items() if k != "k_init")
             traffic_note += "; FETCH_SIZE (raw; gfx950 under-counts wide streaming reads up to 2x) + WRITE_SIZE summed over the pass's kernels"
         # what each kernel keeps busy inside the CU: the path is latency- and issue-bound, an HBM fraction alone does not show progress
-        ij, issue_note = stamped(a.issue_from or os.path.join(ROOT, "profiles", f"r4_issue_{wl_tag}.json"), "issue")
+        ij, issue_note = stamped(a.issue_from or newest("issue"), "issue")
         issue = {"source": issue_note}
         if ij:
-            issue["kernels"] = {k: {f: v[f] for f in ("valu_wave_insts", "valu_frac", "lds_pipe_frac", "ta_busy_frac", "kernel_cycles") if f in v}
+            issue["kernels"] = {k: {f: v[f] for f in ("valu_wave_insts", "valu_frac", "lds_pipe_frac", "ta_busy_frac", "l2_hit_frac", "kernel_cycles") if f in v}
                                 for k, v in ij["kernels"].items()}
             issue["note"] = ij.get("note")
         roof = {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,

@@ -1,6 +1,5 @@
-cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-pick() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['roofline']['kernel_ms'], d['bit_exact'])" "$1"; }
-timeout 100 python bench.py --cpu-seconds 0 --no-ceiling --steps 10 2>/dev/null | pick "cfg4 default(q4)"
-timeout 100 python bench.py --cpu-seconds 0 --no-ceiling --steps 10 --seq-variant 3 2>/dev/null | pick "cfg4 pipe"
-timeout 100 python bench.py --cpu-seconds 0 --no-ceiling --steps 10 --seq-variant 1 2>/dev/null | pick "cfg4 k_seq"
+# the GPU suite, the default bench line (with its `secondary` object) and the fuzz soak on the current sources
+cd ${GRAFT_REPO_ROOT:-$PWD}; mkdir -p gpurun_out
+timeout 2700 python3 -m pytest tests -m gpu -q 2>&1 | tail -6 | tee gpurun_out/r5_pytest_gpu.log
+timeout 900 python3 bench.py > gpurun_out/r5_default_bench.json 2> gpurun_out/r5_default_bench.err; tail -c 600 gpurun_out/r5_default_bench.json
+timeout 1500 python3 tools/fuzz_soak.py ${1:-60000} 5 2>&1 | tail -25 | tee gpurun_out/r5_fuzz_soak.txt

@@ -7,13 +7,15 @@
 # Copy what is to be kept into profiles/ (gpurun_out/ is scratch).
 # usage: tools/profile_round.sh <tag> <config> [extra bench flags]
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r3}
+TAG=${1:-r5}
 CFG=${2:-4}
 shift $(( $# < 2 ? $# : 2 ))
 EXTRA="$@"
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --cpu-seconds 0 --no-ceiling $EXTRA"
+# (--no-verify: the profiled process launches exactly steps + warmup = 7 passes; the verification pass -- an eighth launch of every
+# kernel -- belongs to the bench run at the end, which is not profiled)
+B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --cpu-seconds 0 --no-ceiling --no-verify $EXTRA"
 for k in stats fetch write; do rm -rf $R/gpurun_out/${TAG}_cfg${CFG}_$k; done
 LOG=$R/gpurun_out/${TAG}_cfg${CFG}_rocprof.log
 : > $LOG

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>_cfg<N>_pmc{A,B,C} (tools/profile_counters.sh) -> gpurun_out/<tag>_cfg<N>_sq_counters.csv: per kernel,
+"""gpurun_out/<tag>_cfg<N>_pmc{A,B,C,D} (tools/profile_counters.sh) -> gpurun_out/<tag>_cfg<N>_sq_counters.csv: per kernel,
 per pass of the hot path (sum over the kernel's launches of a pass), one column per counter; and
 gpurun_out/<tag>_issue_cfg<N>.json: what each kernel keeps busy INSIDE the CU (bench.py's roofline.issue), stamped like the
 traffic file with the hash of the device sources and the workload."""
@@ -12,7 +12,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 cmd = sys.argv[4] if len(sys.argv) > 4 else ""
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 order = []
-for grp in "ABC":
+for grp in "ABCD":
     fs = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_cfg{cfg}_pmc{grp}", "*", "*_counter_collection.csv"))
     if not fs:
         continue
@@ -47,7 +47,8 @@ for k in sorted(agg):
                 "lds_insts": int(c.get("SQ_INSTS_LDS", 0)), "branch_insts": int(c.get("SQ_INSTS_BRANCH", 0)),
                 "valu_frac": round(c.get("SQ_INSTS_VALU", 0) * 2 / (N_SIMD * cyc), 4),
                 "lds_pipe_frac": round(c.get("SQ_LDS_IDX_ACTIVE", 0) / busy, 4) if busy else None,
-                "ta_busy_frac": round(c.get("TA_TA_BUSY_sum", 0) / (256 * cyc), 4)}
+                "ta_busy_frac": round(c.get("TA_TA_BUSY_sum", 0) / (256 * cyc), 4),
+                "l2_hit_frac": round(c.get("TCC_HIT_sum", 0) / (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)), 4) if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) else None}
 m = re.search(r"--frames(?:-per-gpu)? (\d+)", cmd)
 frames = int(m.group(1)) if m else {"2": 4096, "3": 4096, "4": 65536}.get(cfg)
 m = re.search(r"--frame-bytes (\d+)", cmd)
