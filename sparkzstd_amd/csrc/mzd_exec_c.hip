@@ -758,6 +758,12 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
 // block of frame f, 256 lanes x 16 bytes per instruction, four loads in flight per lane before the stores; chunk 0 reports the
 // frame.  A block is at most 128 KiB: eight chunks.
 constexpr uint32_t kCopyChunk = 16384, kCopyChunksPerBlock = kBlockMax / kCopyChunk;
+#ifndef MZD_COPY_NT
+#define MZD_COPY_NT 1
+#endif
+// the copy's loads and stores with the nt bit (both streams are touched once): 0.169 -> 0.164 ms for BASELINE config 2, 0.80 -> 0.85 of
+// the copy ceiling measured beside it (profiles/r5_copy_nt.txt)
+constexpr bool kCopyNt = MZD_COPY_NT != 0;
 __global__ __launch_bounds__(256) void k_copy_blocks(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                      const DBlock *__restrict__ blocks, int32_t *frame_status, uint64_t *frame_out_len,
                                                      const uint32_t *__restrict__ order, uint32_t first, uint32_t n_frames)
@@ -792,19 +798,19 @@ __global__ __launch_bounds__(256) void k_copy_blocks(const uint8_t *__restrict__
                 const uint8_t *src = in + b.src_off + lo;
                 uint32_t i = tid;
                 for (; i + 768 < n16; i += 1024) {
-                    const U128U v0 = *(const U128U *)(src + 16 * i), v1 = *(const U128U *)(src + 16 * (i + 256));
-                    const U128U v2 = *(const U128U *)(src + 16 * (i + 512)), v3 = *(const U128U *)(src + 16 * (i + 768));
-                    *(U128U *)(dst + 16 * i) = v0;
-                    *(U128U *)(dst + 16 * (i + 256)) = v1;
-                    *(U128U *)(dst + 16 * (i + 512)) = v2;
-                    *(U128U *)(dst + 16 * (i + 768)) = v3;
+                    const U128U v0 = ld128u_once<kCopyNt>(src + 16 * i), v1 = ld128u_once<kCopyNt>(src + 16 * (i + 256));
+                    const U128U v2 = ld128u_once<kCopyNt>(src + 16 * (i + 512)), v3 = ld128u_once<kCopyNt>(src + 16 * (i + 768));
+                    st128u_once<kCopyNt>(dst + 16 * i, v0);
+                    st128u_once<kCopyNt>(dst + 16 * (i + 256), v1);
+                    st128u_once<kCopyNt>(dst + 16 * (i + 512), v2);
+                    st128u_once<kCopyNt>(dst + 16 * (i + 768), v3);
                 }
                 for (; i < n16; i += 256) *(U128U *)(dst + 16 * i) = *(const U128U *)(src + 16 * i);
                 for (uint32_t j = (n16 << 4) + tid; j < n; j += 256) dst[j] = src[j];
             } else {
                 const uint32_t v = in[b.src_off] * 0x01010101u;
                 const U128U f{v, v, v, v};
-                for (uint32_t i = tid; i < n16; i += 256) *(U128U *)(dst + 16 * i) = f;
+                for (uint32_t i = tid; i < n16; i += 256) st128u_once<kCopyNt>(dst + 16 * i, f);
                 for (uint32_t j = (n16 << 4) + tid; j < n; j += 256) dst[j] = (uint8_t)v;
             }
         }

@@ -55,6 +55,15 @@ __device__ __forceinline__ U128U ld128u_once(const uint8_t *p)
     return U128U{v.x, v.y, v.z, v.w};
 }
 template <bool NT>
+__device__ __forceinline__ void st128u_once(uint8_t *p, const U128U &v)
+{
+    if (!NT) {
+        *(U128U *)p = v;
+        return;
+    }
+    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4_u *)p);
+}
+template <bool NT>
 __device__ __forceinline__ uint64_t ld64u_once(const uint8_t *p)
 {
     if (!NT) return ((const U64U *)p)->v;
