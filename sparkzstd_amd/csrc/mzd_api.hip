@@ -1924,8 +1924,13 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // tables of up to 32 cells -- config 4 -- the lane-per-stream kernel keeps its transposed bulk phase and many wavefronts per CU;
         // and with sequences to decode the Huffman kernel runs beside that stage, where k_huf_seg costs it more than it saves:
         // 8 192 x 1 MiB 26.3 -> 27.5 ms)
+        // (round 5: with sequences in the batch the Huffman kernel runs before or beside the sequence stage, whose round is 1.7 ms
+        // whatever the batch: a lane per stream is then one stream's latency, 0.4-0.7 ms from one wavefront per CU on, where the
+        // wavefront-per-stream kernel beside that stage took 1.70 ms -- the longer of the two for the 8 192-frame shard of configs[4] --
+        // and 0.66 against 0.45 ms in front of it at 16 384 frames; `profiles/r5_shard_huf.txt`)
+        const uint64_t seg_below = 64ull * (db->n_seq_tasks ? 1 : 8) * (uint64_t)std::max(ctx->num_cus, 1);
         const bool seg = hv == 2 || (hv == 0 && db->huf_out_bytes / streams >= 2048 &&
-                                     (streams < 64ull * 8 * (uint64_t)std::max(ctx->num_cus, 1) || (db->huf_slot_cells > 32 && db->n_seq_tasks == 0)));
+                                     (streams < seg_below || (db->huf_slot_cells > 32 && db->n_seq_tasks == 0)));
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
