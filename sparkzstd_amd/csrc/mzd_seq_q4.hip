@@ -318,10 +318,14 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             wk = from_spare(wk);
             rem1 = from_spare(rem1);
         }
-        uint32_t left = last_i;  // steps before the chain's last sequence
+        // steps before the chain's last sequence, TIMES 64: a term of the step's bit limit that must not bind before it is 0 (the last
+        // sequence takes the general step: no state update, sequences.go:178).  Counted in plain steps it bound as soon as it fell
+        // below a step's ~20 bits: the last 20-57 steps of EVERY chain took the general step (1 290 cycles for the whole wavefront,
+        // 119 of the 133 general steps per wavefront: 4 % of the kernel; `-DMZD_Q4_STATS_REASONS`)
+        uint32_t left = last_i << 6;
         uint32_t W0 = (woff + 127u) & ~127u;  // the hot loop counts the cursor in bits below this offset (see Q4_STEP)
         auto park = [&]() {  // the whole quad: constant cell, cursor 0 (the readable front slack; the ring check is always true for it)
-            st = 1; cb = dummy_addr; nbK = 31; woff = 0; wk = 0; W0 = 0; rem1 = 0x7FFFFFFFu; left = 0x7FFFFFFFu; live = false;
+            st = 1; cb = dummy_addr; nbK = 31; woff = 0; wk = 0; W0 = 0; rem1 = 0x7FFFFFFFu; left = 0x7FFFFFC0u; live = false;
         };
         if (!live) park();
         const uint32_t ringl128 = 512u + (uint32_t)offsetof(Q4Shared, ring) + ch * (kPipeRing + 8) + (uint32_t)kPipeRing;
@@ -438,10 +442,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         uint32_t n_general = 0;
         long long general_cycles = 0;
 #endif
-        // Steps [0, ncom) are more than 64 steps away from every chain's last sequence: "steps before the last" cannot be the
-        // smallest term of a step's limit (64 - k is at most 64) and the loop variant that runs them leaves it out.
+        // Steps [0, ncom) come before every chain's last sequence: "steps before the last" (times 64) cannot be the smallest term of a
+        // step's limit (64 - k is at most 64) and the loop variant that runs them leaves it out.
         const uint32_t min_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(live ? last_i : 0xFFFFFFFFu));
-        const uint32_t ncom = min_last >= 64u ? min((min_last - 64u) & ~3u, nmax & ~3u) : 0u;
+        const uint32_t ncom = min(min_last & ~3u, nmax & ~3u);
         while (i < nmax) {
             uint64_t smask = 0;
             {
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 tail0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail0);
                 tail1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail1);
                 polls = (uint32_t)__builtin_amdgcn_readfirstlane((int)polls);
-                if (live) left = last_i - i;
+                if (live) left = (last_i - i) << 6;
 #ifdef MZD_ABL_Q4_NOW1  /* ablations: timing experiments only, wrong results */
 #define MZD_Q4_W1 "s_nop 0\n\t"
 #else
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
                 if (i < ncom) {
                     Q4_HOT_LOOP("", ncom);
                 } else {
-                    Q4_HOT_LOOP("v_sub_u32 v67, %[r0], %[c]\n\tv_min3_u32 v85, v85, v67, %[left]\n\tv_add_u32 %[left], -1, %[left]\n\t", nmax);
+                    Q4_HOT_LOOP("v_sub_u32 v67, %[r0], %[c]\n\tv_min3_u32 v85, v85, v67, %[left]\n\tv_add_u32 %[left], -64, %[left]\n\t", nmax);
                 }
                 woff = W0 - (cur >> 3);
                 wk = cur & 7u;
