@@ -437,7 +437,20 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
             if (need) clow -= 1;
             lds_order();
         };
+#ifdef MZD_HUF_RING_UNALIGNED
         auto ring64 = [&](int x) -> uint64_t { return ((const U64U *)(myring + ((x + badj) & (kHufTRing - 1))))->v; };
+#else
+        // (the 8 bytes at the cursor as TWO aligned 8-byte reads and a funnel shift: a byte-misaligned 8-byte LDS read holds the pipe a
+        // cycle per active lane -- 64 cycles for this wavefront, six times per 64 symbols; the ring's spare bytes serve the second read
+        // of a cursor in the last 8)
+        auto ring64 = [&](int x) -> uint64_t {
+            const uint32_t a = (uint32_t)(x + badj) & (uint32_t)(kHufTRing - 1);
+            const uint64_t *p8 = (const uint64_t *)(myring + (a & ~7u));
+            const uint64_t lo = p8[0], hi = p8[1];
+            const uint32_t sh = 8u * (a & 7u);
+            return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+        };
+#endif
         if (__any(inb)) {
             fill(inb);
             fill(inb);
