@@ -196,13 +196,7 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
         // predefined or small tables costs what it has, not the batch's largest slot (real data: 40 us of staging per
         // workgroup for chains of a few hundred steps), and nothing divides by the slot size.
         const uint32_t nchw = min(nch, n_tasks - blockIdx.x * nch);
-        // (round 5: ALL of a chain's cells in flight at once -- 1 280 cells are 20 per lane; the loop was eight loads deep, three
-        // dependent memory round trips per chain and six chains per wavefront: 35 us of staging per workgroup, 2 % of its life.  Only
-        // the loaded words are kept across the wait, where each goes is computed again behind it.)
-#ifndef MZD_Q4_STAGE_UNR
-#define MZD_Q4_STAGE_UNR 20
-#endif
-        constexpr int UNR = MZD_Q4_STAGE_UNR;
+        constexpr int UNR = 8;
         for (uint32_t c = (uint32_t)wave; c < nchw; c += kQ4Threads / 64) {
             const uint32_t lg3 = desc[4 * c + 3];
             const uint32_t lgL = lg3 & 0xFF, lgM = (lg3 >> 8) & 0xFF, lgO = (lg3 >> 16) & 0xFF;
@@ -210,24 +204,24 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
             const uint32_t oL = desc[4 * c + 0], oM = desc[4 * c + 1], oO = desc[4 * c + 2];
             const uint32_t tot = nL + nM + nO, base = c * slot_cells;
             for (uint32_t i0 = (uint32_t)lane; i0 < tot; i0 += 64 * UNR) {
-                uint32_t e[UNR];
+                uint32_t e[UNR], n[UNR], c6k[UNR], dst[UNR];
+                bool ok[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; u++) {
                     const uint32_t i = i0 + 64u * u;
                     const uint32_t kind = i >= nL + nM ? 2u : (i >= nL ? 1u : 0u);
                     const uint32_t j = i - (kind == 2 ? nL + nM : (kind == 1 ? nL : 0u));
-                    e[u] = i < tot ? fse_entries[(kind == 2 ? oO : (kind == 1 ? oM : oL)) + j] : 0u;  // baseline(16) | nbits(8) | symbol(8)
+                    n[u] = kind == 2 ? nO : (kind == 1 ? nM : nL);
+                    ok[u] = i < tot;
+                    c6k[u] = kind;
+                    dst[u] = base + (kind == 2 ? off_of : (kind == 1 ? off_ml : 0u)) + j;
+                    e[u] = ok[u] ? fse_entries[(kind == 2 ? oO : (kind == 1 ? oM : oL)) + j] : 0u;  // baseline(16) | nbits(8) | symbol(8)
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; u++) {
-                    const uint32_t i = i0 + 64u * u;
-                    const uint32_t kind = i >= nL + nM ? 2u : (i >= nL ? 1u : 0u);
-                    const uint32_t j = i - (kind == 2 ? nL + nM : (kind == 1 ? nL : 0u));
-                    const uint32_t n = kind == 2 ? nO : (kind == 1 ? nM : nL);
-                    const uint32_t dst = base + (kind == 2 ? off_of : (kind == 1 ? off_ml : 0u)) + j;
                     const uint32_t baseline = e[u] & 0xFFFF, nb = (e[u] >> 16) & 0xFF, sym = e[u] >> 24;
-                    const uint32_t c6 = kind == 2 ? sym : seq_code6((int)kind, sym);
-                    if (i < tot) cells[dst] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n) >> (nb & 31)) | (c6 << 10));
+                    const uint32_t c6 = c6k[u] == 2 ? sym : seq_code6((int)c6k[u], sym);
+                    if (ok[u]) cells[dst[u]] = c6 == kPipeEscape ? (uint16_t)0 : (uint16_t)(((baseline + n[u]) >> (nb & 31)) | (c6 << 10));
                 }
             }
         }
