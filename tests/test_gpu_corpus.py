@@ -855,6 +855,44 @@ def test_device_planner_large_frames_stay_on_the_device(oracle):
         c.close()
 
 
+def test_trimmed_batch_keeps_its_output_and_nothing_else(ctx):
+    """mzd_batch_trim (ABI 7; what a reader calls once the statuses are down): the resident output can still be read -- in pieces
+    (mzd_batch_read_out), whole (mzd_batch_download), its layout asked for -- the batch cannot be run again, its scratch is gone
+    (mzd_batch_debug_read refuses), and mzd_batch_last_pass still says what the run took."""
+    from sparkzstd_amd import _lib
+    from sparkzstd_amd.api import MzdError
+    from tools import synth_binding as sb
+    datas = [sb.generate(sb.TEXT, 40 + i, 50000 + 7000 * i) for i in range(6)]
+    frames = [sb.compress(d, sb.MODE_FULL)[0] for d in datas]
+    p = z.Plan(device_tables=True)
+    for f in frames:
+        assert p.add_frame(f)[0] == 0
+    b = p.finalize()
+    rb = ctx.upload(b)
+    try:
+        rb.run()
+        flags = rb.last_pass()  # (the `ctx` fixture forces each execution kernel in turn)
+        _, st, ln = rb.download(want_out=False)
+        assert (st == 0).all()
+        rb.trim()
+        lo, _ = rb.frame_layout()
+        for i, d in enumerate(datas):
+            buf = np.empty(len(d), dtype=np.uint8)
+            rb.read_out(int(lo[i]), buf.ctypes.data, len(d))
+            assert buf.tobytes() == d
+        out, st2, ln2 = rb.download()
+        assert (st2 == 0).all() and (ln2 == ln).all() and out[int(lo[3]):int(lo[3]) + len(datas[3])].tobytes() == datas[3]
+        assert rb.last_pass() == flags
+        with pytest.raises(MzdError):
+            rb.run()
+        with pytest.raises(MzdError):
+            rb.debug_read(_lib.MZD_DEBUG_RECORDS, np.uint64, 0, 1)
+        rb.trim()  # (twice: nothing left to free)
+    finally:
+        rb.free()
+        p.close()
+
+
 def test_device_planner_edge_batches(ctx):
     """Empty batch, empty frame, frame range outside the blob."""
     rb = ctx.upload_frames(b"", [], [])
