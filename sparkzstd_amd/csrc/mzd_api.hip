@@ -1794,7 +1794,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             bool fused = blk_xc && db->n_blocks / blk_gs <= 20480u && !exp_env("MZD_EXP_BLK_SERIAL_PASSES");
             if (fused) {
                 const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat, 0u, blk_np, pstride, stride, db->d_planes};
-                k_exec_c<true><<<db->n_blocks * blk_np, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                k_exec_c<true, 8192><<<db->n_blocks * blk_np, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
                                                                   db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
             }
             for (uint32_t p = 0; p < (fused ? 0u : blk_np); p++) {
@@ -1802,7 +1802,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p, 0u, 0ull, 0ull, nullptr};
                 // (as many wavefronts as blocks: the ones beyond the job list exit)
                 if (blk_xc)
-                    k_exec_c<true><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                    k_exec_c<true, 8192><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
                                                              db->d_status, db->d_out_len, nullptr, 0u, bk);
                 else
                     k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
@@ -1857,8 +1857,19 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (exec_c) {
             size_t xc_extra_lds = 0;  // experiment: extra dynamic LDS per frame = fewer frames in flight per CU
             if (const char *e = exp_env("MZD_EXP_XC_LDS")) xc_extra_lds = (size_t)std::max(0, atoi(e));
-            k_exec_c<false><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
-                                                               db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
+            // Which ring (round 5, `profiles/r5_exec_ring.txt`): 8 KiB at 16 frames per CU serves 64 % of text's matches from LDS instead of
+            // 52 % and wins where the frames are all alike and long enough to have far matches (config 4: the execution stage of the
+            // split pass 13.9 -> 13.2 ms, the pass 18.27 -> 17.95; 8 192 x 1 MiB 23.6 -> 23.4; block mode, always: 1 x 1 GiB 18.8 -> 18.0);
+            // 4 KiB at 20 frames per CU where the frames in flight count -- heterogeneous batches, whose largest frames are serial jobs
+            // (real data 1 GiB 10.8 -> 12.0 ms with the large ring), and small frames (131 072 x 4 KiB 1.51 -> 1.59)
+            bool win8 = db->d_frame_order == nullptr && !db->seq_sorted && db->n_frames > 0 && db->out_size / db->n_frames >= 32768;
+            if (const char *e = exp_env("MZD_EXP_XC_WIN")) win8 = atoi(e) == 8192;
+            if (win8)
+                k_exec_c<false, 8192><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
+            else
+                k_exec_c<false, 4096><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
         if (exec_b) {

@@ -30,31 +30,19 @@
 
 namespace mzd {
 
-// MZD_XC_PREPLACE: a staged match is not kept in a stage area and copied by the passes -- the setup stores its bytes straight into
-// the window ring at the match's place (exact-length byte-misaligned stores), the passes leave them alone (table entry 0: a byte
-// is its own source).  No stage area: the 2 KiB it took go to a ring of 8 KiB at 17 frames per CU, and a match up to 7 040 bytes
-// back -- instead of 3 968 -- is served by the ring: a quarter fewer of the 64-byte sectors the kernel's time is made of.
-#ifndef MZD_XC_WIN
-#ifdef MZD_XC_PREPLACE
-#define MZD_XC_WIN 8192
-#else
-#define MZD_XC_WIN 4096
-#endif
-#endif
-constexpr uint32_t kXcWin = MZD_XC_WIN;  // window ring at LDS offset 0 of the frame's block (a power of two, 4 KiB at least)
+// The window ring's size WIN is a template parameter of the kernel (round 5): 4 KiB at 20 frames per CU for heterogeneous batches and
+// small frames, where the frames in flight count, 8 KiB at 16 frames per CU for batches of frames of one size from 32 KiB on and for
+// block mode, where the matches the ring serves count (text: 48 % of the matches lie beyond 4 KiB, 36 % beyond 8 KiB).
 constexpr uint32_t kXcLit = 512;       // literals of the current stretch
 constexpr uint32_t kXcStageMl = 32;    // longest match that is staged: 32 source bytes per sequence lane
-constexpr uint32_t kXcStage = 64 * kXcStageMl;
+// The staged matches PACKED: 8-byte slots dealt in lane order, ceil(ML / 8) per match (text: 31 staged matches of 8 bytes on average per
+// stretch = 45 slots), instead of 32 bytes per lane whether it stages anything or not -- 768 bytes instead of 2 048, which is what lets
+// an 8 KiB ring keep 16 frames on a CU (10.1 KB per frame).  A match that finds no slot is left to the pass, like one that is too long.
+constexpr uint32_t kXcStageSlots = 96;
+constexpr uint32_t kXcStage = 8 * kXcStageSlots;
 constexpr uint32_t kXcStretch = 1024;  // output bytes per stretch at most (8 passes)
 constexpr uint32_t kXcFlush = 512;     // 64 lanes x 8 bytes leave for the slab at a time
 constexpr uint32_t kXcPass = 128;
-#ifdef MZD_XC_PREPLACE
-// (bytes are stored into the ring up to a whole stretch AHEAD of the passes: what they replace -- positions 8 192 back -- must not
-// be anything a pass of the stretch may still read)
-constexpr int kXcNear = (int)kXcWin - (int)kXcStretch - (int)kXcPass;
-#else
-constexpr int kXcNear = (int)kXcWin - (int)kXcPass;  // a window match this close to its pass is served by the ring
-#endif
 #ifndef MZD_XC_OOR
 #define MZD_XC_OOR 0x00FF0000u
 #endif
@@ -64,24 +52,24 @@ constexpr uint32_t kXcOor = MZD_XC_OOR;   // an LDS address no workgroup has: st
 #define MZD_XC_NT 0
 #endif
 constexpr bool kXcNtRec = (MZD_XC_NT & 1) != 0, kXcNtLit = (MZD_XC_NT & 2) != 0, kXcNtStage = (MZD_XC_NT & 4) != 0;
-constexpr uint32_t kXcFarMark = 2 * kXcWin;   // table entry of a window match that is neither in the ring nor staged: | lane of its sequence
 
+template <uint32_t WIN>
 struct XcLds {
-    uint8_t win[kXcWin];
+    uint8_t win[WIN];               // window ring at LDS offset 0 of the frame's block (a power of two, 4 KiB at least)
     uint8_t lit[kXcLit];
-#ifndef MZD_XC_PREPLACE
     uint8_t stage[kXcStage];
-#endif
     uint32_t bits[kXcStretch / 32];   // heads, one bit per output byte of the stretch; a pass reads four dwords
     uint32_t table[132];              // [0] the run that continues from the stretch before, [1 + k] head k of the stretch
     uint32_t pad[4];
 };
-#ifndef MZD_XC_PREPLACE
-static_assert(offsetof(XcLds, stage) + kXcStage <= 2 * kXcWin, "the stage inside region 1");
-#endif
-static_assert(offsetof(XcLds, win) == 0 && offsetof(XcLds, lit) == kXcWin && offsetof(XcLds, bits) % 128 == 0 && sizeof(XcLds) % 16 == 0,
-              "ring = region 0, literals and stage inside region 0x1000, bitmap on a 128-byte boundary");
-static_assert(kXcStretch + kXcPass + kXcFlush <= kXcWin, "a window unit is issued before the ring wraps onto it");
+template <uint32_t WIN>
+constexpr bool xc_layout_ok()
+{
+    return offsetof(XcLds<WIN>, stage) + kXcStage <= 2 * WIN &&  // the stage inside region 1
+           offsetof(XcLds<WIN>, win) == 0 && offsetof(XcLds<WIN>, lit) == WIN && offsetof(XcLds<WIN>, bits) % 128 == 0 && sizeof(XcLds<WIN>) % 16 == 0 &&
+           kXcStretch + kXcPass + kXcFlush <= WIN;  // a window unit is issued before the ring wraps onto it
+}
+static_assert(xc_layout_ok<4096>() && xc_layout_ok<8192>(), "ring = region 0, literals and stage inside region 1, bitmap on a 128-byte boundary");
 
 #ifdef MZD_XC_STATS
 // tools/xc_stats.py: 0 tiles, 1 stretches, 2 passes, 3 extra fixed-point rounds, 4 passes resolved by pointer jumping,
@@ -96,26 +84,30 @@ __device__ unsigned long long g_xc_stats[16];
 #endif
 
 // bytes [flushed, upto) of the frame leave the window for the slab, byte by byte (block ends, unaligned remainders)
+template <uint32_t WIN>
 __device__ __noinline__ uint32_t xc_flush_bytes(const uint8_t *win, uint8_t *out, uint32_t flushed, uint32_t upto, int lane)
 {
-    for (uint32_t x = flushed + (uint32_t)lane; x < upto; x += 64) out[x] = win[x & (kXcWin - 1)];
+    for (uint32_t x = flushed + (uint32_t)lane; x < upto; x += 64) out[x] = win[x & (WIN - 1)];
     return upto;
 }
 // the 512-byte unit at `flushed` (or the bytes up to the next unit boundary) leaves for the slab; -> the new `flushed`
+template <uint32_t WIN>
 __device__ __forceinline__ uint32_t xc_flush_step(const uint8_t *win, uint8_t *out, uint32_t flushed, int lane)
 {
     if ((flushed & (kXcFlush - 1)) == 0) {
         const uint32_t x = flushed + 8u * (uint32_t)lane;
-        const uint64_t v = *(const uint64_t *)&win[x & (kXcWin - 1)];
+        const uint64_t v = *(const uint64_t *)&win[x & (WIN - 1)];
         ((U64U *)(out + x))->v = v;
         return flushed + kXcFlush;
     }
-    return xc_flush_bytes(win, out, flushed, (flushed + kXcFlush) & ~(kXcFlush - 1), lane);
+    return xc_flush_bytes<WIN>(win, out, flushed, (flushed + kXcFlush) & ~(kXcFlush - 1), lane);
 }
 // after a bulk write straight to the slab (Raw / RLE blocks, literal-only blocks): the window ring takes the last bytes of the
 // frame back from memory so that the next block's window matches find them
+template <uint32_t WIN>
 __device__ __noinline__ void xc_reload_window(uint8_t *win, const uint8_t *out, uint32_t outPos, int lane)
 {
+    constexpr uint32_t kXcWin = WIN;
     xb_wait_vm();  // the bulk stores are in memory (same CU: visible to the loads below)
     const uint32_t lo = outPos > kXcWin ? outPos - kXcWin : 0u;
     const uint32_t lo4 = (lo + 3u) & ~3u;
@@ -171,14 +163,18 @@ __device__ __noinline__ uint2 xc_resolve_in_pass(uint32_t va, uint32_t vb, int r
 // with sequences, from a block flagged kBjHead to the next; a Raw / RLE / literal-only block is a job of its own), `out_blob` is
 // the plane of this pass, and whatever lies before the segment's start S is read from the pass's pattern `bk.pat`: the ring is
 // preloaded with it, staged and far reads below S go to it.
-template <bool BM>
-__global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
+template <bool BM, uint32_t WIN = 4096>
+__global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
                                                   int32_t *frame_status, uint64_t *frame_out_len,
                                                   const uint32_t *__restrict__ order, uint32_t first, XbBlk bk)
 {
-    __shared__ __attribute__((aligned(128))) XcLds sh;
+    constexpr uint32_t kXcWin = WIN;
+    constexpr int kXcNear = (int)WIN - (int)kXcPass;  // a window match this close to its pass is served by the ring
+    constexpr uint32_t kXcFarMark = 2 * WIN;          // table entry of a window match that is neither in the ring nor staged: | lane of its sequence
+    typedef XcLds<WIN> XcLdsW;
+    __shared__ __attribute__((aligned(128))) XcLdsW sh;
     const uint8_t *const lds = (const uint8_t *)&sh;
     const int lane = threadIdx.x;
     uint32_t fidx, bi0 = 0;
@@ -224,10 +220,10 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
     // LDS addresses of the areas the predicated stores go to (the kernel's only shared object: its offset is what the
     // compiler assigned, normally 0; the region arithmetic below is relative to it)
     const uint32_t ldsBase = (uint32_t)(uintptr_t)&sh;
-    const uint32_t tabA = ldsBase + (uint32_t)offsetof(XcLds, table), bitsA = ldsBase + (uint32_t)offsetof(XcLds, bits);
+    const uint32_t tabA = ldsBase + (uint32_t)offsetof(XcLdsW, table), bitsA = ldsBase + (uint32_t)offsetof(XcLdsW, bits);
     for (int i = lane; i < 132; i += 64) sh.table[i] = 0u;
     if (lane < (int)(kXcStretch / 32)) sh.bits[lane] = 0u;
-    if (BM && S > 0 && !(jb.flags & kBjDirect)) xc_reload_window(sh.win, pat, S, lane);  // the ring's view of the frame before the segment
+    if (BM && S > 0 && !(jb.flags & kBjDirect)) xc_reload_window<WIN>(sh.win, pat, S, lane);  // the ring's view of the frame before the segment
     uint32_t bi = bi0;
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
     uint32_t vwmask = kXcWin - 1;
@@ -250,11 +246,11 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 error = MZD_ERR_DST_FULL;
                 break;
             }
-            flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);  // (same ring: the first 4 KiB of the block)
+            flushed = xc_flush_bytes<WIN>(sh.win, out, flushed, outPos, lane);  // (same ring: the first 4 KiB of the block)
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
-            if (!BM) xc_reload_window(sh.win, out, outPos, lane);
+            if (!BM) xc_reload_window<WIN>(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -276,13 +272,13 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
         if (b.n_seq == 0) {
             // no sequences: the block IS its literals (sequence_execution.go:55-59) -- unless the Huffman stage has
             // already put them in place
-            flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);
+            flushed = xc_flush_bytes<WIN>(sh.win, out, flushed, outPos, lane);
             if (!b.pad[0]) {
                 if (litRle) xb_bulk_fill(out + outPos, lits[0], b.lit_regen, lane);
                 else xb_bulk_copy(out + outPos, lits, b.lit_regen, lane);
             }
             outPos += b.lit_regen;
-            if (!BM) xc_reload_window(sh.win, out, outPos, lane);
+            if (!BM) xc_reload_window<WIN>(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
             continue;
         }
@@ -383,14 +379,10 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             const bool mHere = T.ML > 0 && T.mstart < N.sEnd && T.mstart + T.ML > N.P;
             const uint32_t q0 = T.mstart - (uint32_t)T.off;
             const bool farm = mHere && T.off > kXcNear;
-#ifdef MZD_XC_PREPLACE
-            // stored into the ring by the setup: whole matches of whole tiles that do not run over the ring's end
-            const bool stg = farm && P == T.start && sEnd == T.E && T.ML >= 3 && T.ML <= kXcStageMl && q0 + T.ML <= confirmed &&
-                             (T.mstart & (kXcWin - 1)) + kXcStageMl <= kXcWin;
-#else
             // (block mode: a source that straddles the segment's start is left to the pass)
-            const bool stg = farm && T.ML <= kXcStageMl && q0 + T.ML <= confirmed && (!BM || q0 >= S || q0 + T.ML <= S);
-#endif
+            bool stg = farm && T.ML <= kXcStageMl && q0 + T.ML <= confirmed && (!BM || q0 >= S || q0 + T.ML <= S);
+            // (slots in lane order: the staged matches are the lanes whose slots end inside the stage -- a prefix of the candidates)
+            if (wave_incl_scan_dpp(stg ? (T.ML + 7u) >> 3 : 0u) > kXcStageSlots) stg = false;
             const uint8_t *const rb = BM && q0 < S ? pat : (const uint8_t *)out;
             N.stg = wave_ballot(stg);
             N.stg2 = wave_ballot(stg && T.ML > 16);
@@ -418,6 +410,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             (void)xc_t2;
             const uint32_t P0 = C.P, sEnd = C.sEnd, sLen = sEnd - P0, la = C.la;
             const bool stg = (C.stg >> lane) & 1;
+            const uint32_t n8 = stg ? (T.ML + 7u) >> 3 : 0u;
+            const uint32_t stgA = (uint32_t)offsetof(XcLdsW, stage) + 8u * (wave_incl_scan_dpp(n8) - n8);  // where this lane's staged bytes go
             // the heads of the stretch: table entries and bitmap bits.  (A lambda instantiated on both paths below: a `bool` that
             // merges from two branches travels through a VGPR as 0 / 1 and is compared again)
             auto write_heads = [&](bool litIn, bool mIn) {
@@ -430,11 +424,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 const uint32_t eL = ((T.lsrc - la - T.lstart) & (kXcWin - 1)) | kXcWin;
                 uint32_t eM = (uint32_t)(-T.off) & (kXcWin - 1);
                 if (T.off > kXcNear) eM = kXcFarMark | (uint32_t)lane;
-#ifdef MZD_XC_PREPLACE
-                if (stg) eM = 0u;  // its bytes are in the ring already: a byte is its own source
-#else
-                if (stg) eM = (((uint32_t)offsetof(XcLds, stage) + kXcStageMl * (uint32_t)lane - T.mstart) & (kXcWin - 1)) | kXcWin;
-#endif
+                if (stg) eM = ((stgA - T.mstart) & (kXcWin - 1)) | kXcWin;
                 const uint32_t hbm = hb + (litIn ? 1u : 0u);
                 xc_lds_write_b32(litIn ? tabA + 4u * hb : kXcOor, eL);
                 xc_lds_write_b32(mIn ? tabA + 4u * hbm : kXcOor, eM);
@@ -451,10 +441,8 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
                 if (contL) sh.table[0] = ((T.lsrc - la - T.lstart) & (kXcWin - 1)) | kXcWin;
                 if (contM) {
                     uint32_t e = (uint32_t)(-T.off) & (kXcWin - 1);
-#ifndef MZD_XC_PREPLACE
-                    if (stg) e = (((uint32_t)offsetof(XcLds, stage) + kXcStageMl * (uint32_t)lane - T.mstart) & (kXcWin - 1)) | kXcWin;
+                    if (stg) e = ((stgA - T.mstart) & (kXcWin - 1)) | kXcWin;
                     else
-#endif
                     if (T.off > kXcNear) e = kXcFarMark | (uint32_t)lane;
                     sh.table[0] = e;
                 }
@@ -466,55 +454,16 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             xb_wait_vm();  // the staged bytes, the literals and the next tile's records are here; so is every window unit issued before
 #endif
             confirmed = uni(flushed);
-#ifdef MZD_XC_PREPLACE
-            if (C.stg) {
-                const uint32_t ML = T.ML, d = ldsBase + (T.mstart & (kXcWin - 1));
-                // matches of 17 to 32 bytes first, one lane at a time, as four 8-byte stores: what runs over a match's end lands on
-                // bytes that are made later -- by a pass, or by one of the exact stores below (later in program order)
-                for (uint64_t m2 = C.stg2; m2; m2 &= m2 - 1) {
-                    if (lane == __builtin_ctzll(m2)) {
-                        xc_lds_write_b64(d, C.sv.x, C.sv.y);
-                        xc_lds_write_b64(d + 8, C.sv.z, C.sv.w);
-                        xc_lds_write_b64(d + 16, C.sv2.x, C.sv2.y);
-                        xc_lds_write_b64(d + 24, C.sv2.z, C.sv2.w);
-                    }
-                }
-                // exact lengths, by size class (address-predicated: the other lanes store nowhere):
-                //   8..16 bytes: 8 at the start, 8 ending at the end;  4..7: 4 and 4;  3: 2 and 1
-                const bool c8 = stg && ML >= 8 && ML <= 16, c4 = stg && ML >= 4 && ML < 8, c3 = stg && ML == 3;
-                // the 8 source bytes that END at byte ML of the 16 in sv (ML 9..16: a shift of 1..8 bytes)
-                // (as 64-bit shifts of register pairs: a select chain over the four dwords of `sv` was turned into an indexed access of
-                // the plan in scratch memory -- 192 bytes per lane, every reload behind all of the wavefront's memory operations: 19.6 ms)
-                const uint32_t sh8 = ML - 8;
-                const uint64_t slo = (uint64_t)C.sv.x | ((uint64_t)C.sv.y << 32), shi = (uint64_t)C.sv.z | ((uint64_t)C.sv.w << 32);
-                const uint32_t b8 = 8u * (sh8 & 7u);
-                const uint64_t t8 = sh8 >= 8 ? shi : (b8 ? (slo >> b8) | (shi << (64u - b8)) : slo);
-                const uint32_t t8lo = (uint32_t)t8, t8hi = (uint32_t)(t8 >> 32);
-                // the 4 bytes that end at byte ML of the first 8 (ML 4..7: a shift of 0..3 bytes)
-                const uint32_t t4 = __builtin_amdgcn_alignbyte(C.sv.y, C.sv.x, (ML - 4) & 3);
-                // (under exec masks: an out-of-range 8-byte store is not free for the LDS pipe the way a 4-byte one is -- with these
-                // four predicated by address the kernel took 20.6 ms)
-                if (c8) {
-                    xc_lds_write_b64(d, C.sv.x, C.sv.y);
-                    xc_lds_write_b64(d + sh8, t8lo, t8hi);
-                }
-                if (c4) {
-                    xc_lds_write_b32(d, C.sv.x);
-                    xc_lds_write_b32(d + ML - 4, t4);
-                }
-                if (wave_any(c3)) {
-                    if (c3) {
-                        sh.win[T.mstart & (kXcWin - 1)] = (uint8_t)C.sv.x;
-                        sh.win[(T.mstart + 1) & (kXcWin - 1)] = (uint8_t)(C.sv.x >> 8);
-                        sh.win[(T.mstart + 2) & (kXcWin - 1)] = (uint8_t)(C.sv.x >> 16);
-                    }
+            // (every lane stores its 16 bytes: what a lane without a staged match leaves in its slot is never looked at)
+            {
+                uint8_t *const sp = (uint8_t *)&sh + stgA;
+                if (stg) *(uint2 *)sp = make_uint2(C.sv.x, C.sv.y);
+                if (stg && T.ML > 8) *(uint2 *)(sp + 8) = make_uint2(C.sv.z, C.sv.w);
+                if (C.stg2) {
+                    if (stg && T.ML > 16) *(uint2 *)(sp + 16) = make_uint2(C.sv2.x, C.sv2.y);
+                    if (stg && T.ML > 24) *(uint2 *)(sp + 24) = make_uint2(C.sv2.z, C.sv2.w);
                 }
             }
-#else
-            // (every lane stores its 16 bytes: what a lane without a staged match leaves in its slot is never looked at)
-            *(uint4 *)&sh.stage[kXcStageMl * lane] = make_uint4(C.sv.x, C.sv.y, C.sv.z, C.sv.w);
-            if (C.stg2) *(uint4 *)&sh.stage[kXcStageMl * lane + 16] = make_uint4(C.sv2.x, C.sv2.y, C.sv2.z, C.sv2.w);
-#endif
             if (!litRle) *(uint64_t *)&sh.lit[8 * lane] = C.lv;
             const bool farwin = C.farwin != 0;
             XC_STAT(1, 1);
@@ -547,7 +496,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
 #ifdef MZD_ABL_XC_NOFLUSH
                 while (P0 - fl >= kXcFlush) fl += kXcFlush;
 #else
-                while (P0 - fl >= kXcFlush) fl = uni(xc_flush_step(sh.win, out, fl, lane));
+                while (P0 - fl >= kXcFlush) fl = uni(xc_flush_step<WIN>(sh.win, out, fl, lane));
 #endif
                 flushed = fl;
             }
@@ -733,7 +682,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_c(const uint8_t *__restrict__ in
             H0 = n0; H1 = n1; H2 = n2;
         }
     }
-    if (error == MZD_OK) flushed = xc_flush_bytes(sh.win, out, flushed, outPos, lane);
+    if (error == MZD_OK) flushed = xc_flush_bytes<WIN>(sh.win, out, flushed, outPos, lane);
     if (BM) {
         // an offset beyond the produced data (the one defect the scan cannot see): the frame ends at its first such block
         if (lane == 0 && error != MZD_OK && bk.pass == 0) atomicMin(&bk.bframes[fidx].first_bad, bi);
