@@ -399,12 +399,6 @@ int mzd_debug_backbits(mzd_ctx *ctx, const uint8_t *stream, uint32_t len, const 
  * default) = off.  For the parity tests only: a decoded frame never depends on it. */
 int mzd_debug_force_fixup_bail(mzd_ctx *ctx, uint32_t step);
 
-/* Test hook of block mode's slices (mzd_exec_blk.hip: the jobs in k groups by their place in their frame, the fix-up walk of a
- * group beside the passes of the next): k = 1..8 makes every block-mode pass of this context use k slices whatever the batch's
- * size and the execution variant, 0 (the default) leaves the choice to mzd_batch_run.  For the parity tests only: a decoded
- * frame never depends on it. */
-int mzd_debug_force_block_slices(mzd_ctx *ctx, uint32_t k);
-
 /* Test hook of the device planner (mzd_parse.hip): mzd_batch_upload_frames parses a frame of `frame_bytes` compressed bytes and
  * more block by block -- a lane per block after a serial walk of the block headers -- instead of in one lane; 0 (the default) =
  * the library's own threshold (1 MiB).  For the parity tests: small frames through the large-frame path.  ABI 7. */

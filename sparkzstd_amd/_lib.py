@@ -24,7 +24,7 @@ EXPORTS = [
     "mzd_plan_finalize", "mzd_plan_frame_status", "mzd_plan_set_device_tables", "mzd_batch_read_fse_table", "mzd_batch_read_huf_table",
     "mzd_batch_upload_frames", "mzd_batch_out_size", "mzd_batch_frame_layout",
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
-    "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail", "mzd_debug_force_block_slices",
+    "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
     "mzd_batch_last_pass", "mzd_batch_trim", "mzd_debug_plan_unit_bytes",
 ]
 MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT = 2, 4, 8, 16
@@ -168,7 +168,6 @@ def load():
         "mzd_batch_debug_read": (i32, [vp, vp, i32, u64, vp, u64]),
         "mzd_debug_backbits": (i32, [vp, vp, u32, vp, u32, vp, vp]),
         "mzd_debug_force_fixup_bail": (i32, [vp, u32]),
-        "mzd_debug_force_block_slices": (i32, [vp, u32]),
         "mzd_batch_last_pass": (u32, [vp]),
         "mzd_batch_trim": (i32, [vp, vp]),
         "mzd_debug_plan_unit_bytes": (i32, [vp, u64]),

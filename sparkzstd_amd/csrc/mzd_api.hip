@@ -38,7 +38,6 @@ struct mzd_ctx {
     size_t runs = 0;
     bool timing = true;
     bool attr_set = false;
-    uint32_t test_blk_slices = 0;  // mzd_debug_force_block_slices: block mode in this many slices (0: mzd_batch_run's choice)
     uint32_t test_fixup_bail = 0;  // mzd_debug_force_fixup_bail: workgroup 1 of every frame gives up at this step of the fix-up walk
     uint64_t test_large_frame = 0; // mzd_debug_plan_unit_bytes: frames of this many bytes and more are planned block by block (0: the default)
 };
@@ -142,7 +141,7 @@ struct mzd_dbatch {
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
     // block mode of the execution stage (few large frames; mzd_exec_blk.hip): allocated by the first run that takes it
     BJob *d_jobs = nullptr;
-    uint32_t *d_heads = nullptr;  // kBlkMaxSlices lists, n_blocks + 2 words apart: [0] number of jobs, [1 + j] first block of job j; behind them the walk's steps before each slice, per frame
+    uint32_t *d_heads = nullptr;  // [0] number of jobs, [1 + j] first block of job j
     BFrame *d_bframes = nullptr;
     uint32_t *d_fixdone = nullptr;  // block mode: steps each fix-up workgroup of a frame finished (64 per frame)
     size_t cap_fixdone = 0;
@@ -1600,16 +1599,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             }
         }
     }
-    // Slices (round 5): the jobs in K groups by their place in their frame, the walk of slice s on the second stream beside the passes
-    // of slice s + 1 -- for batches whose passes are several rounds of the chip (a pass is bound by the chip, the walk by its hand-offs
-    // and its gathers: they overlap); with one round of jobs a slice would end no sooner than the whole.
-    uint32_t blk_slices = 1;
-    if (blk && ctx->opt.exec_variant == 0) {
-        const uint64_t rounds = (uint64_t)(db->n_blocks / blk_gs) * blk_np / (16u * (uint32_t)std::max(ctx->num_cus, 1));
-        blk_slices = (uint32_t)std::min<uint64_t>(kBlkMaxSlices, std::max<uint64_t>(1, rounds / 2));
-        if (const char *e = exp_env("MZD_EXP_BLK_SLICES")) blk_slices = (uint32_t)std::min<int>(kBlkMaxSlices, std::max(1, atoi(e)));
-    }
-    if (blk && ctx->test_blk_slices) blk_slices = ctx->test_blk_slices;
     if (blk) {
         auto ensure = [&](auto *&ptr, size_t &cap, size_t bytes) -> hipError_t {
             if (ptr && cap >= bytes) return hipSuccess;
@@ -1625,7 +1614,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // (passes - 1 copies of the output layout + the patterns: a batch that leaves no room for them walks its frames' blocks
         // in order instead)
         const bool got = ensure(db->d_jobs, db->cap_jobs, (size_t)std::max<uint32_t>(db->n_blocks, 1) * sizeof(BJob)) == hipSuccess &&
-                         ensure(db->d_heads, db->cap_heads, ((size_t)kBlkMaxSlices * ((size_t)db->n_blocks + 2) + (size_t)kBlkMaxSlices * db->n_frames) * 4) == hipSuccess &&
+                         ensure(db->d_heads, db->cap_heads, ((size_t)db->n_blocks + 2) * 4) == hipSuccess &&
                          ensure(db->d_bframes, db->cap_bframes, (size_t)db->n_frames * sizeof(BFrame)) == hipSuccess &&
                          ensure(db->d_fixdone, db->cap_fixdone, (size_t)std::min<uint32_t>(n_walk, 1024u) * kFixMaxG * sizeof(uint32_t)) == hipSuccess &&
                          ensure(db->d_walk, db->cap_walk, ((size_t)db->n_frames + 1) * 4) == hipSuccess &&
@@ -1786,12 +1775,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (blk) {
             // (the whole batch: block mode never splits)
             const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
-            const uint32_t K = blk_slices, hstride = db->n_blocks + 2;
-            uint32_t *const slice_steps = db->d_heads + (size_t)kBlkMaxSlices * hstride;
-            for (uint32_t sl = 0; sl < K; sl++) (void)hipMemsetAsync(db->d_heads + (size_t)sl * hstride, 0, 4, st);
+            (void)hipMemsetAsync(db->d_heads, 0, 4, st);
             (void)hipMemsetAsync(db->d_walk, 0, 4, st);
-            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads, db->d_walk,
-                                                     K, hstride, slice_steps);
+            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads, db->d_walk);
             if (db->pat_n != (uint32_t)(blk_maxcap + 64) || db->pat_np != blk_np) {
                 k_blk_pattern<<<(uint32_t)((blk_maxcap + 64 + 1023) / 1024), 256, 0, st>>>(db->d_pat, pstride, (uint32_t)(blk_maxcap + 64), blk_np);
                 db->pat_n = (uint32_t)(blk_maxcap + 64);
@@ -1805,30 +1791,23 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // whatever runs beside it), and the passes of a job read the same records and literals
             // (16 x 128 MiB, 16 384 jobs: 31.1 -> 30.4 ms; 64 x 128 MiB, 65 536 jobs: 83.3 -> 85.5 -- a full chip gains nothing from the
             // passes side by side and loses by their interleaving: a launch per pass from 20 480 jobs on)
-            bool fused = blk_xc && db->n_blocks / blk_gs / K <= 20480u && !exp_env("MZD_EXP_BLK_SERIAL_PASSES");
-            if (const char *e = exp_env("MZD_EXP_BLK_FUSED")) fused = blk_xc && atoi(e) != 0;
-            // (a slice's job list holds its jobs only: the launch is sized for the blocks a slice can have -- a K-th of every frame's,
-            // rounded up to a job start at either end -- and the wavefronts beyond the list exit)
-            const uint32_t slice_blocks = K == 1 ? db->n_blocks : std::min<uint64_t>(db->n_blocks, (uint64_t)db->n_blocks / K + (uint64_t)db->n_frames * (blk_gs + 1));
-            auto launch_passes = [&](uint32_t sl) {
-                const uint32_t *const heads = db->d_heads + (size_t)sl * hstride;
-                if (fused) {
-                    const XbBlk bk{db->d_jobs, heads, db->d_bframes, db->d_pat, 0u, blk_np, pstride, stride, db->d_planes};
-                    k_exec_c<true, 8192><<<slice_blocks * blk_np, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
-                                                                           db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
-                }
-                for (uint32_t p = 0; p < (fused ? 0u : blk_np); p++) {
-                    uint8_t *plane = p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride;
-                    const XbBlk bk{db->d_jobs, heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p, 0u, 0ull, 0ull, nullptr};
-                    // (as many wavefronts as blocks: the ones beyond the job list exit)
-                    if (blk_xc)
-                        k_exec_c<true, 8192><<<slice_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
-                                                                      db->d_status, db->d_out_len, nullptr, 0u, bk);
-                    else
-                        k_exec_b<true><<<slice_blocks, 64, xb_extra_lds, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
-                                                                           db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
-                }
-            };
+            bool fused = blk_xc && db->n_blocks / blk_gs <= 20480u && !exp_env("MZD_EXP_BLK_SERIAL_PASSES");
+            if (fused) {
+                const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat, 0u, blk_np, pstride, stride, db->d_planes};
+                k_exec_c<true, 8192><<<db->n_blocks * blk_np, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                                                                  db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
+            }
+            for (uint32_t p = 0; p < (fused ? 0u : blk_np); p++) {
+                uint8_t *plane = p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride;
+                const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat + (size_t)p * pstride, p, 0u, 0ull, 0ull, nullptr};
+                // (as many wavefronts as blocks: the ones beyond the job list exit)
+                if (blk_xc)
+                    k_exec_c<true, 8192><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
+                                                             db->d_status, db->d_out_len, nullptr, 0u, bk);
+                else
+                    k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
+                                                                        db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
+            }
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
             // (frames whose blocks reach back -- 64 x 128 MiB, 8 / 16 / 32 per frame: 113.8 / 103.7 / 114.8 ms per pass; one frame of
             // 1 GiB, 32 / 64 with jobs of two blocks: 49.4 / 44.4 ms, 32 / 64 / 128 with jobs of one: 56.0 / 67.4 / 92.2 ms -- every
@@ -1849,8 +1828,6 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             // 512 up to sixteen -- 8 x 256 MiB 32 / 64: 31.1 / 30.0; 16 x 128 MiB, jobs of four, 32: 28.0)
             if (spread)
                 G = std::min<uint32_t>(32u * blk_gs, n_walk <= 4 ? 256u / n_walk : (n_walk <= 16 ? 512u / n_walk : std::max<uint32_t>(256u / n_walk, 16u)));
-            // (slices: the walk shares the chip with the passes of the next slice, and ONE of its workgroups fits on a CU beside them)
-            if (K > 1) G = std::max<uint32_t>(1u, std::min<uint32_t>(G, (uint32_t)std::max(ctx->num_cus, 1) / n_walk));
             if (const char *e = exp_env("MZD_EXP_BLK_G")) G = (uint32_t)std::min(256, std::max(1, atoi(e)));  // experiment
             // (G > 1: the workgroups of a frame wait for each other.  Should some of them not be resident -- another stream or
             // process on the GPU --, the waiters give up after a bounded wait and a second launch, one workgroup per such frame,
@@ -1860,38 +1837,19 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             const uint32_t spread_arg = spread ? 1u : 0u, fix_wgs = n_walk * G * (G > 1 && !spread ? 8u : 1u);
             if (G > 1) (void)hipMemsetAsync(db->d_fixdone, 0, (size_t)n_walk * kFixMaxG * sizeof(uint32_t), st);
             const uint32_t tb = ctx->test_fixup_bail;
-            const uint8_t *const pl3 = blk_np == 3 ? nullptr : db->d_planes + 2 * stride;
-            auto launch_walk = [&](hipStream_t ws, uint32_t sl) {
-                if (blk_np == 3)
-                    k_blk_fixup<3, false><<<fix_wgs, 256, 0, ws>>>(db->d_out, db->d_planes, db->d_planes + stride, pl3, db->d_frames, db->d_jobs, db->d_bframes,
-                                                                  G, spread_arg, db->d_fixdone, tb, db->d_walk, sl, K, blk_gs, slice_steps);
-                else
-                    k_blk_fixup<4, false><<<fix_wgs, 256, 0, ws>>>(db->d_out, db->d_planes, db->d_planes + stride, pl3, db->d_frames, db->d_jobs, db->d_bframes,
-                                                                  G, spread_arg, db->d_fixdone, tb, db->d_walk, sl, K, blk_gs, slice_steps);
-            };
-            if (K == 1) {
-                launch_passes(0);
-                launch_walk(st, 0);
+            if (blk_np == 3) {
+                k_blk_fixup<3, false><<<fix_wgs, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames,
+                                                                      db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, tb, db->d_walk);
+                if (G > 1)
+                    k_blk_fixup<3, true><<<n_walk, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, nullptr, db->d_frames, db->d_jobs,
+                                                                       db->d_bframes, G, spread_arg, db->d_fixdone, 0u, db->d_walk);
             } else {
-                // the walk of slice sl on the second stream (idle by now: the Huffman stage is done), behind the slice's passes and the
-                // walk of the slice before; the passes of the next slice do not wait for it
-                hipStream_t ws = ctx->stream2;
-                for (uint32_t sl = 0; sl < K; sl++) {
-                    launch_passes(sl);
-                    (void)hipEventRecord(ctx->ev_head_ready, st);
-                    (void)hipStreamWaitEvent(ws, ctx->ev_head_ready, 0);
-                    launch_walk(ws, sl);
-                }
-                (void)hipEventRecord(ctx->ev_head_done, ws);
-                (void)hipStreamWaitEvent(st, ctx->ev_head_done, 0);
-            }
-            if (G > 1) {
-                if (blk_np == 3)
-                    k_blk_fixup<3, true><<<n_walk, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, pl3, db->d_frames, db->d_jobs, db->d_bframes, G,
-                                                                spread_arg, db->d_fixdone, 0u, db->d_walk, 0u, 1u, blk_gs, slice_steps);
-                else
-                    k_blk_fixup<4, true><<<n_walk, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, pl3, db->d_frames, db->d_jobs, db->d_bframes, G,
-                                                                spread_arg, db->d_fixdone, 0u, db->d_walk, 0u, 1u, blk_gs, slice_steps);
+                k_blk_fixup<4, false><<<fix_wgs, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride,
+                                                                      db->d_planes + 2 * stride, db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg,
+                                                                      db->d_fixdone, tb, db->d_walk);
+                if (G > 1)
+                    k_blk_fixup<4, true><<<n_walk, 256, 0, st>>>(db->d_out, db->d_planes, db->d_planes + stride, db->d_planes + 2 * stride,
+                                                                       db->d_frames, db->d_jobs, db->d_bframes, G, spread_arg, db->d_fixdone, 0u, db->d_walk);
             }
             k_blk_final<<<(db->n_frames + 255) / 256, 256, 0, st>>>(db->d_frames, db->d_jobs, db->d_bframes, db->d_status, db->d_out_len, db->n_frames);
             return;
@@ -2364,13 +2322,6 @@ int mzd_debug_plan_unit_bytes(mzd_ctx *ctx, uint64_t frame_bytes)
 {
     if (!ctx) return MZD_ERR_INVALID_ARG;
     ctx->test_large_frame = frame_bytes;
-    return MZD_OK;
-}
-
-int mzd_debug_force_block_slices(mzd_ctx *ctx, uint32_t k)
-{
-    if (!ctx || k > kBlkMaxSlices) return MZD_ERR_INVALID_ARG;
-    ctx->test_blk_slices = k;
     return MZD_OK;
 }
 

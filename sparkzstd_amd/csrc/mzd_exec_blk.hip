@@ -24,34 +24,14 @@
 
 namespace mzd {
 
-// ---- slices: the jobs of a batch in K groups by their place in their frame (slice s = the s-th K-th of every frame's blocks), so that
-// the passes of slice s + 1 run while the walk gathers slice s (mzd_api.hip).  A slice starts at a job start: the first block at or
-// behind n_blocks * s / K whose number in the batch is a multiple of gs (k_blk_scan starts a job there whatever the block is).
-constexpr uint32_t kBlkMaxSlices = 8;
-__device__ __forceinline__ uint32_t blk_slice_begin(uint32_t first_block, uint32_t n_blocks, uint32_t gs, uint32_t s, uint32_t K)
-{
-    if (s == 0) return 0u;
-    if (s >= K) return n_blocks;
-    const uint32_t g = first_block + (uint32_t)((uint64_t)n_blocks * s / K);
-    return min((g + gs - 1) / gs * gs - first_block, n_blocks);
-}
-
 // ---- scan: a wavefront per frame, 64 blocks per round (their summaries loaded side by side, then walked in order)
 __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                  const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes,
-                                                 uint32_t gs, uint32_t *__restrict__ heads, uint32_t *__restrict__ walk, uint32_t K,
-                                                 uint32_t hstride, uint32_t *__restrict__ slice_steps)
+                                                 uint32_t gs, uint32_t *__restrict__ heads, uint32_t *__restrict__ walk)
 {
-    // heads: K lists, hstride words apart -- [0] a counter (zero at launch), [1 ...] the blocks where a job of the slice starts, in no
-    // particular order.  slice_steps[f * kBlkMaxSlices + s]: the steps of the walk of frame f that lie before slice s
+    // heads: [0] a counter (zero at launch), [1 ...] the blocks where a job starts, in no particular order
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
     const DFrame fr = frames[f];
-    uint32_t Bs[kBlkMaxSlices], before[kBlkMaxSlices];
-#pragma unroll
-    for (uint32_t s = 0; s < kBlkMaxSlices; s++) {
-        Bs[s] = blk_slice_begin(fr.first_block, fr.n_blocks, gs, s, K);
-        before[s] = 0;
-    }
     int error = fr.plan_status;
     uint64_t outPos = 0;
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
@@ -172,33 +152,16 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
         }
         prev_direct = (bool)(__shfl((int)flags, 63, 64) & kBjDirect);
         {
-            // this round's job starts go on the lists of their slices (skipped blocks start nothing)
-            const bool starts = valid && (bi == 0 || (fr.first_block + bi) % gs == 0 || (flags & kBjDirect) || pd);  // (kBjHead)
-            const bool head = starts && bi < n_ok;
-            uint32_t sl = 0;
-#pragma unroll
-            for (uint32_t s = 1; s < kBlkMaxSlices; s++) {
-                if (s < K && bi >= Bs[s]) sl = s;
-                // (a step of the walk: a job start behind the frame's first block)
-                if (s < K) before[s] += (uint32_t)__popcll(wave_ballot(starts && bi >= 1 && bi < Bs[s]));
-            }
-            for (uint32_t s = 0; s < K; s++) {
-                const uint64_t hm = wave_ballot(head && sl == s);
-                if (hm) {
-                    uint32_t *hl = heads + (size_t)s * hstride;
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&hl[0], (uint32_t)__popcll(hm));
-                    at = (uint32_t)__shfl((int)at, 0, 64);
-                    if (head && sl == s) hl[1 + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))] = fr.first_block + bi;
-                }
+            // this round's job starts go on the list (skipped blocks start nothing)
+            const bool head = valid && (bi == 0 || (fr.first_block + bi) % gs == 0 || (flags & kBjDirect) || pd) && bi < n_ok;
+            const uint64_t hm = wave_ballot(head);
+            if (hm) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&heads[0], (uint32_t)__popcll(hm));
+                at = (uint32_t)__shfl((int)at, 0, 64);
+                if (head) heads[1 + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))] = fr.first_block + bi;
             }
         }
-    }
-    if (lane < kBlkMaxSlices) {
-        uint32_t v = 0;
-#pragma unroll
-        for (uint32_t s = 1; s < kBlkMaxSlices; s++) v = lane == s ? before[s] : v;
-        slice_steps[(size_t)f * kBlkMaxSlices + lane] = v;
     }
     // how far back the frame's matches go: an origin lies less than the largest offset below its segment's start, so with offsets
     // up to 8 MiB the low 23 bits of the position say which one it is and the pass that spells the bits above is not run
@@ -408,13 +371,10 @@ __device__ __forceinline__ void fix_gather(const FixChunks<NP> &C, uint8_t *p0, 
 // sets that were not gathered, step by step, without waiting for anybody: the frame is decoded instead of failing with
 // MZD_ERR_DEVICE.  (A chunk that WAS gathered must not be looked at again: which bytes are derived is read from the slab's own
 // pass-0 bytes.)
-// (five wavefronts per SIMD = 96 VGPRs: a workgroup of the walk fits on a CU beside the sixteen wavefronts -- four per SIMD, 104 VGPRs
-// each -- of a slice's passes; with 98 it waited for the passes to drain and no slice's walk ran beside anything)
 template <int NP, bool RESCUE>
-__global__ __launch_bounds__(256, RESCUE ? 4 : 5) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
+__global__ __launch_bounds__(256) void k_blk_fixup(uint8_t *out_blob, const uint8_t *pl1, const uint8_t *pl2, const uint8_t *pl3,
                                                    const DFrame *__restrict__ frames, const BJob *__restrict__ jobs, BFrame *bframes, uint32_t G,
-                                                   uint32_t spread, uint32_t *done, uint32_t test_bail_step, const uint32_t *__restrict__ walk,
-                                                   uint32_t slice, uint32_t K, uint32_t gs, const uint32_t *__restrict__ slice_steps)
+                                                   uint32_t spread, uint32_t *done, uint32_t test_bail_step, const uint32_t *__restrict__ walk)
 {
     // XCD placement, for speed only (workgroup b runs on XCD b % 8 -- observed, not promised).  Many frames (`spread` = 0): with
     // several workgroups per frame the launch has eight times the workgroups and the ones on a frame's XCD do its work, so that a
@@ -445,17 +405,8 @@ __global__ __launch_bounds__(256, RESCUE ? 4 : 5) void k_blk_fixup(uint8_t *out_
     // the frame's jobs after its first (which derives nothing: its blocks follow each other inside one job), in order.
     // (Loading the NEXT job's extent and plane bytes while this job's step runs -- a software pipeline over the jobs -- made the
     // walk slower, 8.1 -> 8.9 ms for 4 095 steps: a step is the hand-off between the workgroups, not the loads before it.)
-    // (K > 1: this launch walks the frame's slice `slice` -- the launches follow each other on one stream, the steps are counted
-    // through the whole frame: `cnt`, `done` and the rescue know nothing of slices)
     uint32_t steps = 0;  // jobs this workgroup is done with
-    uint32_t lo = 1, hi = nb;
-    if (!RESCUE && K > 1) {
-        if (bf->bail) return;  // (an earlier slice's walk gave up: the rescue finishes the frame)
-        lo = max(1u, blk_slice_begin(fr.first_block, fr.n_blocks, gs, slice, K));
-        hi = min(nb, blk_slice_begin(fr.first_block, fr.n_blocks, gs, slice + 1, K));
-        steps = slice_steps[(size_t)f * kBlkMaxSlices + slice];
-    }
-    for (uint32_t bi = lo; bi < hi;) {
+    for (uint32_t bi = 1; bi < nb;) {
         // (this block's entry and the four after it in one go: the job's extent should not cost a latency per block)
         BJob c[5];
 #pragma unroll

@@ -196,33 +196,6 @@ def test_block_mode_many_frames_one_fixup_workgroup_each():
     c.close()
 
 
-def test_block_mode_in_slices():
-    """Block mode with its jobs in K slices (the fix-up walk of a slice on the second stream beside the passes of the next; the walk's
-    steps counted through the whole frame): the same bytes for every K, with jobs of one and of four blocks, with frames of fewer
-    blocks than slices beside large ones -- and with the rescue launch finishing a walk that gave up in the first or in a later slice."""
-    from tools import synth_binding as sb
-    from sparkzstd_amd import _lib
-    L = _lib.load()
-    frames, datas = [], []
-    for k, n in enumerate([20 << 20, 9 << 20, 3 << 20 | 12345, 300000, 1000]):
-        d = sb.generate(sb.TEXT, 60 + k, n)
-        frames.append(sb.compress(d, sb.MODE_FULL)[0])
-        datas.append(d)
-    for variant in (3, 4):
-        c = z.Context(0, exec_variant=variant)
-        for k in (2, 3, 5, 8):
-            assert L.mzd_debug_force_block_slices(c._c, k) == 0
-            for step in (0, 1, 40):
-                assert L.mzd_debug_force_fixup_bail(c._c, step) == 0
-                outs, sts = _decode(frames, c)
-                assert sts == [0] * len(frames), (variant, k, step, sts)
-                for i, (o, d) in enumerate(zip(outs, datas)):
-                    assert o == d, (variant, k, step, i)
-        assert L.mzd_debug_force_block_slices(c._c, 9) != 0
-        assert L.mzd_debug_force_block_slices(c._c, 0) == 0
-        c.close()
-
-
 def test_block_mode_fixup_rescue_when_workgroups_give_up():
     """The fix-up walk of block mode lets G workgroups of a frame wait for each other; nothing promises that they are all
     resident (another stream or process on the GPU).  mzd_debug_force_fixup_bail makes workgroup 1 of every frame give up at a
