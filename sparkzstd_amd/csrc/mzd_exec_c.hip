@@ -74,7 +74,7 @@ static_assert(xc_layout_ok<4096>() && xc_layout_ok<8192>(), "ring = region 0, li
 #ifdef MZD_XC_STATS
 // tools/xc_stats.py: 0 tiles, 1 stretches, 2 passes, 3 extra fixed-point rounds, 4 passes resolved by pointer jumping,
 // 5 passes with a byte read from memory, 6 staged matches, 7 matches, 8 cycles setup, 9 cycles plan + flush, 10 cycles passes,
-// 11 cycles total, 12 frames, 13 stretches on the general setup path
+// 11 cycles total, 12 frames, 13 stretches on the general setup path, 14 cycles in blocks without sequences, 15 such blocks
 __device__ unsigned long long g_xc_stats[16];
 #define XC_STAT(i, n) (xcst[i] += (unsigned long long)(n))
 #define XC_CLOCK() __builtin_readcyclecounter()
@@ -115,6 +115,33 @@ __device__ __noinline__ void xc_reload_window(uint8_t *win, const uint8_t *out, 
     for (uint32_t x = lo4 + 4u * (uint32_t)lane; x < hi4; x += 256) *(uint32_t *)&win[x & (kXcWin - 1)] = ((const U32U *)(out + x))->v;
     for (uint32_t x = max(lo4, hi4) + (uint32_t)lane; x < outPos; x += 64) win[x & (kXcWin - 1)] = out[x];
 }
+
+// A SMALL block without sequences (Raw, RLE, literals only) joins the frame through the ring like a run of literals: n bytes from
+// `src` (null: the byte `fill`) are written behind outPos, whole window units leave for the slab as they fill up (`store` false: the
+// bytes are in the slab already -- literals the Huffman stage put in place -- and everything before them has been flushed); -> the
+// new `flushed`.  The other way -- flush, bulk copy to the slab, wait, reload the ring from the slab -- is three trips to memory,
+// 10 900 cycles a block whatever its size, and real data has frames made of hundreds of 1 KiB blocks (the reference's corpus:
+// 22 % of its largest frame's time, 16 % of the stage's over all frames; tools/xc_stats.py).  (src may be read up to 7 bytes beyond
+// n: the input blob, the literal scratch and the output blob all have that slack.)
+template <uint32_t WIN>
+__device__ __noinline__ uint32_t xc_ring_append(uint8_t *win, uint8_t *out, const uint8_t *src, uint32_t fill, uint32_t n, uint32_t outPos,
+                                                uint32_t flushed, bool store, int lane)
+{
+    const uint32_t o = 8u * (uint32_t)lane;
+    for (uint32_t done = 0; done < n; done += kXcFlush) {
+        const uint32_t c = min(kXcFlush, n - done);
+        uint64_t v = fill * 0x0101010101010101ull;
+        if (src && o < c) v = ld64u(src + done + o);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            if (o + j < c) win[(outPos + o + j) & (WIN - 1)] = (uint8_t)(v >> (8 * j));
+        outPos += c;
+        if (store)
+            while (outPos - flushed >= kXcFlush) flushed = xc_flush_step<WIN>(win, out, flushed, lane);
+    }
+    return store ? flushed : outPos;
+}
+constexpr uint32_t kXcRingBlock = 2048;  // blocks without sequences up to this size go through the ring
 
 __device__ __forceinline__ void xc_lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi)
 {
@@ -239,6 +266,8 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
     for (; bi < fr.n_blocks && error == MZD_OK; bi++) {
         // (block mode: the job ends where the next one starts, or where the frame ended)
         if (BM && bi > bi0 && (bk.jobs[fr.first_block + bi].flags & (kBjHead | kBjSkip))) break;
+        const unsigned long long xc_ta = XC_CLOCK();
+        (void)xc_ta;
         const DBlock b = blocks[fr.first_block + bi];
         if (b.type != MZD_BLOCK_COMPRESSED) {
             // Raw (framedecompressor.go:211-215) / RLE (:229-241): straight copy / fill
@@ -246,12 +275,22 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
                 error = MZD_ERR_DST_FULL;
                 break;
             }
+            if (!BM && b.size <= kXcRingBlock) {
+                flushed = xc_ring_append<WIN>(sh.win, out, b.type == MZD_BLOCK_RAW ? in + b.src_off : nullptr,
+                                              b.type == MZD_BLOCK_RAW ? 0u : (uint32_t)in[b.src_off], b.size, outPos, flushed, true, lane);
+                outPos += b.size;
+                XC_STAT(14, XC_CLOCK() - xc_ta);
+                XC_STAT(15, 1);
+                continue;
+            }
             flushed = xc_flush_bytes<WIN>(sh.win, out, flushed, outPos, lane);  // (same ring: the first 4 KiB of the block)
             if (b.type == MZD_BLOCK_RAW) xb_bulk_copy(out + outPos, in + b.src_off, b.size, lane);
             else xb_bulk_fill(out + outPos, in[b.src_off], b.size, lane);
             outPos += b.size;
             if (!BM) xc_reload_window<WIN>(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
+            XC_STAT(14, XC_CLOCK() - xc_ta);
+            XC_STAT(15, 1);
             continue;
         }
 
@@ -272,6 +311,19 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
         if (b.n_seq == 0) {
             // no sequences: the block IS its literals (sequence_execution.go:55-59) -- unless the Huffman stage has
             // already put them in place
+            if (!BM && b.lit_regen <= kXcRingBlock) {
+                if (b.pad[0]) {  // in place: the ring takes them from the slab, nothing is stored again
+                    flushed = xc_flush_bytes<WIN>(sh.win, out, flushed, outPos, lane);
+                    flushed = xc_ring_append<WIN>(sh.win, out, out + outPos, 0u, b.lit_regen, outPos, flushed, false, lane);
+                } else {
+                    flushed = xc_ring_append<WIN>(sh.win, out, litRle ? nullptr : lits, litRle ? (uint32_t)lits[0] : 0u, b.lit_regen, outPos, flushed,
+                                                  true, lane);
+                }
+                outPos += b.lit_regen;
+                XC_STAT(14, XC_CLOCK() - xc_ta);
+                XC_STAT(15, 1);
+                continue;
+            }
             flushed = xc_flush_bytes<WIN>(sh.win, out, flushed, outPos, lane);
             if (!b.pad[0]) {
                 if (litRle) xb_bulk_fill(out + outPos, lits[0], b.lit_regen, lane);
@@ -280,6 +332,8 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
             outPos += b.lit_regen;
             if (!BM) xc_reload_window<WIN>(sh.win, out, outPos, lane);
             flushed = confirmed = outPos;
+            XC_STAT(14, XC_CLOCK() - xc_ta);
+            XC_STAT(15, 1);
             continue;
         }
         if (litRle) {  // RLE literals (literals.go:390-396): every literal of every stretch is this byte
