@@ -90,6 +90,101 @@ def test_multi_block_synthetic_frames(ctx):
     assert outs == want
 
 
+def _frame_blocks(frame):
+    """the blocks of a zstd frame as [(type, payload bytes, regenerated size for RLE)] (frame.go / block.go)"""
+    fhd = frame[4]
+    single, dict_flag, fcs_flag = (fhd >> 5) & 1, fhd & 3, fhd >> 6
+    pos = 5 + (0 if single else 1) + (0, 1, 2, 4)[dict_flag] + ((1 if single else 0), 2, 4, 8)[fcs_flag]
+    blocks = []
+    while True:
+        h = frame[pos] | (frame[pos + 1] << 8) | (frame[pos + 2] << 16)
+        last, typ, size = h & 1, (h >> 1) & 3, h >> 3
+        n = 1 if typ == 1 else size
+        blocks.append((typ, frame[pos + 3:pos + 3 + n], size))
+        pos += 3 + n
+        if last:
+            return blocks
+
+
+def _splice_frame(blocks):
+    """a frame of these blocks: no content size, a window of 128 MiB (window descriptor 0x88)"""
+    out = bytearray(b"\x28\xb5\x2f\xfd\x00\x88")
+    for i, (typ, payload, size) in enumerate(blocks):
+        h = (1 if i + 1 == len(blocks) else 0) | (typ << 1) | (size << 3)
+        out += bytes([h & 0xFF, (h >> 8) & 0xFF, h >> 16]) + bytes(payload)
+    return bytes(out)
+
+
+def _literal_block(data, rle=False):
+    """a compressed block without sequences whose literals are raw (or one repeated byte)"""
+    n = len(data)
+    lit_type = 1 if rle else 0
+    if n < 32:
+        lh = bytes([lit_type | (n << 3)])
+    elif n < 4096:
+        v = lit_type | (1 << 2) | (n << 4)
+        lh = bytes([v & 0xFF, v >> 8])
+    else:
+        v = lit_type | (3 << 2) | (n << 4)
+        lh = bytes([v & 0xFF, (v >> 8) & 0xFF, v >> 16])
+    body = lh + (data[:1] if rle else data) + b"\x00"
+    return (2, body, len(body))
+
+
+def test_small_blocks_without_sequences_between_blocks_with_matches(ctx, oracle):
+    """k_exec_c takes small Raw / RLE / literal-only blocks through its ring like a run of literals (up to 2 KiB; larger ones are
+    copied to the slab and the ring reloaded).  Frames spliced from the blocks of multi-block text frames -- their matches and
+    their offset history reach back over what is put between them -- with such blocks of every size around the path's
+    boundaries (a window unit is 512 bytes, a lane carries 8) in between, several in a row, first and last; against the oracle."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(11)
+    sizes = [0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 500, 511, 512, 513, 1000, 1023, 1024, 1025, 1536, 2047, 2048, 2049, 3000, 5000]
+    huf_only = []  # compressed blocks with Huffman literals and no sequences (the Huffman stage writes them in place)
+    for k, n in enumerate([300, 700, 1500, 2048, 2500, 6000]):
+        huf_only += [b for b in _frame_blocks(sb.compress(sb.generate(sb.TEXT, 900 + k, n), sb.MODE_LITERALS)[0]) if b[0] == 2]
+    assert huf_only
+
+    def small(n):
+        kind = int(rng.integers(0, 5))
+        data = bytes(rng.integers(0, 256, size=max(n, 1), dtype=np.uint8))[:n]
+        if kind == 0 or n == 0:
+            return (0, data, n)                      # Raw
+        if kind == 1:
+            return (1, data[:1], n)                  # RLE
+        if kind == 2:
+            return _literal_block(data)              # raw literals, no sequences
+        if kind == 3:
+            return _literal_block(data, rle=True)    # RLE literals, no sequences
+        return huf_only[int(rng.integers(0, len(huf_only)))]
+
+    frames = []
+    for i in range(10):
+        src = _frame_blocks(sb.compress(sb.generate(sb.TEXT, 700 + i, (3 + i % 3) * 131072 - 1000 * i), sb.MODE_FULL)[0])
+        assert len(src) >= 3 and all(t == 2 for t, _, _ in src)
+        blocks = [small(sizes[(5 * i + j) % len(sizes)]) for j in range(i % 3)]  # (some frames start with small blocks)
+        for j, b in enumerate(src):
+            blocks.append(b)
+            blocks += [small(sizes[int(rng.integers(0, len(sizes)))]) for _ in range(1 + (i + j) % 4)]
+        frames.append(_splice_frame(blocks))
+    # every size once, in one frame, between two blocks with sequences
+    src = _frame_blocks(sb.compress(sb.generate(sb.TEXT, 799, 2 * 131072), sb.MODE_FULL)[0])
+    for kind_blocks in ([(0, bytes(rng.integers(0, 256, size=max(n, 1), dtype=np.uint8))[:n], n) for n in sizes],
+                        [(1, b"\x5a", n) for n in sizes if n],
+                        [_literal_block(bytes(rng.integers(0, 256, size=n, dtype=np.uint8))) for n in sizes if n]):
+        frames.append(_splice_frame([src[0]] + kind_blocks + [src[1]]))
+    want = []
+    for f in frames:
+        rc, ref, *_ = oracle.decode_frame(f, cap=8 << 20)
+        assert rc == 0, rc
+        want.append(ref)
+    outs, sts = _decode(frames, ctx)
+    assert sts == [0] * len(frames), sts
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert o == w, i
+    outs, sts = z.decode_frames(frames, ctx, device_plan=True)
+    assert sts == [0] * len(frames) and all(o == w for o, w in zip(outs, want))
+
+
 @pytest.mark.parametrize("exec_variant", [0, 3, 4])
 def test_large_frames_blocks_side_by_side(exec_variant):
     """Few large frames: the blocks of a frame are executed side by side (mzd_exec_blk.hip) -- three passes for frames below
