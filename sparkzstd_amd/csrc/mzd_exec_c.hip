@@ -123,25 +123,36 @@ __device__ __noinline__ void xc_reload_window(uint8_t *win, const uint8_t *out, 
 // 10 900 cycles a block whatever its size, and real data has frames made of hundreds of 1 KiB blocks (the reference's corpus:
 // 22 % of its largest frame's time, 16 % of the stage's over all frames; tools/xc_stats.py).  (src may be read up to 7 bytes beyond
 // n: the input blob, the literal scratch and the output blob all have that slack.)
+#ifndef MZD_XC_RING_BLOCK
+#define MZD_XC_RING_BLOCK 2048
+#endif
+constexpr uint32_t kXcRingBlock = MZD_XC_RING_BLOCK;  // blocks without sequences up to this size go through the ring
 template <uint32_t WIN>
 __device__ __noinline__ uint32_t xc_ring_append(uint8_t *win, uint8_t *out, const uint8_t *src, uint32_t fill, uint32_t n, uint32_t outPos,
                                                 uint32_t flushed, bool store, int lane)
 {
+    // (n <= kXcRingBlock: four window units at most, all of the block's loads in flight together -- one trip to memory per block)
+    constexpr int kUnits = kXcRingBlock / kXcFlush;
     const uint32_t o = 8u * (uint32_t)lane;
-    for (uint32_t done = 0; done < n; done += kXcFlush) {
-        const uint32_t c = min(kXcFlush, n - done);
-        uint64_t v = fill * 0x0101010101010101ull;
-        if (src && o < c) v = ld64u(src + done + o);
+    uint64_t v[kUnits];
+#pragma unroll
+    for (int k = 0; k < kUnits; k++) {
+        v[k] = fill * 0x0101010101010101ull;
+        if (src && (uint32_t)k * kXcFlush + o < n) v[k] = ld64u(src + (uint32_t)k * kXcFlush + o);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnits; k++) {
+        if ((uint32_t)k * kXcFlush >= n) break;
+        const uint32_t c = min(kXcFlush, n - (uint32_t)k * kXcFlush);
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++)
-            if (o + j < c) win[(outPos + o + j) & (WIN - 1)] = (uint8_t)(v >> (8 * j));
+            if (o + j < c) win[(outPos + o + j) & (WIN - 1)] = (uint8_t)(v[k] >> (8 * j));
         outPos += c;
         if (store)
             while (outPos - flushed >= kXcFlush) flushed = xc_flush_step<WIN>(win, out, flushed, lane);
     }
     return store ? flushed : outPos;
 }
-constexpr uint32_t kXcRingBlock = 2048;  // blocks without sequences up to this size go through the ring
 
 __device__ __forceinline__ void xc_lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi)
 {
