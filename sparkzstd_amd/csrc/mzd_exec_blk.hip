@@ -45,24 +45,26 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
         int e = MZD_OK, h0 = 0, h1 = 0, h2 = 0;
         bool hist = false;
         if (valid) {
-            const DBlock b = blocks[fr.first_block + bi];
-            if (b.type != MZD_BLOCK_COMPRESSED) {
-                bo = b.size;
+            // (field by field: whole structs indexed per lane went through 80 bytes of scratch)
+            const DBlock *const bp = blocks + fr.first_block + bi;
+            if (bp->type != MZD_BLOCK_COMPRESSED) {
+                bo = bp->size;
                 flags = kBjDirect;
             } else {
                 // the checks of k_exec_b's serial walk, in its order
-                const BlockSum s = sums[fr.first_block + bi];
-                e = s.huf_err != 0xFFFFFFFFu ? (int)(s.huf_err & 0xFF) : s.status;
-                if (e == MZD_OK && s.lit_total > b.lit_regen) e = MZD_ERR_LITERALS;  // sequence_execution.go:27-29
-                bo = s.out_total + (b.lit_regen - min(s.lit_total, b.lit_regen));
+                const BlockSum *const sp = sums + fr.first_block + bi;
+                const uint32_t huf_err = sp->huf_err, lit_total = sp->lit_total, lit_regen = bp->lit_regen;
+                e = huf_err != 0xFFFFFFFFu ? (int)(huf_err & 0xFF) : sp->status;
+                if (e == MZD_OK && lit_total > lit_regen) e = MZD_ERR_LITERALS;  // sequence_execution.go:27-29
+                bo = sp->out_total + (lit_regen - min(lit_total, lit_regen));
                 if (e == MZD_OK && bo > kBlockMax) e = MZD_ERR_CORRUPT_SIZES;
-                if (b.n_seq == 0) flags = kBjDirect;
+                if (bp->n_seq == 0) flags = kBjDirect;
                 else {
-                    reach = max(reach, s.reach);
+                    reach = max(reach, sp->reach);
                     hist = true;
-                    h0 = s.hist[0];
-                    h1 = s.hist[1];
-                    h2 = s.hist[2];
+                    h0 = sp->hist[0];
+                    h1 = sp->hist[1];
+                    h2 = sp->hist[2];
                 }
             }
         }
@@ -94,10 +96,15 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
                 const uint32_t ak0 = (uint32_t)__shfl_up((int)k0, sft, 64), ak1 = (uint32_t)__shfl_up((int)k1, sft, 64), ak2 = (uint32_t)__shfl_up((int)k2, sft, 64);
                 const uint32_t av0 = (uint32_t)__shfl_up((int)v0, sft, 64), av1 = (uint32_t)__shfl_up((int)v1, sft, 64), av2 = (uint32_t)__shfl_up((int)v2, sft, 64);
                 if ((int)lane >= sft) {
+                    // (the three-way picks by masks: as `k == 0 ? a : (k == 1 ? b : c)` over values that live in a lambda's captures the
+                    // compiler made them lookups in a table it kept in scratch -- 112 bytes per lane, 138 scratch accesses per round)
+                    auto pick = [](uint32_t k, uint32_t x0, uint32_t x1, uint32_t x2) -> uint32_t {
+                        return (x0 & (0u - (uint32_t)(k == 0))) | (x1 & (0u - (uint32_t)(k == 1))) | (x2 & (0u - (uint32_t)(k >= 2)));
+                    };
                     auto comp = [&](bool &c, uint32_t &k, uint32_t &v) {  // this lane's component after the earlier lanes' map A
                         if (c) return;
-                        const bool ac = k == 0 ? ac0 : (k == 1 ? ac1 : ac2);
-                        const uint32_t ak = k == 0 ? ak0 : (k == 1 ? ak1 : ak2), av = k == 0 ? av0 : (k == 1 ? av1 : av2);
+                        const bool ac = pick(k, (uint32_t)ac0, (uint32_t)ac1, (uint32_t)ac2) != 0;
+                        const uint32_t ak = pick(k, ak0, ak1, ak2), av = pick(k, av0, av1, av2);
                         if (ac) { c = true; k = 0; v = av - v; }
                         else { k = ak; v = av + v; }
                     };
@@ -137,18 +144,13 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
         const bool pd_up = (bool)__shfl_up((int)(flags & kBjDirect), 1, 64);  // (all lanes)
         const bool pd = lane == 0 ? prev_direct : pd_up;
         if (valid) {
-            BJob j;
-            j.start = myStart;
-            j.len = bo;
-            j.H0 = m0;
-            j.H1 = m1;
-            j.H2 = m2;
-            j.flags = flags | (bi >= n_ok ? kBjSkip : 0u);
-            j.frame = f;
-            j.pad = 0;
             // a job starts at every gs-th block (of the batch's numbering), at a block without sequences and behind one
-            if (bi == 0 || (fr.first_block + bi) % gs == 0 || (flags & kBjDirect) || pd) j.flags |= kBjHead;
-            jobs[fr.first_block + bi] = j;
+            uint32_t jf = flags | (bi >= n_ok ? kBjSkip : 0u);
+            if (bi == 0 || (fr.first_block + bi) % gs == 0 || (flags & kBjDirect) || pd) jf |= kBjHead;
+            static_assert(sizeof(BJob) == 32, "stored as two 16-byte halves");
+            uint4 *const jp = (uint4 *)(jobs + fr.first_block + bi);  // start, len, H0, H1 | H2, flags, frame, pad
+            jp[0] = make_uint4(myStart, bo, (uint32_t)m0, (uint32_t)m1);
+            jp[1] = make_uint4((uint32_t)m2, jf, f, 0u);
         }
         prev_direct = (bool)(__shfl((int)flags, 63, 64) & kBjDirect);
         {
