@@ -318,10 +318,11 @@ def test_block_mode_fixup_rescue_when_workgroups_give_up():
             c.close()
 
 
-def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
+def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus, oracle):
     """Damaged multi-block frames: block mode (a scan over the block summaries + per-block execution) names the same status
     and the same produced length per frame as k_exec_b walking the blocks in order -- the first failing block ends the frame
-    (framedecompressor.go:246-254), whatever later blocks would have reported."""
+    (framedecompressor.go:246-254), whatever later blocks would have reported -- and both agree with the oracle: a frame the
+    device reports as decoded is one the oracle decodes to the same bytes, a frame the oracle rejects carries a status."""
     from tools import synth_binding as sb
     rng = np.random.default_rng(77)
     base = []
@@ -352,6 +353,13 @@ def test_block_mode_reports_status_and_length_of_the_serial_walk(corpus):
         c.close()
     (s2, l2, o2) = res[0]
     assert (s2 != 0).any() and (s2 == 0).any()
+    for i, f in enumerate(frames):
+        rc, want, _, _ = oracle.decode_frame(f, cap=4 << 20)
+        if s2[i] == 0:
+            assert rc == 0, (i, oracle.strerror(rc))
+            assert int(l2[i]) == len(want) and bytes(o2[offs[i]:offs[i] + len(want)]) == want, i
+        if rc != 0:
+            assert s2[i] != 0, i
     for (s3, l3, o3) in res[1:]:
         assert (s2 == s3).all(), np.nonzero(s2 != s3)[0][:8]
         assert (l2 == l3).all(), np.nonzero(l2 != l3)[0][:8]
