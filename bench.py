@@ -361,7 +361,7 @@ def secondary_workloads(z, sb, torch, device, headline):
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "copy_ceiling_GBs": ceil, "frac_of_copy_ceiling": round(achieved / ceil, 4) if achieved and ceil else None,
                          "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
-                         "library_chose": [n for n, bit in (("block mode", 2), ("k_exec_c", 4), ("k_exec_b", 8), ("split pass", 16)) if rb.last_pass() & bit],
+                         "library_chose": [n for n, bit in (("block mode", 2), ("k_exec_c", 4), ("k_exec_b", 8), ("split pass", 16), ("two groups of frames", 32)) if rb.last_pass() & bit],
                          "bit_exact": ok, "poisoned_output": True, "wall_s": round(time.perf_counter() - t_all, 2)}
             if note:
                 out[name]["note"] = note

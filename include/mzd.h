@@ -410,7 +410,9 @@ enum {
     MZD_PASS_BLOCK_MODE = 2, /* the blocks of a frame side by side (mzd_exec_blk.hip) */
     MZD_PASS_EXEC_C = 4,     /* k_exec_c executed the sequences */
     MZD_PASS_EXEC_B = 8,     /* k_exec_b */
-    MZD_PASS_SPLIT = 16      /* the last round of the sequence stage ran beside the execution of the frames before it */
+    MZD_PASS_SPLIT = 16,     /* the last round of the sequence stage ran beside the execution of the frames before it */
+    MZD_PASS_TWO_GROUPS = 32 /* a heterogeneous batch: the frames that hold its longest chains were decoded and executed on a stream of
+                              * their own, beside the others (mzd_batch_upload groups them) */
 };
 uint32_t mzd_batch_last_pass(const mzd_dbatch *db);
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
     "mzd_batch_last_pass", "mzd_batch_trim", "mzd_debug_plan_unit_bytes",
 ]
-MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT = 2, 4, 8, 16
+MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT, MZD_PASS_TWO_GROUPS = 2, 4, 8, 16, 32
 
 MZD_DEBUG_LITERALS, MZD_DEBUG_RECORDS, MZD_DEBUG_TILES, MZD_DEBUG_BLOCKS = 0, 1, 2, 3
 

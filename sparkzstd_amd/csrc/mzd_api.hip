@@ -30,6 +30,7 @@ struct mzd_ctx {
     mzd_options opt{};
     std::string last_error;
     hipStream_t stream2 = nullptr;  // the execution kernel of the head of a split batch runs here
+    hipStream_t stream3 = nullptr;  // the frames with the longest chains of a heterogeneous batch (created by the first pass that has such)
     hipEvent_t ev_head_ready = nullptr, ev_head_done = nullptr, ev_init_done = nullptr, ev_huf_done = nullptr;
     int num_cus = 256;
     // HIP events around every kernel of every mzd_batch_run since the last mzd_timing_reset
@@ -139,6 +140,9 @@ struct mzd_dbatch {
     bool huf_sorted = false;           // d_huf_tasks' quads are grouped by table size class, longest streams first
     uint32_t huf_class_end[3] = {0, 0, 0};  // quads of class 0 (tables <= 32 cells), 1 (<= 256), 2 end here
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
+    // a heterogeneous batch whose sequence stage is as long as its longest chain: the first long_frames frames of d_frame_order hold the
+    // long chains, and their chains are the first long_tasks of d_seq_tasks (0: no such grouping)
+    uint32_t long_frames = 0, long_tasks = 0;
     // block mode of the execution stage (few large frames; mzd_exec_blk.hip): allocated by the first run that takes it
     BJob *d_jobs = nullptr;
     uint32_t *d_heads = nullptr;  // [0] number of jobs, [1 + j] first block of job j
@@ -196,6 +200,7 @@ struct ListOrder {
     std::vector<uint32_t> seq_perm, huf_perm, frame_order;  // empty: leave the list in frame order
     uint32_t huf_class_end[3] = {0, 0, 0};
     uint32_t seq_class_end[3] = {0, 0, 0}, seq_class_logs[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // LL, ML, OF accuracy logs per class
+    uint32_t long_frames = 0, long_tasks = 0;  // see mzd_dbatch
 };
 inline uint32_t seq_key(uint32_t n_seq, uint32_t ll, uint32_t ml, uint32_t of) { return std::min(n_seq, 0xFFFFFu) | (ll << 20) | (ml << 24) | (of << 28); }
 // seq_nseq[i]: seq_key() of chain i; huf_key[q]: MaxBits << 24 | longest stream of quad q (capped); frame_cap[f]: output bound
@@ -354,6 +359,7 @@ void mzd_destroy(mzd_ctx *ctx)
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_head_ready) (void)hipEventDestroy(ctx->ev_head_ready);
     if (ctx->ev_head_done) (void)hipEventDestroy(ctx->ev_head_done);
     if (ctx->ev_init_done) (void)hipEventDestroy(ctx->ev_init_done);
@@ -674,6 +680,34 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         for (size_t q = 0; q < kh.size(); q++) kh[q] = huf_quad_key(&huf_tasks[4 * q]);
         for (uint32_t f = 0; f < b->n_frames; f++) caps[f] = b->frames[f].out_capacity;
         plan_order(ks.data(), ks.size(), kh.data(), kh.size(), caps.data(), caps.size(), b->in_size, order);
+        // The frames that hold the longest chains, apart (real data: one chain of 42 k sequences is 4.9 ms of a sequence stage whose
+        // work is 0.8 ms at 1 GiB -- and the execution of every OTHER frame, 4.9 ms of its own, waited for it).  When the longest chain
+        // is more than 2.5 rounds of the chip's work: the chains of at least half its length (and 2 048 sequences) are the long ones,
+        // the frames that hold any of them go first in the frame order, their chains first in the task list, each part in its old order;
+        // mzd_batch_run decodes and executes the two groups on two streams.
+        if (!order.seq_perm.empty() && !order.frame_order.empty()) {
+            const size_t ns = ks.size();
+            uint64_t sum = 0;
+            for (size_t i = 0; i < ns; i++) sum += ks[i] & 0xFFFFFu;
+            const uint32_t n_max = ks[order.seq_perm[0]] & 0xFFFFFu, lim = std::max(n_max / 2, 2048u);
+            const uint64_t in_flight = (uint64_t)kQ4Chains * (uint64_t)std::max(ctx->num_cus, 1);
+            size_t nl = 0;
+            while (nl < ns && (ks[order.seq_perm[nl]] & 0xFFFFFu) >= lim) nl++;
+            // (measured on the reference's corpus, longest chain x chains in flight / all sequences = 6.3 / 3.1 / 1.6 at 1 / 2 / 4 GiB: the pass
+            // 9.86 -> 8.26, 10.84 -> 9.19, 14.14 -> 15.2 ms -- beyond 2.5 the grouping pays)
+            if ((uint64_t)n_max * in_flight * 2 >= 5 * sum && nl > 0 && nl <= (size_t)kQ4Chains * 64) {
+                std::vector<uint8_t> is_long(b->n_frames, 0);
+                auto frame_of = [&](uint32_t task) {
+                    return (uint32_t)(std::upper_bound(frame_seq_task.begin(), frame_seq_task.end(), task) - frame_seq_task.begin()) - 1u;
+                };
+                for (size_t i = 0; i < nl; i++) is_long[frame_of(order.seq_perm[i])] = 1;
+                std::stable_partition(order.frame_order.begin(), order.frame_order.end(), [&](uint32_t f) { return is_long[f] != 0; });
+                std::stable_partition(order.seq_perm.begin(), order.seq_perm.end(), [&](uint32_t t) { return is_long[frame_of(t)] != 0; });
+                for (uint32_t f = 0; f < b->n_frames; f++) order.long_frames += is_long[f];
+                for (size_t i = 0; i < ns; i++) order.long_tasks += is_long[frame_of(order.seq_perm[i])];
+                if (order.long_frames == b->n_frames) order.long_frames = order.long_tasks = 0;  // (nothing to run beside them)
+            }
+        }
         if (!order.seq_perm.empty()) {
             std::vector<SeqTask> sorted(seq_tasks.size());
             for (size_t i = 0; i < sorted.size(); i++) sorted[i] = seq_tasks[order.seq_perm[i]];
@@ -701,6 +735,8 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     for (int k = 0; k < 3; k++) db->seq_cells[k] = 1u << std::min<uint32_t>(seq_logs[k], k == 2 ? 8u : 9u);
     db->huf_slot_cells = 1u << max_huf_bits;
     db->seq_sorted = seq_sorted;
+    db->long_frames = order.long_frames;
+    db->long_tasks = order.long_tasks;
     for (int c = 0; c < 3; c++) {
         db->seq_class_end[c] = order.seq_class_end[c];
         for (int k = 0; k < 3; k++) db->seq_class_cells[c][k] = 1u << std::min<uint32_t>(order.seq_class_logs[c][k], k == 2 ? 8u : 9u);
@@ -1234,6 +1270,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     // gathered there
     db->seq_sorted = db->huf_sorted = false;
     bool have_order = false;
+    db->long_frames = db->long_tasks = 0;  // (batches planned on the device keep one group)
     if (n_seq > 64 || n_hufb > 64 || n_frames > 64) {
         const uint32_t ns = (uint32_t)n_seq, nq = (uint32_t)n_hufb, nk = std::max(ns, nq);
         std::vector<uint32_t> keys((size_t)ns + nq);
@@ -1685,8 +1722,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         ev = ctx->ev.data() + ctx->runs * kEvPerRun;
     }
     bool seq_pack = false;  // the launches to come have the execution stage of earlier frames beside them
+    hipStream_t seq_stream = s;  // (the stream the next sequence launch goes to)
     auto launch_seq_tasks = [&](uint32_t first, uint32_t count, bool use_pipe, uint64_t base) {
         if (!count) return;
+        hipStream_t s = seq_stream;
         if (use_pipe) {
             // chains per workgroup: as few per workgroup as spread the chains over all CUs (a lone chain per CU when the batch is
             // small: the step latency does not depend on the number of lanes) -- unless the execution stage of earlier frames runs
@@ -1985,6 +2024,49 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // CUs; k_huf's small workgroups then fill what is left instead of delaying them.  (Tried: k_huf beside the LAST,
     // partial round of the sequence stage instead of the first, k_exec in one launch after both: 22.3-22.5 ms against
     // 21.2-21.8 ms per pass.)
+    // Two groups of frames (a heterogeneous batch whose sequence stage is as long as its longest chain; mzd_batch_upload): the frames that
+    // hold the long chains are decoded and executed on a third stream, everything else on the caller's -- the execution of the other
+    // frames runs beside the long chains instead of behind them (real data at 1 GiB: the sequence stage 4.9 ms for 0.8 ms of work, the
+    // execution stage 4.9 ms, one after the other)
+    //   s3 : [wait init] k_seq(long chains' frames) -> [wait huf] k_exec(those frames)
+    //   s  : k_init -> k_seq(the others) -> [wait huf] k_exec(the others) -> [wait s3]
+    //   s2 : [wait init] k_huf (all frames)
+    const bool two_groups = db->long_tasks > 0 && db->long_tasks < db->n_seq_tasks && db->long_frames > 0 && db->long_frames < db->n_frames &&
+                            db->seq_sorted && db->d_frame_order && q4 && pipe && exec_c && !blk && !split && !huf_first && !no_exec;
+    if (two_groups) {
+        db->last_pass |= MZD_PASS_TWO_GROUPS;
+        if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        hipStream_t s3 = ctx->stream3;
+        HIP_TRY(ctx, hipStreamWaitEvent(s3, ctx->ev_init_done, 0));
+        seq_pack = true;  // (full workgroups: the long chains on as few CUs as hold them)
+        seq_stream = s3;
+        launch_seq_tasks(0, db->long_tasks, true, 0);
+        seq_stream = s;
+        seq_pack = false;
+        launch_seq_tasks(db->long_tasks, db->n_seq_tasks - db->long_tasks, true, 0);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_init_done, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s2));
+        launch_huf();
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
+        HIP_TRY(ctx, hipStreamWaitEvent(s3, ctx->ev_huf_done, 0));
+        launch_exec(s3, 0, db->long_frames);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s3));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
+        launch_exec(s, db->long_frames, db->n_frames - db->long_frames);
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_head_done, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[5], s));
+        launch_verify(s, 0, db->n_frames);
+        if (ev) {
+            HIP_TRY(ctx, hipEventRecord(ev[11], s));
+            HIP_TRY(ctx, hipEventRecord(ev[8], s));
+            ctx->runs++;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return MZD_OK;
+    }
     if (huf_first) {
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[9], s));
         launch_huf();

@@ -131,6 +131,47 @@ def _literal_block(data, rle=False):
     return (2, body, len(body))
 
 
+def test_heterogeneous_batch_in_two_groups_of_frames(corpus):
+    """A batch whose sequence stage is as long as its longest chain (the reference's corpus: one chain of 42 k sequences among 2 445)
+    is decoded and executed in two groups of frames on two streams -- the frames that hold the long chains, and the others beside
+    them (mzd_batch_upload groups them, MZD_PASS_TWO_GROUPS says so); the same bytes and statuses as with the frames in one group
+    (a batch of frames of one kind; the same corpus planned on the device), damaged frames included, run after run."""
+    from sparkzstd_amd import _lib
+    from tools import synth_binding as sb
+    frames = [comp for _, comp, *_ in corpus] * 3
+    rng = np.random.default_rng(5)
+    for k in (7, 33, 91, 97, 133):  # (damaged copies, some of them of the frames with the long chains)
+        b = bytearray(frames[k])
+        b[len(b) // 2 + int(rng.integers(0, 64))] ^= 0x5A
+        frames[k] = bytes(b)
+    c = z.Context(0)
+    rb, _, _, sts_r = z.decode_frames_resident(frames, c)
+    assert rb.pass_flags & _lib.MZD_PASS_TWO_GROUPS and rb.pass_flags & _lib.MZD_PASS_EXEC_C
+    rb.free()
+    rb3, _, _, sts_r3 = z.decode_frames_resident(frames, c, device_plan=True)
+    assert not rb3.pass_flags & _lib.MZD_PASS_TWO_GROUPS  # (batches planned on the device keep one group)
+    rb3.free()
+    outs, sts = z.decode_frames(frames, c)
+    outs2, sts2 = z.decode_frames(frames, c)  # (run after run: the third stream's work is ordered behind the pass before)
+    outs3, sts3 = z.decode_frames(frames, c, device_plan=True)
+    assert list(sts) == list(sts2) == list(sts3) == list(sts_r) == list(sts_r3)
+    assert any(s != 0 for s in sts) and sum(1 for s in sts if s == 0) >= len(frames) - 5
+    for i, (a, b, d) in enumerate(zip(outs, outs2, outs3)):
+        if sts[i] == 0:
+            assert bytes(a) == bytes(b) == bytes(d), i
+    for i in range(100):
+        if i not in (7, 33, 91, 97):
+            name, comp, length, sha, exp = corpus[i]
+            check_expected(name, bytes(outs[i]), length, sha, exp)
+    # frames of one kind: one group
+    blob, off, ln, ck, ns = sb.make_batch(4, 0, 512, 131072, threads=4)
+    fr = [bytes(blob[int(o):int(o) + int(l)]) for o, l in zip(off, ln)]
+    rb, _, _, sts = z.decode_frames_resident(fr, c)
+    assert not rb.pass_flags & _lib.MZD_PASS_TWO_GROUPS and list(sts) == [0] * 512
+    rb.free()
+    c.close()
+
+
 def test_small_blocks_without_sequences_between_blocks_with_matches(ctx, oracle):
     """k_exec_c takes small Raw / RLE / literal-only blocks through its ring like a run of literals (up to 2 KiB; larger ones are
     copied to the slab and the ring reloaded).  Frames spliced from the blocks of multi-block text frames -- their matches and
