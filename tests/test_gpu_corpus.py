@@ -136,7 +136,7 @@ def test_heterogeneous_batch_in_two_groups_of_frames(corpus):
     is decoded and executed in two groups of frames on two streams -- the frames that hold the long chains, and the others beside
     them (mzd_batch_upload groups them, MZD_PASS_TWO_GROUPS says so); the same bytes and statuses as with the frames in one group
     (a batch of frames of one kind; the same corpus planned on the device), damaged frames included, run after run."""
-    from sparkzstd_amd import _lib
+    from sparkzstd_amd import _lib, api
     from tools import synth_binding as sb
     frames = [comp for _, comp, *_ in corpus] * 3
     rng = np.random.default_rng(5)
@@ -145,10 +145,10 @@ def test_heterogeneous_batch_in_two_groups_of_frames(corpus):
         b[len(b) // 2 + int(rng.integers(0, 64))] ^= 0x5A
         frames[k] = bytes(b)
     c = z.Context(0)
-    rb, _, _, sts_r = z.decode_frames_resident(frames, c)
+    rb, _, _, sts_r = api.decode_frames_resident(frames, c)
     assert rb.pass_flags & _lib.MZD_PASS_TWO_GROUPS and rb.pass_flags & _lib.MZD_PASS_EXEC_C
     rb.free()
-    rb3, _, _, sts_r3 = z.decode_frames_resident(frames, c, device_plan=True)
+    rb3, _, _, sts_r3 = api.decode_frames_resident(frames, c, device_plan=True)
     assert not rb3.pass_flags & _lib.MZD_PASS_TWO_GROUPS  # (batches planned on the device keep one group)
     rb3.free()
     outs, sts = z.decode_frames(frames, c)
@@ -166,7 +166,7 @@ def test_heterogeneous_batch_in_two_groups_of_frames(corpus):
     # frames of one kind: one group
     blob, off, ln, ck, ns = sb.make_batch(4, 0, 512, 131072, threads=4)
     fr = [bytes(blob[int(o):int(o) + int(l)]) for o, l in zip(off, ln)]
-    rb, _, _, sts = z.decode_frames_resident(fr, c)
+    rb, _, _, sts = api.decode_frames_resident(fr, c)
     assert not rb.pass_flags & _lib.MZD_PASS_TWO_GROUPS and list(sts) == [0] * 512
     rb.free()
     c.close()
