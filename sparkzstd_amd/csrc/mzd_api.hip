@@ -253,6 +253,34 @@ void plan_order(const uint32_t *seq_nseq, size_t ns, const uint32_t *huf_key, si
         std::stable_sort(o.frame_order.begin(), o.frame_order.end(), [&](uint32_t x, uint32_t y) { return frame_cap[x] > frame_cap[y]; });
     }
 }
+// The frames that hold the longest chains, apart (real data: one chain of 42 k sequences is 4.9 ms of a sequence stage whose work is
+// 0.8 ms at 1 GiB -- and the execution of every OTHER frame, 4.9 ms of its own, waited for it).  When the longest chain is more than 2.5
+// rounds of the chip's work: the chains of at least half its length (and 2 048 sequences) are the long ones, the frames that hold any of
+// them go first in the frame order, their chains first in the task list, each part in its old order; mzd_batch_run decodes and executes
+// the two groups on two streams.  ks: seq_key() of every chain, in frame order; frame_seq_task[f]: the first chain of frame f (+ total).
+void group_long_frames(const uint32_t *ks, size_t ns, const std::vector<uint32_t> &frame_seq_task, uint32_t n_frames, int num_cus, ListOrder &order)
+{
+    if (order.seq_perm.empty() || order.frame_order.empty() || ns == 0) return;
+    uint64_t sum = 0;
+    for (size_t i = 0; i < ns; i++) sum += ks[i] & 0xFFFFFu;
+    const uint32_t n_max = ks[order.seq_perm[0]] & 0xFFFFFu, lim = std::max(n_max / 2, 2048u);
+    const uint64_t in_flight = (uint64_t)kQ4Chains * (uint64_t)std::max(num_cus, 1);
+    size_t nl = 0;
+    while (nl < ns && (ks[order.seq_perm[nl]] & 0xFFFFFu) >= lim) nl++;
+    // (measured on the reference's corpus, longest chain x chains in flight / all sequences = 6.3 / 3.1 / 1.6 at 1 / 2 / 4 GiB: the pass
+    // 9.86 -> 8.26, 10.84 -> 9.19, 14.14 -> 15.2 ms -- beyond 2.5 the grouping pays)
+    if ((uint64_t)n_max * in_flight * 2 < 5 * sum || nl == 0 || nl > (size_t)kQ4Chains * 64) return;
+    std::vector<uint8_t> is_long(n_frames, 0);
+    auto frame_of = [&](uint32_t task) {
+        return (uint32_t)(std::upper_bound(frame_seq_task.begin(), frame_seq_task.end(), task) - frame_seq_task.begin()) - 1u;
+    };
+    for (size_t i = 0; i < nl; i++) is_long[frame_of(order.seq_perm[i])] = 1;
+    std::stable_partition(order.frame_order.begin(), order.frame_order.end(), [&](uint32_t f) { return is_long[f] != 0; });
+    std::stable_partition(order.seq_perm.begin(), order.seq_perm.end(), [&](uint32_t t) { return is_long[frame_of(t)] != 0; });
+    for (uint32_t f = 0; f < n_frames; f++) order.long_frames += is_long[f];
+    for (size_t i = 0; i < ns; i++) order.long_tasks += is_long[frame_of(order.seq_perm[i])];
+    if (order.long_frames == n_frames) order.long_frames = order.long_tasks = 0;  // (nothing to run beside them)
+}
 inline uint32_t huf_quad_key(const HufTask *q4)
 {
     uint32_t longest = 0, mb = 1;
@@ -680,34 +708,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         for (size_t q = 0; q < kh.size(); q++) kh[q] = huf_quad_key(&huf_tasks[4 * q]);
         for (uint32_t f = 0; f < b->n_frames; f++) caps[f] = b->frames[f].out_capacity;
         plan_order(ks.data(), ks.size(), kh.data(), kh.size(), caps.data(), caps.size(), b->in_size, order);
-        // The frames that hold the longest chains, apart (real data: one chain of 42 k sequences is 4.9 ms of a sequence stage whose
-        // work is 0.8 ms at 1 GiB -- and the execution of every OTHER frame, 4.9 ms of its own, waited for it).  When the longest chain
-        // is more than 2.5 rounds of the chip's work: the chains of at least half its length (and 2 048 sequences) are the long ones,
-        // the frames that hold any of them go first in the frame order, their chains first in the task list, each part in its old order;
-        // mzd_batch_run decodes and executes the two groups on two streams.
-        if (!order.seq_perm.empty() && !order.frame_order.empty()) {
-            const size_t ns = ks.size();
-            uint64_t sum = 0;
-            for (size_t i = 0; i < ns; i++) sum += ks[i] & 0xFFFFFu;
-            const uint32_t n_max = ks[order.seq_perm[0]] & 0xFFFFFu, lim = std::max(n_max / 2, 2048u);
-            const uint64_t in_flight = (uint64_t)kQ4Chains * (uint64_t)std::max(ctx->num_cus, 1);
-            size_t nl = 0;
-            while (nl < ns && (ks[order.seq_perm[nl]] & 0xFFFFFu) >= lim) nl++;
-            // (measured on the reference's corpus, longest chain x chains in flight / all sequences = 6.3 / 3.1 / 1.6 at 1 / 2 / 4 GiB: the pass
-            // 9.86 -> 8.26, 10.84 -> 9.19, 14.14 -> 15.2 ms -- beyond 2.5 the grouping pays)
-            if ((uint64_t)n_max * in_flight * 2 >= 5 * sum && nl > 0 && nl <= (size_t)kQ4Chains * 64) {
-                std::vector<uint8_t> is_long(b->n_frames, 0);
-                auto frame_of = [&](uint32_t task) {
-                    return (uint32_t)(std::upper_bound(frame_seq_task.begin(), frame_seq_task.end(), task) - frame_seq_task.begin()) - 1u;
-                };
-                for (size_t i = 0; i < nl; i++) is_long[frame_of(order.seq_perm[i])] = 1;
-                std::stable_partition(order.frame_order.begin(), order.frame_order.end(), [&](uint32_t f) { return is_long[f] != 0; });
-                std::stable_partition(order.seq_perm.begin(), order.seq_perm.end(), [&](uint32_t t) { return is_long[frame_of(t)] != 0; });
-                for (uint32_t f = 0; f < b->n_frames; f++) order.long_frames += is_long[f];
-                for (size_t i = 0; i < ns; i++) order.long_tasks += is_long[frame_of(order.seq_perm[i])];
-                if (order.long_frames == b->n_frames) order.long_frames = order.long_tasks = 0;  // (nothing to run beside them)
-            }
-        }
+        group_long_frames(ks.data(), ks.size(), frame_seq_task, b->n_frames, ctx->num_cus, order);
         if (!order.seq_perm.empty()) {
             std::vector<SeqTask> sorted(seq_tasks.size());
             for (size_t i = 0; i < sorted.size(); i++) sorted[i] = seq_tasks[order.seq_perm[i]];
@@ -1270,7 +1271,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
     // gathered there
     db->seq_sorted = db->huf_sorted = false;
     bool have_order = false;
-    db->long_frames = db->long_tasks = 0;  // (batches planned on the device keep one group)
+    db->long_frames = db->long_tasks = 0;
     if (n_seq > 64 || n_hufb > 64 || n_frames > 64) {
         const uint32_t ns = (uint32_t)n_seq, nq = (uint32_t)n_hufb, nk = std::max(ns, nq);
         std::vector<uint32_t> keys((size_t)ns + nq);
@@ -1282,6 +1283,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         }
         ListOrder order;
         plan_order(keys.data(), ns, keys.data() + ns, nq, db->frame_out_cap.data(), n_frames, in_size, order);
+        group_long_frames(keys.data(), ns, db->frame_seq_task, n_frames, ctx->num_cus, order);
         ENSURE(tp.d_perm, tp.cap_perm, (size_t)std::max<uint32_t>(nk, 1) * 4);
         if (!order.seq_perm.empty()) {
             ENSURE(tp.d_sorted, tp.cap_sorted, (size_t)ns * sizeof(SeqTask));
@@ -1309,6 +1311,10 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
             HIP_OR_FAIL(hipMemcpyAsync(db->d_frame_order, order.frame_order.data(), (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
             HIP_OR_FAIL(hipStreamSynchronize(s));
             have_order = true;
+            if (db->seq_sorted) {
+                db->long_frames = order.long_frames;
+                db->long_tasks = order.long_tasks;
+            }
         }
     }
     if (!have_order && db->d_frame_order) {  // a recycled slot whose previous batch had an order

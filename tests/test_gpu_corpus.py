@@ -135,7 +135,7 @@ def test_heterogeneous_batch_in_two_groups_of_frames(corpus):
     """A batch whose sequence stage is as long as its longest chain (the reference's corpus: one chain of 42 k sequences among 2 445)
     is decoded and executed in two groups of frames on two streams -- the frames that hold the long chains, and the others beside
     them (mzd_batch_upload groups them, MZD_PASS_TWO_GROUPS says so); the same bytes and statuses as with the frames in one group
-    (a batch of frames of one kind; the same corpus planned on the device), damaged frames included, run after run."""
+    (a batch of frames of one kind takes no grouping), planned on the host and on the device, damaged frames included, run after run."""
     from sparkzstd_amd import _lib, api
     from tools import synth_binding as sb
     frames = [comp for _, comp, *_ in corpus] * 3
@@ -149,7 +149,7 @@ def test_heterogeneous_batch_in_two_groups_of_frames(corpus):
     assert rb.pass_flags & _lib.MZD_PASS_TWO_GROUPS and rb.pass_flags & _lib.MZD_PASS_EXEC_C
     rb.free()
     rb3, _, _, sts_r3 = api.decode_frames_resident(frames, c, device_plan=True)
-    assert not rb3.pass_flags & _lib.MZD_PASS_TWO_GROUPS  # (batches planned on the device keep one group)
+    assert rb3.pass_flags & _lib.MZD_PASS_TWO_GROUPS  # (planned on the device: the same grouping from the keys the device hands back)
     rb3.free()
     outs, sts = z.decode_frames(frames, c)
     outs2, sts2 = z.decode_frames(frames, c)  # (run after run: the third stream's work is ordered behind the pass before)
