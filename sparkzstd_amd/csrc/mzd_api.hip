@@ -139,6 +139,7 @@ struct mzd_dbatch {
     uint32_t seq_class_cells[3][3] = {{512, 512, 256}, {512, 512, 256}, {512, 512, 256}};
     bool huf_sorted = false;           // d_huf_tasks' quads are grouped by table size class, longest streams first
     uint32_t huf_class_end[3] = {0, 0, 0};  // quads of class 0 (tables <= 32 cells), 1 (<= 256), 2 end here
+    uint32_t huf_class_long[3] = {0, 0, 0};  // ... of which the first so many have a stream of kHufLongStream bytes or more
     uint32_t *d_frame_order = nullptr;  // execution order of the frames (largest first), or null
     // a heterogeneous batch whose sequence stage is as long as its longest chain: the first long_frames frames of d_frame_order hold the
     // long chains, and their chains are the first long_tasks of d_seq_tasks (0: no such grouping)
@@ -196,9 +197,12 @@ constexpr const char *exp_env(const char *) { return nullptr; }
 
 // ---- heterogeneous work lists are ordered by size (see mzd_dbatch): chains of one workgroup run until the longest is done,
 // the 64 Huffman streams of a wavefront until the longest is done, a frame is one serial job of the execution stage.
+// A lane per stream lasts as long as its stream: the quads of a class whose longest stream regenerates this many bytes or more take
+// k_huf_seg (a wavefront per stream, its segments in parallel) -- real data's Huffman stage, alone: 3.05 -> 1.12 ms at 1 GiB
+constexpr uint32_t kHufLongStream = 4096;
 struct ListOrder {
     std::vector<uint32_t> seq_perm, huf_perm, frame_order;  // empty: leave the list in frame order
-    uint32_t huf_class_end[3] = {0, 0, 0};
+    uint32_t huf_class_end[3] = {0, 0, 0}, huf_class_long[3] = {0, 0, 0};
     uint32_t seq_class_end[3] = {0, 0, 0}, seq_class_logs[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // LL, ML, OF accuracy logs per class
     uint32_t long_frames = 0, long_tasks = 0;  // see mzd_dbatch
 };
@@ -242,7 +246,11 @@ void plan_order(const uint32_t *seq_nseq, size_t ns, const uint32_t *huf_key, si
         o.huf_perm.resize(nq);
         for (size_t q = 0; q < nq; q++) o.huf_perm[q] = (uint32_t)q;
         std::stable_sort(o.huf_perm.begin(), o.huf_perm.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
-        for (size_t q = 0; q < nq; q++) o.huf_class_end[key[o.huf_perm[q]] >> 40] = (uint32_t)q + 1;
+        for (size_t q = 0; q < nq; q++) {
+            const uint64_t kq = key[o.huf_perm[q]];
+            o.huf_class_end[kq >> 40] = (uint32_t)q + 1;
+            if (0xFFFFFFu - (uint32_t)(kq & 0xFFFFFFu) >= kHufLongStream) o.huf_class_long[kq >> 40]++;  // (the first ones of the class: longest first)
+        }
         for (int c = 1; c < 3; c++) o.huf_class_end[c] = std::max(o.huf_class_end[c], o.huf_class_end[c - 1]);
     }
     uint64_t csum = 0, cmx = 0;
@@ -743,7 +751,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         for (int k = 0; k < 3; k++) db->seq_class_cells[c][k] = 1u << std::min<uint32_t>(order.seq_class_logs[c][k], k == 2 ? 8u : 9u);
     }
     db->huf_sorted = huf_sorted;
-    for (int c = 0; c < 3; c++) db->huf_class_end[c] = huf_class_end[c];
+    for (int c = 0; c < 3; c++) {
+        db->huf_class_end[c] = huf_class_end[c];
+        db->huf_class_long[c] = order.huf_class_long[c];
+    }
     db->frame_seq_task = std::move(frame_seq_task);
     db->frame_in_lo = std::move(frame_in_lo);
     db->frame_in_hi = std::move(frame_in_hi);
@@ -1314,7 +1325,10 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
             HIP_OR_FAIL(hipMemcpyAsync(db->d_huf_tasks, tp.d_sorted, (size_t)nq * 4 * sizeof(HufTask), hipMemcpyDeviceToDevice, s));
             HIP_OR_FAIL(hipStreamSynchronize(s));
             db->huf_sorted = true;
-            for (int c = 0; c < 3; c++) db->huf_class_end[c] = order.huf_class_end[c];
+            for (int c = 0; c < 3; c++) {
+                db->huf_class_end[c] = order.huf_class_end[c];
+                db->huf_class_long[c] = order.huf_class_long[c];
+            }
         }
         if (!order.frame_order.empty()) {
             ENSURE(db->d_frame_order, db->cap.frame_order, (size_t)n_frames * 4);
@@ -2008,6 +2022,19 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             uint32_t q0 = 0;
             for (int c = 0; c < 3; c++) {
                 const uint32_t q1 = db->huf_class_end[c];
+                // the class's long streams first, a wavefront each (round 5, `profiles/r5_het_huf.txt`: the stage alone 3.05 -> 1.12 ms at 1 GiB
+                // of real data, 3.9 -> 2.5 at 4 GiB; beside the sequence stage 3.2 -> 1.6 -- which is when the execution of a batch in two
+                // groups of frames may start)
+                if (q1 > q0 && hv == 0) {
+                    const uint32_t nl = std::min(db->huf_class_long[c], q1 - q0);
+                    if (nl) {
+                        const uint32_t cells = std::min(db->huf_slot_cells, kClassCells[c]);
+                        const uint32_t tbl = (uint32_t)(((size_t)cells * 2 + 15) & ~(size_t)15);
+                        k_huf_seg<<<nl, 256, (size_t)tbl + kHufSegStripBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, 4 * nl, db->d_huf_entries,
+                                                                                  db->d_litbuf, db->d_out, db->d_sums, tbl);
+                        q0 += nl;
+                    }
+                }
                 if (q1 > q0) {
                     const uint32_t cells = std::min(db->huf_slot_cells, kClassCells[c]), n = 4 * (q1 - q0);
                     const size_t lds = std::max<size_t>((size_t)kHufQuads * cells * 2, ctx->opt.huf_min_lds);
