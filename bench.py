@@ -393,6 +393,12 @@ def secondary_workloads(z, sb, torch, device, headline):
     cb, co, cl, ce = corpus_batch(corpus, corpus["reps"])
     measure("decodecorpus_1GiB_real_data", cb, co, cl, ce, lambda d_out, rb: verify_corpus(torch, d_out, rb, corpus, ce, len(co))[0], steps=5,
             note=f"the reference's {len(corpus['names'])} golden frames x {corpus['reps']} replicas; sha256 of the first replica and one frame of every other")
+    del cb, co, cl, ce
+    corpus4 = load_corpus(4.0)  # (the size profiles/r*_corpus_* are measured at: the sequence stage bound by its work, frames in one group)
+    cb, co, cl, ce = corpus_batch(corpus4, corpus4["reps"])
+    measure("decodecorpus_4GiB_real_data", cb, co, cl, ce, lambda d_out, rb: verify_corpus(torch, d_out, rb, corpus4, ce, len(co))[0], steps=5,
+            note=f"the reference's {len(corpus4['names'])} golden frames x {corpus4['reps']} replicas; sha256 of the first replica and one frame of every other")
+    del cb, co, cl, ce
     synth("one_frame_256MiB_block_mode", 4, 1, 268435456, steps=3, warmup=1)
     return out
 
