@@ -45,6 +45,35 @@ def test_synth_frames_decode_with_oracle_and_libzstd(oracle, kind, mode, n):
         assert not L.ZSTD_isError(r) and dst.raw[:r] == data
 
 
+def test_spliced_frames_decode_alike_with_oracle_and_libzstd(oracle):
+    """The frames the GPU suite splices for the executor's small-block path (tests/frame_splice.py: blocks with sequences whose
+    matches and offset history reach back over Raw / RLE / literals-only blocks of every size put between them): the oracle and
+    libzstd regenerate the same bytes -- the oracle, which the device is checked against there, is pinned on them too."""
+    from tests.frame_splice import frame_blocks, splice_frame, literal_block
+    L = _libzstd()
+    if L is None:
+        pytest.skip("no libzstd on this box")
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 7, 8, 9, 63, 64, 511, 512, 513, 1024, 2047, 2048, 2049, 5000]
+    src = frame_blocks(sb.compress(sb.generate(sb.TEXT, 4242, 3 * 131072 - 777), sb.MODE_FULL)[0])
+    huf = [b for b in frame_blocks(sb.compress(sb.generate(sb.TEXT, 4243, 1500), sb.MODE_LITERALS)[0]) if b[0] == 2]
+    assert len(src) >= 3 and huf
+    blocks = []
+    for j, b in enumerate(src):
+        blocks.append(b)
+        for n in sizes[j::3]:
+            data = bytes(rng.integers(0, 256, size=max(n, 1), dtype=np.uint8))[:n]
+            # (a compressed block of two bytes -- no literals, no sequences -- is below libzstd's minimum and rejected there; the reference
+            # takes it, and so do the oracle and the device: the GPU suite has it, this comparison cannot)
+            blocks += [(0, data, n), (1, b"\x7e", max(n, 1)), literal_block(data or b"x"), literal_block(data or b"x", rle=True), huf[0]]
+    frame = splice_frame(blocks)
+    rc, out, consumed, _ = oracle.decode_frame(frame, cap=8 << 20)
+    assert rc == 0 and consumed == len(frame)
+    dst = ctypes.create_string_buffer(8 << 20)
+    r = L.ZSTD_decompress(dst, 8 << 20, frame, len(frame))
+    assert not L.ZSTD_isError(r) and r == len(out) and dst.raw[:r] == out
+
+
 def test_config_batches_have_the_surveyed_shape(oracle):
     """config 4 ~ 12.5k sequences / ~43 KB per frame (zstd -3 shape), config 3 has 0
     sequences and MaxBits 11, config 2 alternates raw / rle."""
