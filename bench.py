@@ -33,18 +33,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("sparkzstd_amd/csrc/mzd_kernels.hip", "sparkzstd_amd/csrc/mzd_seq_q4.hip", "sparkzstd_amd/csrc/mzd_exec_b.hip", "sparkzstd_amd/csrc/mzd_exec_c.hip", "sparkzstd_amd/csrc/mzd_exec_blk.hip", "sparkzstd_amd/csrc/mzd_api.hip",
-                  "sparkzstd_amd/csrc/mzd_device.h")
+# the files libmzd.so is made of, in the order sparkzstd_amd/csrc/Makefile hashes them into mzd_build_id()
+LIBRARY_SOURCES = ("mzd_api.hip", "mzd_device.h", "mzd_exec_b.hip", "mzd_exec_blk.hip", "mzd_exec_c.hip", "mzd_kernels.hip", "mzd_parse.hip",
+                   "mzd_seq_q4.hip", "planner.cpp", "../../include/mzd.h")
+
+
+def library_src_sha16():
+    """what `make -C sparkzstd_amd/csrc` would stamp into a library built from the sources in the tree NOW (None: no sources here)"""
+    h = hashlib.sha256()
+    try:
+        for rel in LIBRARY_SOURCES:
+            with open(os.path.join(ROOT, "sparkzstd_amd", "csrc", rel), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
 
 
 def kernel_src_sha16():
-    """Identity of the device code a counter file was measured on (the GPU box has no .git): a traffic file
-    carries it and is only quoted when it matches the sources this run was built from."""
-    h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    """Identity of the device code a counter file was measured on: what the LOADED library says about itself (mzd_build_id: the
+    hash of its sources, put in at build time) -- not a hash of the files beside it, which a stale libmzd.so would carry too.  A
+    traffic / issue file carries it and is only quoted when it matches the library this run loaded."""
+    from sparkzstd_amd import _lib
+    return _lib.load().mzd_build_id().decode()
 
 
 def parse():
@@ -143,7 +154,7 @@ def usable_cores():
     return n, quota
 
 
-def cpu_baseline(blob, off, ln, exp_len, budget_s):
+def cpu_baseline(blob, off, ln, exp_len, budget_s, cks=None):
     """Oracle ("port" of the reference algorithm, plain C) on the host cores, bounded sample of the
     SAME frames.  Reported next to the GPU number; never the thing measured as `value`."""
     from tests.oracle_binding import load_oracle
@@ -207,6 +218,16 @@ def cpu_baseline(blob, off, ln, exp_len, budget_s):
            "one_thread": {"value": round(csum[n1] / dt1 / 1e6, 1), "unit": "MB/s", "cores": 1,
                           "sample": f"first {n1} frames, {dt1:.2f}s"}}
     res["libzstd"] = libzstd_line(blob, off, ln, exp_len, n1, cores)
+    if cks is not None:
+        # The batch pinned to the ORACLE at the sample's full size (untimed, one more pass): the word sum of every frame the oracle
+        # regenerates against the generator's figure for the original content -- the same figure the device's output is held to,
+        # so device == generator == oracle, frame by frame.  (A position-weighted sum is a detector, not a hash.)
+        st, ol, ws = orc.decode_frames_wsum(blob, off[:sample], ln[:sample], cap, threads=cores)
+        good = bool((st == 0).all() and (ol == exp_len[:sample]).all() and (ws == np.asarray(cks[:sample], dtype=np.uint64)).all())
+        res["oracle_frames_checked"] = int(sample)
+        res["oracle_bytes_checked"] = int(csum[sample])
+        res["oracle_equals_generator"] = good
+        res["ok"] = bool(res["ok"] and good)
     return res
 
 
@@ -406,6 +427,46 @@ def secondary_workloads(z, sb, torch, device, headline):
     return out
 
 
+def rank_share(a, rank, world, corpus_reps=None):
+    """What rank `rank` of `world` decodes: -> (first unit, units of this rank, scaling, units of the whole job's base batch).  The unit
+    is the frame (the replica of the corpus for --workload corpus).  Default = BASELINE configs[4]: ONE batch of `base` units cut
+    into contiguous ranges, the remainder to the first ranks (sparkzstd_amd/sharding.py: the split the library's own multi-GPU
+    entry makes; framedecompressor.go:42-52 is why it is legal) -- "strong"; --weak: `base` units on EVERY rank."""
+    base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
+    if corpus_reps is not None:
+        base = corpus_reps
+    if a.weak and not a.strong:
+        return rank * base, base, "weak", base
+    from sparkzstd_amd.sharding import frame_range
+    first, end = frame_range(base, rank, world)
+    return first, end - first, "strong", base
+
+
+def gen_threads_for(a, world, cores):
+    """host threads a rank generates / plans its frames with: the ranks of one node share its cores"""
+    return a.gen_threads or max(1, cores // max(1, world))
+
+
+def per_gpu_rows(gathered):
+    """the ranks' own figures (rank, device, frames, ms per step, path ms, algorithmic GB/s, C bytes, D bytes -- one 8-vector per
+    rank, as all_gather hands them over) -> (rows for the line's `per_gpu`, C bytes of all ranks, D bytes of all ranks)"""
+    rows = [{"rank": int(g[0]), "device": int(g[1]), "frames": int(g[2]), "ms_per_step": round(float(g[3]), 4),
+             "path_ms": round(float(g[4]), 4), "algorithmic_GBs": round(float(g[5]), 1),
+             "hbm_frac": round(float(g[5]) / HBM_PEAK_GBS, 4)} for g in gathered]
+    return rows, sum(int(g[6]) for g in gathered), sum(int(g[7]) for g in gathered)
+
+
+def job_figures(rows, c_bytes_all, d_bytes_all, elapsed, steps, world):
+    """whole-job figures from the slowest rank's clock: value = regenerated bytes of ALL ranks / max-over-ranks time"""
+    ms = elapsed / steps * 1e3
+    return {"value": d_bytes_all / (elapsed / steps) / 1e6, "ms_per_step": ms,
+            "aggregate": {"algorithmic_GBs": round((c_bytes_all + d_bytes_all) / (ms * 1e-3) / 1e9, 1),
+                          "hbm_frac_of_all_gpus": round((c_bytes_all + d_bytes_all) / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                          "slowest_rank": max(rows, key=lambda r: r["ms_per_step"])["rank"],
+                          "devices": sorted(r["device"] for r in rows),
+                          "devices_distinct": len({r["device"] for r in rows}) == len(rows)}}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -441,22 +502,11 @@ def main():
     if a.workload == "corpus":
         corpus = load_corpus(a.corpus_gib, world)
         assert not a.frames_per_gpu, "--workload corpus sizes the batch with --corpus-gib"
-    base = a.frames_per_gpu or (65536 if a.config == 4 else 4096)
-    if corpus:
-        base = corpus["reps"]  # the unit that is split over the ranks is the replica
-    if a.weak and not a.strong:
-        per = base
-        first, scaling = rank * per, "weak"
-    else:
-        # contiguous ranges of ONE batch of `base` frames (sparkzstd_amd/sharding.py: the same split the library's
-        # multi-GPU helper makes); the remainder goes to the first ranks
-        from sparkzstd_amd.sharding import frame_range
-        first, end = frame_range(base, rank, world)
-        per, scaling = end - first, "strong"
+    first, per, scaling, base = rank_share(a, rank, world, corpus["reps"] if corpus else None)  # (the corpus is split by replicas)
 
     # ---- synthetic batch (host), planning (host), upload: all outside the timed region
     t0 = time.perf_counter()
-    gen_threads = a.gen_threads or max(1, usable_cores()[0] // max(1, world))
+    gen_threads = gen_threads_for(a, world, usable_cores()[0])
     if corpus:
         reps = per
         blob, off, ln, exp_len = corpus_batch(corpus, reps)
@@ -581,11 +631,10 @@ def main():
         dist.all_gather(gathered, mine)
     else:
         gathered = [mine]
-    per_gpu = [{"rank": int(g[0].item()), "device": int(g[1].item()), "frames": int(g[2].item()),
-                "ms_per_step": round(g[3].item(), 4), "path_ms": round(g[4].item(), 4),
-                "algorithmic_GBs": round(g[5].item(), 1), "hbm_frac": round(g[5].item() / HBM_PEAK_GBS, 4)} for g in gathered]
-    c_bytes_all = sum(int(g[6].item()) for g in gathered)
-    d_bytes_all = sum(int(g[7].item()) for g in gathered)
+    per_gpu, c_bytes_all, d_bytes_all = per_gpu_rows([g.tolist() for g in gathered])
+    if world > 1 and "MZD_BENCH_DEVICE" not in os.environ:
+        # one process per GPU means one GPU per process: two ranks on one device would halve each other and still print a line
+        assert len({p["device"] for p in per_gpu}) == world, f"ranks share a device: {[p['device'] for p in per_gpu]}"
 
     # measured copy ceiling: a plain 16 B/lane streaming kernel that reads C and writes D bytes (this rank's)
     ceiling = None
@@ -601,8 +650,8 @@ def main():
     if rank == 0:
         total_frames = sum(p["frames"] for p in per_gpu)
         d_bytes = d_bytes_all
-        ms_per_step = elapsed / a.steps * 1e3
-        value = d_bytes / (elapsed / a.steps) / 1e6
+        job = job_figures(per_gpu, c_bytes_all, d_bytes_all, elapsed, a.steps, world)
+        ms_per_step, value = job["ms_per_step"], job["value"]
         # roofline of the dominant kernel set: algorithmic bytes = compressed bytes read once +
         # decompressed bytes written once, per launch (= one pass over this rank's batch)
         c_bytes = int(stats.compressed_bytes)
@@ -672,7 +721,7 @@ def main():
                                "frac": round(my_d_bytes / (xxh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         cpu = None
         if a.cpu_seconds > 0:
-            cpu = cpu_baseline(blob, off, ln, exp_len, a.cpu_seconds)
+            cpu = cpu_baseline(blob, off, ln, exp_len, a.cpu_seconds, None if corpus else cks)
         names = {2: "config2 raw/rle single-block 128KiB frames", 3: "config3 4-stream huffman literals, 0 sequences",
                  4: "config4 text-like 128KiB frames: huffman literals + FSE sequences + match copy"}
         line = {
@@ -693,7 +742,11 @@ def main():
                        "seq_variant": a.seq_variant, "exec_threads": a.exec_threads or 128,
                        "exec_chunk": a.exec_chunk or 8192},
             "roofline": roof, "cpu_baseline": cpu, "bit_exact": ok, "ranks_seen": len(per_gpu), "per_gpu": per_gpu,
+            # (all ranks together, on the slowest rank's clock: what SCALE's N = 1 line is compared with BENCH's by, and N > 1 with N = 1)
+            "aggregate": job["aggregate"],
             "kernel_src_sha16": kernel_src_sha16(),
+            # (the library reports the hash of the sources it was BUILT from; the tree's sources hashed now: a stale library shows)
+            "library_matches_tree_sources": (library_src_sha16() == kernel_src_sha16()) if library_src_sha16() else None,
             "hbm_peak_frac_decompressed": round(value / 1e3 / world / HBM_PEAK_GBS, 4),
             "exec_variant": a.exec_variant,
             "setup_s": {"generate": round(t_gen, 2), "plan": round(t_plan, 3), "upload": round(t_upload, 3),

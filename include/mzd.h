@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 7
+#define MZD_ABI_VERSION 8
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -195,6 +195,10 @@ typedef struct mzd_dbatch mzd_dbatch; /* a batch resident in HBM */
 typedef struct mzd_plan mzd_plan;     /* host planner state */
 
 int mzd_abi_version(void);
+/* Identity of the binary (ABI 8): the first 16 hex digits of the sha256 over the sources the library was built from
+ * (sparkzstd_amd/csrc/Makefile puts it in at build time; "unstamped" for a build that went around the Makefile).  bench.py stamps
+ * its line and the rocprof counter files with it: what RAN, not what lies beside it in the tree. */
+const char *mzd_build_id(void);
 /* "hip-gfx950". There is no CPU backend. */
 const char *mzd_backend(void);
 const char *mzd_strerror(int code);

@@ -1122,6 +1122,41 @@ int orc_decode_frames(const uint8_t *blob, const uint64_t *frame_off, const uint
     return first;
 }
 
+int orc_decode_frames_wsum(const uint8_t *blob, const uint64_t *frame_off, const uint64_t *frame_len,
+                           int n_frames, uint8_t *dst, const uint64_t *dst_off, const uint64_t *dst_cap,
+                           uint64_t *out_len, int32_t *status, uint64_t *wsum)
+{
+    int first = 0;
+    frame_state *fs = (frame_state *)calloc(1, sizeof(frame_state));
+    if (!fs) return ORC_ERR_UNSUPPORTED;
+    for (int f = 0; f < n_frames; f++) {
+        size_t ol = 0;
+        uint8_t *d = dst + dst_off[f];
+        int rc = decode_frame_with(fs, blob + frame_off[f], (size_t)frame_len[f], d, (size_t)dst_cap[f], &ol, NULL, NULL);
+        if (out_len) out_len[f] = ol;
+        if (status) status[f] = rc;
+        if (rc && !first) first = rc;
+        if (wsum) {
+            uint64_t acc = 0, j = 0;
+            size_t i = 0;
+            for (; i + 8 <= ol; i += 8, j++) {
+                uint64_t w;
+                memcpy(&w, d + i, 8);
+                acc += w * (2 * j + 1);
+            }
+            if (i < ol) {
+                uint64_t w = 0;
+                memcpy(&w, d + i, ol - i);
+                acc += w * (2 * j + 1);
+            }
+            wsum[f] = acc;
+        }
+    }
+    frame_state_free(fs);
+    free(fs);
+    return first;
+}
+
 const char *orc_strerror(int code)
 {
     switch (code) {

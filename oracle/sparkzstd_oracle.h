@@ -206,6 +206,14 @@ int orc_decode_frames(const uint8_t *blob, const uint64_t *frame_off, const uint
                       int n_frames, uint8_t *dst, const uint64_t *dst_off, const uint64_t *dst_cap,
                       uint64_t *out_len, int32_t *status);
 
+/* The same, and a word sum of every frame's regenerated bytes: sum_j w_j * (2j + 1) mod 2^64 over its little-endian 64-bit words
+ * (tail zero padded) -- the detector bench.py and the full-size tests compare a synthetic batch with (a position-weighted sum,
+ * not a hash; tools/synth takes it from the ORIGINAL content).  Not a reference function: test plumbing that lets the frames of
+ * a thread share one destination buffer and still be checked byte for byte against the generator, at the headline's full size. */
+int orc_decode_frames_wsum(const uint8_t *blob, const uint64_t *frame_off, const uint64_t *frame_len,
+                           int n_frames, uint8_t *dst, const uint64_t *dst_off, const uint64_t *dst_cap,
+                           uint64_t *out_len, int32_t *status, uint64_t *wsum);
+
 const char *orc_strerror(int code);
 
 #ifdef __cplusplus

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 7
+MZD_ABI_VERSION = 8
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -16,7 +16,7 @@ MZD_BATCH_OUT_ON_DEVICE = 2
 
 # every symbol include/mzd.h declares (tests/test_abi.py checks the export list against the header)
 EXPORTS = [
-    "mzd_abi_version", "mzd_backend", "mzd_strerror", "mzd_device_count", "mzd_create", "mzd_destroy",
+    "mzd_abi_version", "mzd_build_id", "mzd_backend", "mzd_strerror", "mzd_device_count", "mzd_create", "mzd_destroy",
     "mzd_last_error", "mzd_batch_upload", "mzd_batch_run", "mzd_sync", "mzd_batch_download", "mzd_batch_read_out",
     "mzd_batch_device_out", "mzd_batch_device_status", "mzd_batch_device_out_len", "mzd_batch_free",
     "mzd_decode_batch", "mzd_last_run_kernel_ms", "mzd_timing_reset", "mzd_batch_get_stats", "mzd_plan_create",
@@ -126,6 +126,7 @@ def load():
     sig = {
         "mzd_abi_version": (i32, []),
         "mzd_backend": (ctypes.c_char_p, []),
+        "mzd_build_id": (ctypes.c_char_p, []),
         "mzd_strerror": (ctypes.c_char_p, [i32]),
         "mzd_device_count": (i32, []),
         "mzd_create": (vp, [i32, ctypes.POINTER(Options), ctypes.POINTER(i32)]),

@@ -591,13 +591,14 @@ def decode_frames_resident(frames, ctx: Context = None, device_tables: bool = Tr
         rb = ctx.upload_frames(blob, off, ln)
         try:
             rb.run()
-            rb.pass_flags = rb.last_pass()
+            last_pass = rb.last_pass()
             _, status, out_len = rb.download(want_out=False)
+            if trim:
+                rb.trim()
         except Exception:
             rb.free()
             raise
-        if trim:
-            rb.trim()
+        rb.pass_flags = last_pass
         return rb, np.asarray(rb.frame_out_offset, dtype=np.uint64), out_len, [int(x) for x in status]
     plan = Plan(device_tables=device_tables)
     try:

@@ -162,7 +162,7 @@ struct mzd_dbatch {
 
 namespace {
 
-constexpr size_t kEvPerRun = 12;
+constexpr size_t kEvPerRun = 14;  // ([12], [13]: the third stream's execution launch of a pass in two groups of frames)
 thread_local std::string g_create_error;
 
 #define HIP_TRY(ctx, expr)                                                                    \
@@ -321,6 +321,10 @@ const int kMaxLog[3] = {9, 8, 9};
 extern "C" {
 
 int mzd_abi_version(void) { return MZD_ABI_VERSION; }
+#ifndef MZD_BUILD_ID
+#define MZD_BUILD_ID "unstamped"
+#endif
+const char *mzd_build_id(void) { return MZD_BUILD_ID; }
 const char *mzd_backend(void) { return "hip-gfx950"; }
 
 const char *mzd_strerror(int code)
@@ -992,35 +996,46 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
         std::vector<uint64_t> starts;
         std::vector<uint32_t> capoff(large.size() + 1, 0);
         if (!large.empty()) {
-            // (room for a block start per 64 bytes of frame; a frame with more blocks than that stays one lane's)
-            std::vector<uint64_t> lo(large.size()), ll(large.size());
+            // (room for a block start per KiB of frame -- 0.8 % of the compressed bytes as transient HBM, 8 MiB for a 1 GiB frame; a slot
+            // per 64 bytes was 12.5 %, ADVICE r5 -- and a frame with more blocks than that stays one lane's, as does a frame that
+            // would take the list beyond 2^28 slots: never a saturated total that the allocation below multiplies by eight.  The
+            // test hook's tiny frames, whose blocks are a few bytes each, keep the slot per 64 bytes.)
+            const uint64_t slot_bytes = ctx->test_large_frame ? 64 : 1024;
+            std::vector<uint64_t> lo, ll;
             uint64_t total = 0;
+            size_t kept = 0;
             for (size_t j = 0; j < large.size(); j++) {
-                lo[j] = frame_off[large[j]];
-                ll[j] = frame_len[large[j]];
-                total += ll[j] / 64 + 16;
-                if (total > 0xFFFFFFFFull) total = 0xFFFFFFFFull;
-                capoff[j + 1] = (uint32_t)total;
+                const uint64_t slots = frame_len[large[j]] / slot_bytes + 16;
+                if (total + slots > (1ull << 28)) continue;  // (stays one lane's)
+                large[kept++] = large[j];
+                lo.push_back(frame_off[large[j]]);
+                ll.push_back(frame_len[large[j]]);
+                total += slots;
+                capoff[kept] = (uint32_t)total;
             }
-            ENSURE(tp.d_foff, tp.cap_foff, large.size() * 8);
-            ENSURE(tp.d_flen, tp.cap_flen, large.size() * 8);
-            ENSURE(tp.d_capoff, tp.cap_capoff, capoff.size() * 4);
-            ENSURE(tp.d_nfound, tp.cap_nfound, large.size() * 4);
-            ENSURE(tp.d_starts, tp.cap_starts, (size_t)total * 8);
-            HIP_OR_FAIL(hipMemcpyAsync(tp.d_foff, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, s));
-            HIP_OR_FAIL(hipMemcpyAsync(tp.d_flen, ll.data(), ll.size() * 8, hipMemcpyHostToDevice, s));
-            HIP_OR_FAIL(hipMemcpyAsync(tp.d_capoff, capoff.data(), capoff.size() * 4, hipMemcpyHostToDevice, s));
-            k_parse_index<<<(uint32_t)((large.size() + 63) / 64), 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, tp.d_capoff, (uint32_t)large.size(),
-                                                                             tp.d_starts, tp.d_nfound);
-            nfound.resize(large.size());
-            HIP_OR_FAIL(hipMemcpyAsync(nfound.data(), tp.d_nfound, large.size() * 4, hipMemcpyDeviceToHost, s));
-            HIP_OR_FAIL(hipStreamSynchronize(s));
-            uint64_t used = 0;
-            for (size_t j = 0; j < large.size(); j++)
-                if (nfound[j] != 0xFFFFFFFFu) used = std::max<uint64_t>(used, (uint64_t)capoff[j] + nfound[j]);
-            starts.resize(used);
-            if (used) HIP_OR_FAIL(hipMemcpyAsync(starts.data(), tp.d_starts, used * 8, hipMemcpyDeviceToHost, s));
-            HIP_OR_FAIL(hipStreamSynchronize(s));
+            large.resize(kept);
+            capoff.resize(kept + 1);
+            if (kept) {
+                ENSURE(tp.d_foff, tp.cap_foff, large.size() * 8);
+                ENSURE(tp.d_flen, tp.cap_flen, large.size() * 8);
+                ENSURE(tp.d_capoff, tp.cap_capoff, capoff.size() * 4);
+                ENSURE(tp.d_nfound, tp.cap_nfound, large.size() * 4);
+                ENSURE(tp.d_starts, tp.cap_starts, (size_t)total * 8);
+                HIP_OR_FAIL(hipMemcpyAsync(tp.d_foff, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, s));
+                HIP_OR_FAIL(hipMemcpyAsync(tp.d_flen, ll.data(), ll.size() * 8, hipMemcpyHostToDevice, s));
+                HIP_OR_FAIL(hipMemcpyAsync(tp.d_capoff, capoff.data(), capoff.size() * 4, hipMemcpyHostToDevice, s));
+                k_parse_index<<<(uint32_t)((large.size() + 63) / 64), 64, 0, s>>>(db->d_in, in_size, tp.d_foff, tp.d_flen, tp.d_capoff, (uint32_t)large.size(),
+                                                                                 tp.d_starts, tp.d_nfound);
+                nfound.resize(large.size());
+                HIP_OR_FAIL(hipMemcpyAsync(nfound.data(), tp.d_nfound, large.size() * 4, hipMemcpyDeviceToHost, s));
+                HIP_OR_FAIL(hipStreamSynchronize(s));
+                uint64_t used = 0;
+                for (size_t j = 0; j < large.size(); j++)
+                    if (nfound[j] != 0xFFFFFFFFu) used = std::max<uint64_t>(used, (uint64_t)capoff[j] + nfound[j]);
+                starts.resize(used);
+                if (used) HIP_OR_FAIL(hipMemcpyAsync(starts.data(), tp.d_starts, used * 8, hipMemcpyDeviceToHost, s));
+                HIP_OR_FAIL(hipStreamSynchronize(s));
+            }
         }
         size_t j = 0;
         for (uint32_t f = 0; f < n_frames; f++) {
@@ -1200,7 +1215,7 @@ static int upload_frames_impl(mzd_ctx *ctx, const uint8_t *in, uint64_t in_size,
             df.first_block = frame_block0;
             df.n_blocks = (uint32_t)f_blocks;
             df.plan_status = MZD_OK;
-            df.has_checksum = (counts[u0].flags & 0x80000000u) ? 1 : 0;
+            df.has_checksum = (counts[u0].flags & 0x80000000u) && (counts[u1 - 1].flags & 0x40000000u) ? 1 : 0;  // header flag AND the 4 bytes were there
             df.checksum = df.has_checksum ? counts[u1 - 1].checksum : 0;
             host_frames.push_back(df);
             host_frame_idx.push_back(f);
@@ -2083,7 +2098,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         HIP_TRY(ctx, hipStreamWaitEvent(s3, ctx->ev_init_done, 0));
         seq_pack = true;  // (full workgroups: the long chains on as few CUs as hold them)
         seq_stream = s3;
+        // (the third stream's launches carry events of their own -- [6], [7] around its sequence kernel, [12], [13] around its execution
+        // kernel -- and mzd_last_run_kernel_ms adds them to the stages' figures as it does for the head of a split pass: without them
+        // both stages of the real-data workloads were under-reported by the long chains' share)
+        if (ev) {
+            ctx->run_split[ctx->runs] |= 8;  // bit 3: two groups of frames
+            HIP_TRY(ctx, hipEventRecord(ev[6], s3));
+        }
         launch_seq_tasks(0, db->long_tasks, true, 0);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[7], s3));
         seq_stream = s;
         seq_pack = false;
         launch_seq_tasks(db->long_tasks, db->n_seq_tasks - db->long_tasks, true, 0);
@@ -2094,7 +2117,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s2));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_huf_done, s2));
         HIP_TRY(ctx, hipStreamWaitEvent(s3, ctx->ev_huf_done, 0));
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[12], s3));
         launch_exec(s3, 0, db->long_frames);
+        if (ev) HIP_TRY(ctx, hipEventRecord(ev[13], s3));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_head_done, s3));
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_huf_done, 0));
         if (ev) HIP_TRY(ctx, hipEventRecord(ev[4], s));
@@ -2213,6 +2238,10 @@ extern "C" int mzd_debug_pipe_stats(unsigned long long *out, int reset)
 int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_fse_entry *out, uint32_t cap)
 {
     if (!ctx || !db || !out || (size_t)table + 1 >= db->fse_dev_off.size()) return -MZD_ERR_INVALID_ARG;
+    if (db->trimmed) {  // (mzd_batch_trim freed the tables: say so instead of handing hipMemcpy a null base)
+        ctx->last_error = "mzd_batch_read_fse_table on a batch that mzd_batch_trim has reduced to its output";
+        return -MZD_ERR_INVALID_ARG;
+    }
     const uint32_t first = db->fse_dev_off[table], n = db->fse_dev_off[table + 1] - first;
     if (n > cap) return -MZD_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return -MZD_ERR_DEVICE;
@@ -2223,6 +2252,10 @@ int mzd_batch_read_fse_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_f
 int mzd_batch_read_huf_table(mzd_ctx *ctx, mzd_dbatch *db, uint32_t table, mzd_huf_entry *out, uint32_t cap)
 {
     if (!ctx || !db || !out || (size_t)table + 1 >= db->huf_dev_off.size()) return -MZD_ERR_INVALID_ARG;
+    if (db->trimmed) {  // (mzd_batch_trim freed the tables: say so instead of handing hipMemcpy a null base)
+        ctx->last_error = "mzd_batch_read_huf_table on a batch that mzd_batch_trim has reduced to its output";
+        return -MZD_ERR_INVALID_ARG;
+    }
     const uint32_t first = db->huf_dev_off[table], n = db->huf_dev_off[table + 1] - first;
     if (n > cap) return -MZD_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return -MZD_ERR_DEVICE;
@@ -2355,7 +2388,7 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
     };
     for (size_t r = 0; r < ctx->runs; r++) {
         hipEvent_t *e = ctx->ev.data() + r * kEvPerRun;
-        const bool split = ctx->run_split[r] & 1, huf_first = ctx->run_split[r] & 2;
+        const bool split = ctx->run_split[r] & 1, huf_first = ctx->run_split[r] & 2, two = ctx->run_split[r] & 8;
         if (ctx->run_split[r] & 4) {  // a copy-only pass (Raw / RLE blocks only)
             acc[3] += el(e[4], e[5]);
             acc[4] += el(e[4], ctx->opt.verify_checksum ? e[11] : e[5]);
@@ -2366,8 +2399,8 @@ int mzd_last_run_kernel_ms(mzd_ctx *ctx, const char **names, float *ms, int cap)
         acc[0] += el(e[0], e[1]);
         acc[1] += el(e[9], e[2]);                                           // k_huf (second stream, or first on the caller's)
         // k_seq head (+ tail, incl. its wait for k_huf); with k_huf first on the same stream the head starts at ITS end
-        acc[2] += el(huf_first ? e[2] : e[1], e[3]) + (split ? el(e[3], e[4]) : 0.0);
-        acc[3] += el(e[4], e[5]) + (split ? el(e[6], e[7]) : 0.0);
+        acc[2] += el(huf_first ? e[2] : e[1], e[3]) + (split ? el(e[3], e[4]) : 0.0) + (two ? el(e[6], e[7]) : 0.0);
+        acc[3] += el(e[4], e[5]) + (split ? el(e[6], e[7]) : 0.0) + (two ? el(e[12], e[13]) : 0.0);
         acc[4] += el(e[0], e[8]);
         if (ctx->opt.verify_checksum) acc[5] += el(e[5], e[11]) + (split ? el(e[7], e[10]) : 0.0);
         cnt++;

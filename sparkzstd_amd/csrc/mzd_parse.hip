@@ -592,7 +592,9 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
     // host keeps them if the first unit saw the flag)
     if (last && (((fhd >> 2) & 1) || !first_unit) && end - p >= 4) {
         c.checksum = base[p] | ((uint32_t)base[p + 1] << 8) | ((uint32_t)base[p + 2] << 16) | ((uint32_t)base[p + 3] << 24);
-        if (first_unit) c.flags |= MZD_FRAME_HAS_CHECKSUM;
+        // (a later unit: "the four bytes were there" -- without it the host would turn a frame cut inside its checksum into
+        // has_checksum = 1, checksum = 0, where the single-lane walk and the host planner leave the flag clear)
+        c.flags |= first_unit ? MZD_FRAME_HAS_CHECKSUM : 0x40000000u;
     }
     // never more than the blocks can regenerate: a (corrupt) header may declare any content size
     if (c.content_size != MZD_UNKNOWN_SIZE && (uflags & kUnitFinal)) c.out_bound = min(c.out_bound, c.content_size);

@@ -24,6 +24,10 @@ class FseTable(ctypes.Structure):
                 ("rle_additional_bits", ctypes.c_int), ("state", ctypes.c_int64)]
 
 
+class HufTable(ctypes.Structure):
+    _fields_ = [("max_bits", ctypes.c_int), ("n_entries", ctypes.c_int), ("symbols", ctypes.c_uint8 * 4096), ("nbits", ctypes.c_uint8 * 4096)]
+
+
 class Ring(ctypes.Structure):
     _fields_ = [("data", u8p), ("len", ctypes.c_int), ("offset", ctypes.c_int),
                 ("all_dirty", ctypes.c_int), ("dump", u8p), ("dump_len", ctypes.c_size_t),
@@ -65,6 +69,8 @@ class Oracle:
         L.orc_rbs_init.argtypes = [ctypes.POINTER(Rbs), ctypes.c_char_p, ctypes.c_int64]
         L.orc_fse_build_predefined.argtypes = [ctypes.POINTER(FseTable), ctypes.c_int]
         L.orc_fse_free.argtypes = [ctypes.POINTER(FseTable)]
+        L.orc_fse_build.argtypes = [ctypes.POINTER(FseTable), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.orc_huf_build.argtypes = [ctypes.POINTER(HufTable), ctypes.c_void_p, ctypes.c_int]
         L.orc_ring_init.argtypes = [ctypes.POINTER(Ring), ctypes.c_int]
         L.orc_ring_free.argtypes = [ctypes.POINTER(Ring)]
         L.orc_ring_push.argtypes = [ctypes.POINTER(Ring), ctypes.c_char_p, ctypes.c_int]
@@ -78,6 +84,8 @@ class Oracle:
         L.orc_xxh64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
         L.orc_decode_frames.restype = ctypes.c_int
         L.orc_decode_frames.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 5
+        L.orc_decode_frames_wsum.restype = ctypes.c_int
+        L.orc_decode_frames_wsum.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 6
 
     def decode_frame(self, src: bytes, cap: int = None, want_trace=False):
         """-> (rc, output bytes, consumed, trace-or-None)"""
@@ -101,6 +109,38 @@ class Oracle:
             }
             self.lib.orc_trace_free(ctypes.byref(tr))
         return rc, out, cons.value, trace
+
+    def decode_frames_wsum(self, blob, off, ln, cap, threads=1):
+        """Every frame of a batch (numpy: blob uint8, off / ln uint64) through the oracle on `threads` host threads, each frame of a
+        thread into the same `cap`-byte buffer -> (status int32[], out_len uint64[], wsum uint64[]): the position-weighted word sum
+        of the bytes the ORACLE regenerated, the figure tools/synth takes from the original content (sb.checksum64)."""
+        import threading
+        import numpy as np
+        n = len(off)
+        st = np.zeros(n, dtype=np.int32)
+        ol = np.zeros(n, dtype=np.uint64)
+        ws = np.zeros(n, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ln = np.ascontiguousarray(ln, dtype=np.uint64)
+        threads = max(1, min(threads, n))
+        per = (n + threads - 1) // threads
+        keep, ths = [], []
+        for t in range(threads):
+            a, b = t * per, min(n, (t + 1) * per)
+            if a >= b:
+                continue
+            dst = np.zeros(cap + 64, dtype=np.uint8)
+            doff = np.zeros(b - a, dtype=np.uint64)
+            dcap = np.full(b - a, cap, dtype=np.uint64)
+            keep.append((dst, doff, dcap))
+            ths.append(threading.Thread(target=self.lib.orc_decode_frames_wsum, args=(
+                blob.ctypes.data, off[a:b].ctypes.data, ln[a:b].ctypes.data, b - a, dst.ctypes.data, doff.ctypes.data, dcap.ctypes.data,
+                ol[a:b].ctypes.data, st[a:b].ctypes.data, ws[a:b].ctypes.data)))
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return st, ol, ws
 
     def xxh64(self, data: bytes, seed: int = 0) -> int:
         return int(self.lib.orc_xxh64(data, len(data), seed))

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
 
 def test_identity_and_errors():
     L = _lib.load()
-    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 7
+    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 8
     assert L.mzd_backend() == b"hip-gfx950"
     assert b"Magicnum" in L.mzd_strerror(2)
     assert L.mzd_device_count() >= 0

@@ -640,13 +640,14 @@ def test_fuzzed_frames_never_fault_and_agree_with_oracle(corpus, oracle, seq_var
     assert sts2 == [0]
 
 
-def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
+def test_device_built_fse_tables_equal_host_tables(corpus, ctx, oracle):
     """k_fse_build / k_huf_build: every FSE table built on the device from its normalised
     counts and every Huffman table filled from its weights is cell-for-cell the table the host planner
     builds (fse.go:136-230, huffman.go:112-190), over the whole corpus plus synthetic config-3/4
     frames; and the batch decodes to the same bytes in both forms."""
     from sparkzstd_amd import _lib
     from tools import synth_binding as sb
+    from tests import fse_build_ref, oracle_binding as ob
     blob, off, ln, ck, ns = sb.make_batch(4, 7, 96, threads=4)
     blob3, off3, ln3, _, _ = sb.make_batch(3, 11, 32, threads=4)  # MaxBits 11 Huffman tables
     frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)] + \
@@ -662,13 +663,29 @@ def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
         st = rb.stats()
         n_counts = sum(1 for i in range(bd.n_fse_tables) if bd.fse_tables[i].build & _lib.MZD_FSE_FROM_COUNTS)
         assert st.n_fse_built == n_counts and n_counts > 2000
+        n_vs_oracle = 0
         for ti in range(bd.n_fse_tables):
             dh = bh.fse_tables[ti]
             want = host[dh.entries_off:dh.entries_off + (1 << dh.acc_log)]
             got = rb.read_fse_table(ti)
             assert got.shape == want.shape and (got == want).all(), (ti, dh.acc_log, dh.kind)
+            # ... and the ORACLE's: orc_fse_build (fse.go:136-230 restated) on the same normalised counts, cell for cell
+            # (baseline, number of bits, the untranslated symbol) -- the device against the checker, not only against the host planner
+            if bd.fse_tables[ti].build & _lib.MZD_FSE_FROM_COUNTS:
+                counts = fse_build_ref.counts_of(bd, ti)
+                t = ob.FseTable()
+                t.acc_log, t.n_values = dh.acc_log, len(counts)
+                for k, cnt in enumerate(counts):
+                    t.values[k] = cnt + 1  # (fse.go:19: the value kept is the probability + 1)
+                assert oracle.lib.orc_fse_build(ctypes.byref(t), None, 0, None, 0) == 0, ti
+                cells = np.array([t.table[i].baseline | (t.table[i].nbits << 16) | (t.table[i].raw_symbol << 24) for i in range(1 << dh.acc_log)], dtype=np.uint32)
+                oracle.lib.orc_fse_free(ctypes.byref(t))
+                assert (got == cells).all(), ("oracle", ti, dh.acc_log, dh.kind)
+                n_vs_oracle += 1
+        assert n_vs_oracle == n_counts
         # the same for the Huffman decode tables filled from their weights (k_huf_build, huffman.go:112-190)
         hufh = np.ctypeslib.as_array(ctypes.cast(bh.huf_entries, ctypes.POINTER(ctypes.c_uint16)), shape=(bh.n_huf_entries,)).copy()
+        ht = ob.HufTable()
         assert bd.n_huf_tables == bh.n_huf_tables and st.n_huf_built == bd.n_huf_tables > 1000
         for ti in range(bd.n_huf_tables):
             dh, dd = bh.huf_tables[ti], bd.huf_tables[ti]
@@ -676,6 +693,16 @@ def test_device_built_fse_tables_equal_host_tables(corpus, ctx):
             want = hufh[dh.entries_off:dh.entries_off + (1 << dh.max_bits)]
             got = rb.read_huf_table(ti)
             assert got.shape == want.shape and (got == want).all(), (ti, dh.max_bits)
+            # ... and the ORACLE's: orc_huf_build (huffman.go:112-190 restated) on the same weights
+            nw = (dd.max_bits >> 8) & 0xFFFF
+            ws = (ctypes.c_uint8 * max(nw, 1))()
+            for j in range(nw):
+                e = bd.huf_entries[dd.entries_off + (j >> 1)]
+                ws[j] = e.nbits if j & 1 else e.symbol
+            assert oracle.lib.orc_huf_build(ctypes.byref(ht), ws, nw) == 0 and ht.max_bits == dh.max_bits, ti
+            cells = np.frombuffer(ht.symbols, dtype=np.uint8, count=1 << dh.max_bits).astype(np.uint16) | \
+                (np.frombuffer(ht.nbits, dtype=np.uint8, count=1 << dh.max_bits).astype(np.uint16) << 8)
+            assert (got == cells).all(), ("oracle", ti, dh.max_bits)
         rb.run()
         out_d, status_d, len_d = rb.download()
     finally:
@@ -922,6 +949,20 @@ def test_device_planner_block_by_block_corpus_and_fuzz(corpus, oracle):
             (_,), (sd,) = z.decode_frames([comp[:cut]], c, device_plan=True)
             (_,), (sh,) = z.decode_frames([comp[:cut]], c)
             assert sd == sh != 0, (cut, sd, sh)
+        # ... and cut INSIDE its content checksum (fewer than four bytes behind the last block): the frame's last unit must say
+        # whether the four bytes were there -- with verification on, both planners leave the flag clear, the frame decodes, and
+        # nobody reports the failure of a checksum that is not there (the block-by-block route used to)
+        cv = z.Context(0, verify_checksum=True)
+        try:
+            for cut in range(len(comp) - 3, len(comp) + 1):
+                _plan_by_blocks(cv)
+                (od,), (sd,) = z.decode_frames([comp[:cut]], cv, device_plan=True)
+                _plan_by_blocks(cv, False)
+                (oh,), (sh,) = z.decode_frames([comp[:cut]], cv)
+                (ow,), (sw,) = z.decode_frames([comp[:cut]], cv, device_plan=True)  # (the single-lane walk: the library's own threshold)
+                assert sd == sh == sw == 0 and od == oh == ow and len(od) == max(it[2] for it in corpus), (cut, sd, sh, sw)
+        finally:
+            cv.close()
     finally:
         c.close()
 

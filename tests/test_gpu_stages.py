@@ -307,7 +307,7 @@ def test_huf_seg_reports_the_lane_kernels_status_on_damaged_streams(corpus, orac
 
 # ---- BASELINE.json configs at their stated sizes: size-independent properties on every frame
 
-def _run_full_config(config, n_frames, ctx, frame_bytes=131072):
+def _run_full_config(config, n_frames, ctx, frame_bytes=131072, oracle=None):
     import torch
     from tools import synth_binding as sb
     blob, off, ln, cks, nseq = sb.make_batch(config, 0, n_frames, frame_bytes, threads=0)
@@ -344,34 +344,41 @@ def _run_full_config(config, n_frames, ctx, frame_bytes=131072):
         for c0 in range(0, n_frames, 4096):
             got = (o64[c0:c0 + 4096] * wts).sum(dim=1)
             assert bool((got == exp[c0:c0 + 4096]).all()), (config, c0)
+        if oracle is not None:
+            # ... and the generator's figure pinned to the ORACLE: ~2 048 frames spread over the batch go through the C restatement
+            # of the reference, whose regenerated bytes must give the same word sums (device == generator == oracle; bench.py's
+            # cpu_baseline leg does this for every frame of the headline batch)
+            idx = np.arange(0, n_frames, max(1, n_frames // 2048))
+            st, ol, ws = oracle.decode_frames_wsum(blob, off[idx], ln[idx], frame_bytes, threads=os.cpu_count() or 1)
+            assert (st == 0).all() and (ol == frame_bytes).all() and (ws == cks[idx]).all(), config
         return rb.stats()
     finally:
         rb.free()
         plan.close()
 
 
-def test_config2_raw_rle_4096_frames_full_size(ctx):
+def test_config2_raw_rle_4096_frames_full_size(ctx, oracle):
     """BASELINE configs[1]: 4096 single-block Raw / RLE frames of 128 KiB (framedecompressor.go:211-215,229-241)."""
-    st = _run_full_config(2, 4096, ctx)
+    st = _run_full_config(2, 4096, ctx, oracle=oracle)
     assert list(st.n_blocks) == [2048, 2048, 0]
 
 
-def test_config3_huffman_only_4096_frames_full_size(ctx):
+def test_config3_huffman_only_4096_frames_full_size(ctx, oracle):
     """BASELINE configs[2]: 4096 frames, 4-stream Huffman literals (MaxBits 11), no sequences."""
-    st = _run_full_config(3, 4096, ctx)
+    st = _run_full_config(3, 4096, ctx, oracle=oracle)
     assert st.n_huf_streams == 4 * 4096 and st.n_sequences == 0
 
 
-def test_config4_full_frames_65536_full_size(ctx):
+def test_config4_full_frames_65536_full_size(ctx, oracle):
     """BASELINE configs[3]: 65536 text-like single-block frames, Huffman literals + FSE sequences + match copy."""
-    st = _run_full_config(4, 65536, ctx)
+    st = _run_full_config(4, 65536, ctx, oracle=oracle)
     assert st.n_huf_streams == 4 * 65536 and st.n_sequences > 65536 * 10000
 
 
-def test_config4_shard_of_eight_gpus_8192_frames_full_size(ctx):
+def test_config4_shard_of_eight_gpus_8192_frames_full_size(ctx, oracle):
     """BASELINE configs[4]: what ONE of eight GPUs runs -- the 8 192-frame shard of the 65 536-frame batch, at full size
     (a single round of the sequence stage: 32 chains per CU, the Huffman kernel beside it)."""
-    st = _run_full_config(4, 8192, ctx)
+    st = _run_full_config(4, 8192, ctx, oracle=oracle)
     assert st.n_huf_streams == 4 * 8192 and st.n_sequences > 8192 * 10000
 
 
@@ -440,6 +447,34 @@ def test_bench_launches_its_own_ranks(extra):
     assert all(p["frames"] == per for p in line["per_gpu"]) and line["scaling"] == ("weak" if extra else "strong")
     assert line["config"]["rendezvous"] == "gloo" and line["config"]["frames"] == 2 * per
     assert line["value"] > 0 and all(p["algorithmic_GBs"] > 0 for p in line["per_gpu"])
+    assert line["aggregate"]["devices_distinct"] is (torch.cuda.device_count() >= 2) and line["aggregate"]["hbm_frac_of_all_gpus"] > 0
+
+
+def test_two_distinct_gpus_product_entry_and_bench(corpus):
+    """The N > 1 path on DISTINCT devices (framedecompressor.go:42-52: frames share nothing, so a device takes a contiguous range and
+    there is no collective): the product's entry `decode_frames(devices=[0, 1])` against the goldens, and `bench.py --gpus 2` with a
+    rank per physical GPU -- the rows must name two devices.  Skipped, with the reason, on a one-GPU box: there the same code runs
+    with both contexts / ranks on device 0 (the two tests above), and `hipSetDevice(1)` never executes."""
+    import torch
+    from tests.conftest import check_expected
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"{torch.cuda.device_count()} GPU on this box: the N > 1 path on distinct devices needs two")
+    frames = [comp for _, comp, *_ in corpus]
+    for kw in ({}, {"device_plan": True}):
+        outs, sts = z.decode_frames(frames, devices=[0, 1], **kw)
+        assert sts == [0] * len(frames)
+        for (name, comp, length, sha, exp), got in zip(corpus, outs):
+            check_expected(name, got, length, sha, exp)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "MZD_BENCH_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames-per-gpu", "4096", "--cpu-seconds", "0", "--no-ceiling"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["bit_exact"] is True
+    assert sorted(p["device"] for p in line["per_gpu"]) == [0, 1] and line["aggregate"]["devices_distinct"] is True
+    assert all(p["frames"] == 2048 and p["hbm_frac"] > 0 for p in line["per_gpu"])
 
 
 def test_bench_real_data_line_small():

@@ -3,6 +3,7 @@ corpus, executed by the test-only descriptor interpreter, must regenerate the or
 error behaviour of the header parsers.  No GPU, no oracle involvement in the product path."""
 import ctypes
 
+import numpy as np
 import pytest
 
 import sparkzstd_amd as z
@@ -230,3 +231,54 @@ def test_declared_frame_cost_and_shard_ranges(corpus):
     assert max(per) <= 2.5 * (sum(costs) / 4) + max(costs)
     assert shard_frames([b"x" * 10] * 10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_frames([], 2) == [(0, 0), (0, 0)]
+
+
+def test_planner_tables_equal_the_oracles_cell_for_cell(oracle, corpus):
+    """The host planner's FSE decode tables (planner.cpp build_fse_cells) and Huffman decode tables (build_huffman_cells) against the
+    ORACLE's builds of the same normalised counts / weights -- orc_fse_build (fse.go:136-230) and orc_huf_build (huffman.go:112-190)
+    -- cell for cell: baseline, number of bits, symbol.  (The GPU suite holds the DEVICE-built tables to the same oracle cells:
+    tests/test_gpu_corpus.py::test_device_built_fse_tables_equal_host_tables.)"""
+    import ctypes
+    from tests import fse_build_ref, oracle_binding as ob
+    from tools import synth_binding as sb
+    blob, off, ln, _, _ = sb.make_batch(4, 7, 12, threads=4)
+    blob3, off3, ln3, _, _ = sb.make_batch(3, 11, 6, threads=4)  # MaxBits 11 Huffman tables
+    frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)] + \
+             [bytes(blob3[o:o + l]) for o, l in zip(off3, ln3)]
+    ph, pd = z.Plan(), z.Plan(device_tables=True)
+    for f in frames:
+        assert ph.add_frame(f)[0] == 0 and pd.add_frame(f)[0] == 0
+    bh, bd = ph.finalize(), pd.finalize()
+    host = np.ctypeslib.as_array(ctypes.cast(bh.fse_entries, ctypes.POINTER(ctypes.c_uint32)), shape=(bh.n_fse_entries,)).copy()
+    n_fse = 0
+    for ti in range(bd.n_fse_tables):
+        if not bd.fse_tables[ti].build & _lib.MZD_FSE_FROM_COUNTS:
+            continue
+        dh = bh.fse_tables[ti]
+        counts = fse_build_ref.counts_of(bd, ti)
+        t = ob.FseTable()
+        t.acc_log, t.n_values = dh.acc_log, len(counts)
+        for k, cnt in enumerate(counts):
+            t.values[k] = cnt + 1  # (fse.go:19: the value kept is the probability + 1)
+        assert oracle.lib.orc_fse_build(ctypes.byref(t), None, 0, None, 0) == 0, ti
+        cells = np.array([t.table[i].baseline | (t.table[i].nbits << 16) | (t.table[i].raw_symbol << 24) for i in range(1 << dh.acc_log)],
+                         dtype=np.uint32)
+        oracle.lib.orc_fse_free(ctypes.byref(t))
+        assert (host[dh.entries_off:dh.entries_off + (1 << dh.acc_log)] == cells).all(), (ti, dh.acc_log, dh.kind)
+        n_fse += 1
+    hufh = np.ctypeslib.as_array(ctypes.cast(bh.huf_entries, ctypes.POINTER(ctypes.c_uint16)), shape=(bh.n_huf_entries,)).copy()
+    ht = ob.HufTable()
+    for ti in range(bd.n_huf_tables):
+        dh, dd = bh.huf_tables[ti], bd.huf_tables[ti]
+        nw = (dd.max_bits >> 8) & 0xFFFF
+        ws = (ctypes.c_uint8 * max(nw, 1))()
+        for j in range(nw):
+            e = bd.huf_entries[dd.entries_off + (j >> 1)]
+            ws[j] = e.nbits if j & 1 else e.symbol
+        assert oracle.lib.orc_huf_build(ctypes.byref(ht), ws, nw) == 0 and ht.max_bits == dh.max_bits, ti
+        cells = np.frombuffer(ht.symbols, dtype=np.uint8, count=1 << dh.max_bits).astype(np.uint16) | \
+            (np.frombuffer(ht.nbits, dtype=np.uint8, count=1 << dh.max_bits).astype(np.uint16) << 8)
+        assert (hufh[dh.entries_off:dh.entries_off + (1 << dh.max_bits)] == cells).all(), (ti, dh.max_bits)
+    assert n_fse > 500 and bd.n_huf_tables > 300
+    ph.close()
+    pd.close()

@@ -77,3 +77,58 @@ def test_frame_range_and_balanced_ranges():
     costs = [1] * 10 + [10] * 2
     rs = balanced_ranges(costs, 3)
     assert rs[0][0] == 0 and rs[-1][1] == len(costs) and all(rs[i][1] == rs[i + 1][0] for i in range(2))
+
+
+def _bench_args(*argv):
+    """bench.py's own argument parser on a made-up command line (no GPU is touched: parse() only reads sys.argv)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    sys.argv = ["bench.py", *argv]
+    try:
+        return bench, bench.parse()
+    finally:
+        sys.argv = old
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_bench_rank_arithmetic_of_a_node(world):
+    """What `bench.py --gpus N` does with its ranks, the device calls left out: BASELINE configs[4] is ONE 65 536-frame batch cut into
+    contiguous ranges (8 192 per GPU at N = 8), every frame in exactly one range, the host threads of the node shared between the
+    ranks, and the line's per-GPU rows / whole-job figures assembled from what the ranks gather (value = the bytes of ALL ranks over
+    the SLOWEST rank's clock).  The first 8-GPU lease has to produce a curve, not a traceback: this is its rank arithmetic on CPU."""
+    bench, a = _bench_args("--gpus", str(world))
+    shares = [bench.rank_share(a, r, world) for r in range(world)]
+    assert [s[2] for s in shares] == ["strong"] * world and all(s[3] == 65536 for s in shares)
+    assert shares[0][0] == 0 and sum(s[1] for s in shares) == 65536 and all(s[1] == 65536 // world for s in shares)
+    assert all(shares[r][0] + shares[r][1] == shares[r + 1][0] for r in range(world - 1))
+    # a batch that does not divide: the remainder goes to the first ranks, nothing is lost
+    bench, a = _bench_args("--gpus", str(world), "--frames", "65539")
+    shares = [bench.rank_share(a, r, world) for r in range(world)]
+    assert sum(s[1] for s in shares) == 65539 and max(s[1] for s in shares) - min(s[1] for s in shares) <= 1
+    assert all(shares[r][0] + shares[r][1] == shares[r + 1][0] for r in range(world - 1))
+    # --weak: the whole batch on every rank, at frame indices of its own
+    bench, a = _bench_args("--gpus", str(world), "--weak")
+    shares = [bench.rank_share(a, r, world) for r in range(world)]
+    assert [s[:3] for s in shares] == [(r * 65536, 65536, "weak") for r in range(world)]
+    # the corpus is split by replicas
+    bench, a = _bench_args("--gpus", str(world), "--workload", "corpus")
+    assert sum(bench.rank_share(a, r, world, corpus_reps=372)[1] for r in range(world)) == 372
+    # the node's host threads are shared between its ranks, never zero
+    assert bench.gen_threads_for(a, world, 16) == max(1, 16 // world) and bench.gen_threads_for(a, world, 1) == 1
+    # the line: the ranks' 8-vectors as all_gather hands them over (rank, device, frames, ms, path ms, GB/s, C bytes, D bytes)
+    per = 65536 // world
+    c1, d1 = per * 45694, per * 131072
+    ms = [2.8 + 0.01 * r for r in range(world)]  # the last rank is the slowest
+    rows, c_all, d_all = bench.per_gpu_rows([[r, r, per, ms[r], ms[r] - 0.05, (c1 + d1) / (ms[r] - 0.05) / 1e6, c1, d1] for r in range(world)])
+    assert [p["rank"] for p in rows] == list(range(world)) and c_all == world * c1 and d_all == world * d1 == 65536 * 131072
+    assert all(p["frames"] == per and 0 < p["hbm_frac"] < 1 for p in rows)
+    job = bench.job_figures(rows, c_all, d_all, elapsed=ms[-1] * 1e-3 * 20, steps=20, world=world)
+    assert abs(job["ms_per_step"] - ms[-1]) < 1e-9 and abs(job["value"] - d_all / (ms[-1] * 1e-3) / 1e6) < 1e-3
+    agg = job["aggregate"]
+    assert agg["slowest_rank"] == world - 1 and agg["devices"] == list(range(world)) and agg["devices_distinct"] is True
+    assert 0 < agg["hbm_frac_of_all_gpus"] < 1
+    # two ranks on ONE device are named as such (the line's assert in bench.py refuses them outside the one-GPU test hook)
+    if world > 1:
+        rows2, _, _ = bench.per_gpu_rows([[r, 0, per, 1.0, 1.0, 1.0, c1, d1] for r in range(world)])
+        assert bench.job_figures(rows2, c_all, d_all, 1.0, 1, world)["aggregate"]["devices_distinct"] is False
