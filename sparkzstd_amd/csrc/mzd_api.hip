@@ -16,6 +16,7 @@
 
 // unity build: the kernels live in their own file but are compiled in this translation unit
 #include "mzd_kernels.hip"
+#include "mzd_huf_w.hip"
 #include "mzd_seq_q4.hip"
 #include "mzd_exec_b.hip"
 #include "mzd_exec_c.hip"
@@ -1586,6 +1587,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2 + 16 + kHufTStageBytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_seg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_w, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 4 * kHwWaveBytes));
         ctx->attr_set = true;
     }
     // ---- split point: k_seq runs ceil(tasks / (chains per CU * CUs)) rounds of one chain latency each and
@@ -1594,7 +1596,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // second stream (frames are independent, so the two never touch the same data).
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
-    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 3 || ctx->opt.exec_variant > 5) return MZD_ERR_INVALID_ARG;
+    if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 4 || ctx->opt.exec_variant > 5) return MZD_ERR_INVALID_ARG;
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1717,7 +1719,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // (block mode too, round 4: the frames' literals are not needed before the passes -- one 64 MiB frame 5.18 -> 4.77 ms, 100 frames of
     // the reference's corpus, which take block mode, 12.5 -> 10.2 ms, 64 x 128 MiB 83.3 -> 82.9; profiles/r4_huf_beside_block_mode.txt)
     const bool huf_het_beside = serial && ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_HET_HUF_FIRST");
-    const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 ||
+    const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 || (ctx->opt.huf_variant == 4 && db->n_seq_tasks > 0) ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
                             db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) &&
                             // ... and more chains than one round of the sequence stage: with a single round (the 8 192-frame shard
@@ -2024,9 +2026,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         // wavefront-per-stream kernel beside that stage took 1.70 ms -- the longer of the two for the 8 192-frame shard of configs[4] --
         // and 0.66 against 0.45 ms in front of it at 16 384 frames; `profiles/r5_shard_huf.txt`)
         const uint64_t seg_below = 64ull * (db->n_seq_tasks ? 1 : 8) * (uint64_t)std::max(ctx->num_cus, 1);
-        const bool seg = hv == 2 || (hv == 0 && db->huf_out_bytes / streams >= 2048 &&
+        const bool seg = hv == 2 || hv == 4 || (hv == 0 && db->huf_out_bytes / streams >= 2048 &&
                                      (streams < seg_below || (db->huf_slot_cells > 32 && db->n_seq_tasks == 0)));
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
+        // k_huf_w (round 6, mzd_huf_w.hip): k_huf_seg's method with whole lines between the CU and memory -- what `seg` means from
+        // now on; huf_variant 2 keeps k_huf_seg itself alive for the parity tests, 4 forces k_huf_w wherever there are streams
+        const bool hw = hv != 2;
+        const uint32_t hw_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 63) & ~(size_t)63);
+        const size_t hw_lds = (size_t)hw_tbl + 4 * (size_t)kHwWaveBytes;
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
         const hipStream_t hs = huf_first ? s : s2;
@@ -2040,11 +2047,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 // the class's long streams first, a wavefront each (round 5, `profiles/r5_het_huf.txt`: the stage alone 3.05 -> 1.12 ms at 1 GiB
                 // of real data, 3.9 -> 2.5 at 4 GiB; beside the sequence stage 3.2 -> 1.6 -- which is when the execution of a batch in two
                 // groups of frames may start)
-                if (q1 > q0 && hv == 0) {
-                    const uint32_t nl = std::min(db->huf_class_long[c], q1 - q0);
+                if (q1 > q0 && (hv == 0 || hv == 4)) {
+                    const uint32_t nl = hv == 4 ? q1 - q0 : std::min(db->huf_class_long[c], q1 - q0);  // (4: every stream through k_huf_w)
                     if (nl) {
                         const uint32_t cells = std::min(db->huf_slot_cells, kClassCells[c]);
                         const uint32_t tbl = (uint32_t)(((size_t)cells * 2 + 15) & ~(size_t)15);
+                        const uint32_t wtbl = (uint32_t)(((size_t)cells * 2 + 63) & ~(size_t)63);
+                        if (hw)
+                            k_huf_w<<<nl, 256, (size_t)wtbl + 4 * (size_t)kHwWaveBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, 4 * nl, db->d_huf_entries,
+                                                                                          db->d_litbuf, db->d_out, db->d_sums, wtbl);
+                        else
                         k_huf_seg<<<nl, 256, (size_t)tbl + kHufSegStripBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, 4 * nl, db->d_huf_entries,
                                                                                   db->d_litbuf, db->d_out, db->d_sums, tbl);
                         q0 += nl;
@@ -2066,7 +2078,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             }
             return;
         }
-        if (seg)
+        if (seg && hw)
+            k_huf_w<<<db->n_huf_tasks / 4, 256, hw_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
+                                                                          db->d_litbuf, db->d_out, db->d_sums, hw_tbl);
+        else if (seg)
             k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                db->d_litbuf, db->d_out, db->d_sums, seg_tbl);
         else if (huf_first) {
@@ -2190,6 +2205,14 @@ extern "C" int mzd_debug_q4_stats(unsigned long long *out, int reset)
 {
     if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_q4_stats), sizeof(unsigned long long) * 8);
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_q4_stats), z, sizeof z); }
+    return 0;
+}
+#endif
+#ifdef MZD_HUF_W_STATS
+extern "C" int mzd_debug_huf_w_stats(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mzd::g_huf_w_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mzd::g_huf_w_stats), z, sizeof z); }
     return 0;
 }
 #endif

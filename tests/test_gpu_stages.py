@@ -100,7 +100,7 @@ def _next_offset(hist, value, ll):
     return off
 
 
-@pytest.mark.parametrize("seq_variant,huf_variant", [(0, 1), (1, 1), (0, 2), (3, 1), (0, 3)])
+@pytest.mark.parametrize("seq_variant,huf_variant", [(0, 1), (1, 1), (0, 2), (3, 1), (0, 3), (0, 4)])
 def test_literals_and_sequences_per_block_equal_the_oracle_trace(corpus, oracle, seq_variant, huf_variant):
     """After one pass over the whole corpus: for every compressed block, the literal bytes the Huffman stage
     regenerated (literals.go:283-361 LiteralSection.Data) and every sequence's (LiteralLength, MatchLength,
@@ -229,10 +229,10 @@ def _check_stage_boundaries(c, corpus, oracle):
 
 # ---- k_huf_seg: one wavefront per Huffman stream, segments decoded in parallel (self-synchronising codes)
 
-@pytest.mark.parametrize("huf_variant", [2, 3])
+@pytest.mark.parametrize("huf_variant", [2, 3, 4])
 def test_huf_seg_corpus_bit_exact_all_maxbits(corpus, huf_variant):
     """The whole corpus (Huffman tables with MaxBits 1..11, 1- and 4-stream sections, Treeless tables, streams from
-    a few bytes to 40 KB) through k_huf_seg (2) and through k_huf with its transposed bulk phase (3: the wavefronts
+    a few bytes to 40 KB) through k_huf_seg (2), k_huf_w (4: every stream; round 6) and through k_huf with its transposed bulk phase (3: the wavefronts
     whose tables have MaxBits <= 5 take it, lanes with other streams' chunks to load and symbols to store): golden bytes."""
     from tests.conftest import check_expected
     c = z.Context(0, huf_variant=huf_variant)
@@ -258,7 +258,7 @@ def test_huf_seg_literal_heavy_frames_of_every_size(oracle):
         mode = sb.MODE_LITERALS if i % 2 == 0 else sb.MODE_FULL
         frames.append(sb.compress(data, mode)[0])
         want.append(data)
-    for hv in (2, 1, 3):
+    for hv in (2, 1, 3, 4):
         c = z.Context(0, huf_variant=hv)
         outs, sts = z.decode_frames(frames, c)
         assert sts == [0] * len(frames), (hv, sts)
@@ -286,10 +286,12 @@ def test_huf_seg_reports_the_lane_kernels_status_on_damaged_streams(corpus, orac
                 b[int(pos)] ^= int(rng.integers(1, 256))
             frames.append(bytes(b))
     res = {}
-    for hv in (1, 2, 3):
+    for hv in (1, 2, 3, 4):
         c = z.Context(0, huf_variant=hv)
         res[hv] = z.decode_frames(frames, c)
         c.close()
+    assert res[1][1] == res[4][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[1][1], res[4][1])) if a != b][:20]
+    assert res[1][0] == res[4][0]
     assert res[1][1] == res[2][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[1][1], res[2][1])) if a != b][:20]
     assert res[1][0] == res[2][0]
     assert res[1][1] == res[3][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[1][1], res[3][1])) if a != b][:20]
