@@ -10,6 +10,7 @@
 // Header-only; link with libmzd.so.
 #pragma once
 #include <cstdint>
+#include <condition_variable>
 #include <cstring>
 #include <istream>
 #include <iterator>
@@ -402,52 +403,106 @@ class FrameReader {
 // A FrameReader that BATCHES.  The reference's harness feeds many frames through ONE reader, Reset per frame
 // (framereader.go:35, cmd/sparkzstd/main.go:59,126); one frame at a time that is one device batch per frame.  Here the
 // sources of the frames to come are known to the reader (Enqueue), it reads `lookahead` of them ahead, decodes them as ONE
-// device batch -- on a background thread, the batch after the one being served -- and serves them in order:
+// device batch -- on a background thread -- and serves them in order:
 //     BatchFrameReader r(256);  for (auto &s : streams) r.Enqueue(&s);
 //     while (r.Reset()) { while (size_t n = r.Read(buf, sizeof buf)) consume(buf, n); }
 // Errors surface where FrameReader's do: a wrong magic number at Reset, a damaged block at the frame's first Read; the
 // frames behind a damaged one are unaffected.
+//
+// Round 6: on one device the reader sits on the STREAMING path (mzd_stream_submit / mzd_stream_wait): a worker thread gathers
+// the frames of a batch into a PINNED input buffer (several threads copy), submits it -- the device plans the frames itself, no
+// host planner -- and keeps TWO batches in flight, so that the copy-in of one batch, the decode of the one before and the copy-out
+// of the one before that overlap (what mzd_stream_* is for); the regenerated bytes arrive in a pinned output buffer and the reader
+// hands them out from there -- Read copies into the caller's buffer like io.Reader does, View() lends the frame's bytes in place
+// (valid until the next Reset) for consumers that can do without that copy.  Four slots: one served, two in flight, one being
+// gathered.  A source handed to Enqueue belongs to the reader until its frame has been served (streams are read on the worker).
+// With a list of devices a batch goes through DecodeFramesOn instead (one context and host thread per device), one at a time.
 class BatchFrameReader {
   public:
-    explicit BatchFrameReader(size_t lookahead = 256, std::vector<int> devices = {}, mzd_ctx *ctx = nullptr)
-        : lookahead_(lookahead ? lookahead : 1), devices_(std::move(devices)), ctx_(ctx)
+    explicit BatchFrameReader(size_t lookahead = 256, std::vector<int> devices = {}, mzd_ctx *ctx = nullptr, unsigned gather_threads = 4)
+        : lookahead_(lookahead ? lookahead : 1), devices_(std::move(devices)), ctx_(ctx), gather_threads_(gather_threads ? gather_threads : 1)
     {
     }
     ~BatchFrameReader()
     {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
         if (worker_.joinable()) worker_.join();
+        if (stream_) mzd_stream_destroy(stream_);
+        for (Slot &sl : slots_) {
+            if (sl.in) mzd_host_free(sl.in);
+            if (sl.out) mzd_host_free(sl.out);
+        }
     }
-    void Enqueue(std::istream *source) { pending_.push_back({source, {}}); }
-    void Enqueue(std::vector<uint8_t> frame) { pending_.push_back({nullptr, std::move(frame)}); }
+    BatchFrameReader(const BatchFrameReader &) = delete;
+    BatchFrameReader &operator=(const BatchFrameReader &) = delete;
+    void Enqueue(std::istream *source) { Push({source, {}, nullptr, 0}); }
+    void Enqueue(std::vector<uint8_t> frame) { Push({nullptr, std::move(frame), nullptr, 0}); }
+    // the frame's bytes stay the caller's (alive until the frame has been served): nothing is copied before the gather
+    void EnqueueView(const uint8_t *p, size_t n) { Push({nullptr, {}, p, n}); }
     // the next frame becomes the current one; false when there is none left
     bool Reset()
     {
-        buffer_.clear();
-        pos_ = 0;
         have_ = false;
         status_ = MZD_OK;
-        if (ready_pos_ == ready_.size()) {
-            if (!worker_.joinable()) StartBatch();
-            if (!worker_.joinable()) return false;
-            CollectBatch();
+        cur_ = nullptr;
+        cur_len_ = pos_ = 0;
+        while (serving_ < 0 || ready_pos_ == slots_[serving_].n) {
+            std::unique_lock<std::mutex> g(mu_);
+            if (serving_ >= 0) {  // the slot that has been served goes back to the worker
+                free_.push_back(serving_);
+                serving_ = -1;
+                cv_.notify_all();
+            }
+            if (!worker_.joinable() && !dead_) worker_ = std::thread([this] { Work(); });
+            if (dead_) return false;  // (a device error ended the worker: it was thrown once)
+            cv_.wait(g, [this] { return !ready_.empty() || error_ != MZD_OK || dead_ || (pending_.empty() && busy_ == 0); });
+            if (error_ != MZD_OK) {
+                const int e = error_;
+                error_ = MZD_OK;
+                throw Error(e, "BatchFrameReader: " + what_);
+            }
+            if (ready_.empty()) return false;  // nothing queued, nothing in flight
+            serving_ = ready_.front();
+            ready_.erase(ready_.begin());
+            ready_pos_ = 0;
         }
-        Decoded &d = ready_[ready_pos_++];
-        if (ready_.size() - ready_pos_ <= lookahead_ / 2 && !worker_.joinable()) StartBatch();  // decode ahead while this batch is served
+        const Slot &sl = slots_[serving_];
+        const size_t i = ready_pos_++;
         have_ = true;
         FramesServed++;
-        if (d.status == MZD_ERR_MAGIC || (d.status == MZD_ERR_TRUNCATED && d.frame_len < 4)) throw Error(d.status, "Reset");
-        status_ = d.status;
-        buffer_ = std::move(d.bytes);
+        const int st = sl.status[i];
+        if (sl.owned.empty()) {
+            cur_ = sl.out + sl.out_off[i];
+            cur_len_ = st == MZD_OK ? (size_t)sl.out_len[i] : 0;
+        } else {  // (the multi-device path: a vector per frame)
+            cur_ = sl.owned[i].data();
+            cur_len_ = sl.owned[i].size();
+        }
+        if (st == MZD_ERR_MAGIC || (st == MZD_ERR_TRUNCATED && sl.len[i] < 4)) throw Error(st, "Reset");
+        status_ = st;
         return true;
     }
     size_t Read(uint8_t *p, size_t n)
     {
         if (!have_ && !Reset()) return 0;
         if (status_ != MZD_OK) throw Error(status_, "Read");
-        const size_t k = std::min(n, buffer_.size() - pos_);
-        std::memcpy(p, buffer_.data() + pos_, k);
+        const size_t k = std::min(n, cur_len_ - pos_);
+        std::memcpy(p, cur_ + pos_, k);
         pos_ += k;
         return k;
+    }
+    // the current frame's regenerated bytes where they are (pinned host memory on the streaming path): no copy; valid until the
+    // next Reset.  Throws what Read would throw.
+    std::pair<const uint8_t *, size_t> View()
+    {
+        if (!have_ && !Reset()) return {nullptr, 0};
+        if (status_ != MZD_OK) throw Error(status_, "Read");
+        pos_ = cur_len_;
+        return {cur_, cur_len_};
     }
     size_t FramesServed = 0;
 
@@ -455,59 +510,174 @@ class BatchFrameReader {
     struct Source {
         std::istream *stream;
         std::vector<uint8_t> bytes;
+        const uint8_t *view;
+        size_t view_len;
     };
-    struct Decoded {
-        std::vector<uint8_t> bytes;
-        int status;
-        size_t frame_len;
+    struct Slot {  // one batch: pinned buffers (grow only) and what mzd_stream_wait reports per frame
+        uint8_t *in = nullptr, *out = nullptr;
+        size_t in_cap = 0, out_cap = 0, n = 0;
+        std::vector<uint64_t> off, len, out_len, out_off;
+        std::vector<int32_t> status;
+        std::vector<std::vector<uint8_t>> owned;  // (multi-device path only)
+        uint64_t ticket = 0;
     };
-    void StartBatch()
+    static constexpr int kSlots = 4;
+    void Push(Source s)
     {
-        std::vector<std::vector<uint8_t>> frames;
-        while (frames.size() < lookahead_ && pending_head_ < pending_.size()) {
-            Source &s = pending_[pending_head_++];
-            if (s.stream) frames.emplace_back(std::istreambuf_iterator<char>(*s.stream), std::istreambuf_iterator<char>());
-            else frames.push_back(std::move(s.bytes));
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            pending_.push_back(std::move(s));
         }
-        if (pending_head_ == pending_.size()) {
-            pending_.clear();
-            pending_head_ = 0;
-        }
-        if (frames.empty()) return;
-        inflight_.clear();
-        inflight_error_ = MZD_OK;
-        worker_ = std::thread([this, frames = std::move(frames)]() {
-            try {
-                std::vector<int> st;
-                auto out = devices_.empty() ? DecodeFrames(frames, &st, ctx_) : DecodeFramesOn(devices_, frames, &st);
-                for (size_t i = 0; i < frames.size(); i++) inflight_.push_back({std::move(out[i]), st[i], frames[i].size()});
-            } catch (const Error &e) {
-                inflight_error_ = e.code();
-                inflight_what_ = e.what();
-            }
-        });
+        cv_.notify_all();
     }
-    void CollectBatch()
+    static void grow(uint8_t *&p, size_t &cap, size_t need)
     {
-        worker_.join();
-        if (inflight_error_ != MZD_OK) throw Error(inflight_error_, "BatchFrameReader: " + inflight_what_);
-        ready_.erase(ready_.begin(), ready_.begin() + (long)ready_pos_);
-        ready_pos_ = 0;
-        for (auto &d : inflight_) ready_.push_back(std::move(d));
-        inflight_.clear();
+        if (cap >= need) return;
+        if (p) mzd_host_free(p);
+        cap = need + need / 4 + 4096;
+        p = (uint8_t *)mzd_host_alloc(cap);
+        if (!p) {
+            cap = 0;
+            throw Error(MZD_ERR_DEVICE, "mzd_host_alloc");
+        }
+    }
+    // the worker: gather -> submit, two batches in flight, collect the oldest -> ready
+    void Work()
+    {
+        std::vector<int> inflight;
+        try {
+            for (;;) {
+                std::vector<Source> take;
+                int slot = -1;
+                {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_.wait(g, [&] { return stop_ || !inflight.empty() || (!pending_.empty() && !free_.empty()); });
+                    if (stop_) break;
+                    const bool can_fill = !pending_.empty() && !free_.empty() && inflight.size() < 2;
+                    if (can_fill) {
+                        slot = free_.back();
+                        free_.pop_back();
+                        const size_t n = std::min(lookahead_, pending_.size());
+                        take.assign(std::make_move_iterator(pending_.begin()), std::make_move_iterator(pending_.begin() + (long)n));
+                        pending_.erase(pending_.begin(), pending_.begin() + (long)n);
+                        busy_++;
+                    } else if (inflight.empty()) {
+                        continue;  // (sources but no free slot: the consumer has to return one)
+                    }
+                }
+                if (slot >= 0) {
+                    Fill(slots_[slot], take);
+                    inflight.push_back(slot);
+                    // one more batch right away if there is room: its copy-in overlaps the decode of this one
+                    std::lock_guard<std::mutex> g(mu_);
+                    if (inflight.size() < 2 && !pending_.empty() && !free_.empty()) continue;
+                }
+                if (!inflight.empty()) {
+                    const int s0 = inflight.front();
+                    inflight.erase(inflight.begin());
+                    Collect(slots_[s0]);
+                    {
+                        std::lock_guard<std::mutex> g(mu_);
+                        ready_.push_back(s0);
+                        busy_--;
+                    }
+                    cv_.notify_all();
+                }
+            }
+        } catch (const Error &e) {
+            std::lock_guard<std::mutex> g(mu_);
+            error_ = e.code();
+            what_ = e.what();
+            busy_ = 0;
+            dead_ = true;
+            cv_.notify_all();
+        }
+    }
+    void Fill(Slot &sl, std::vector<Source> &take)
+    {
+        const size_t n = take.size();
+        for (Source &s : take)
+            if (s.stream) s.bytes.assign(std::istreambuf_iterator<char>(*s.stream), std::istreambuf_iterator<char>());
+        sl.n = n;
+        sl.off.resize(n);
+        sl.len.resize(n);
+        sl.out_len.assign(n, 0);
+        sl.out_off.assign(n, 0);
+        sl.status.assign(n, MZD_OK);
+        sl.owned.clear();
+        sl.ticket = 0;
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) {
+            sl.off[i] = total;
+            sl.len[i] = take[i].view ? take[i].view_len : take[i].bytes.size();
+            total += sl.len[i];
+        }
+        if (!devices_.empty()) {  // several devices: DecodeFramesOn, a vector per frame (no streaming path across devices yet)
+            std::vector<std::vector<uint8_t>> frames;
+            for (Source &s : take) frames.push_back(s.view ? std::vector<uint8_t>(s.view, s.view + s.view_len) : std::move(s.bytes));
+            std::vector<int> st;
+            sl.owned = DecodeFramesOn(devices_, frames, &st);
+            for (size_t i = 0; i < n; i++) sl.status[i] = st[i];
+            if (sl.owned.empty()) sl.owned.resize(1);  // (marks the slot as this path's)
+            return;
+        }
+        mzd_ctx *ctx = ctx_ ? ctx_ : default_context();
+        if (!stream_) {
+            int err = 0;
+            stream_ = mzd_stream_create(ctx, 2, &err);
+            if (!stream_) throw Error(err, "mzd_stream_create");
+        }
+        grow(sl.in, sl.in_cap, total + 64);
+        // gather + the output the batch may need: every frame's bound (declared content size, capped by what its blocks can
+        // regenerate) from a walk over its headers; a frame the walk cannot read gets an empty slab and its status from the device
+        std::vector<uint64_t> need(gather_threads_, 0);
+        auto part = [&](unsigned t) {
+            uint64_t nd = 0;
+            for (size_t i = n * t / gather_threads_; i < n * (t + 1) / gather_threads_; i++) {
+                if (sl.len[i]) std::memcpy(sl.in + sl.off[i], take[i].view ? take[i].view : take[i].bytes.data(), sl.len[i]);
+                uint64_t fo = 0, fl = 0, bound = 0, tot = 0;
+                uint32_t found = 0;
+                (void)mzd_split_frames(sl.in + sl.off[i], sl.len[i], &fo, &fl, &bound, 1, &found, &tot);
+                nd += ((found ? bound : 0) + 255) / 256 * 256 + 256;
+            }
+            need[t] = nd;
+        };
+        std::vector<std::thread> helpers;
+        for (unsigned t = 1; t < gather_threads_; t++) helpers.emplace_back(part, t);
+        part(0);
+        for (auto &h : helpers) h.join();
+        uint64_t need_all = 512;
+        for (uint64_t v : need) need_all += v;
+        grow(sl.out, sl.out_cap, need_all);
+        const int rc = mzd_stream_submit(stream_, sl.in, total, sl.off.data(), sl.len.data(), (uint32_t)n, sl.out, sl.out_cap, &sl.ticket);
+        if (rc != MZD_OK) throw Error(rc, "mzd_stream_submit");
+    }
+    void Collect(Slot &sl)
+    {
+        if (!sl.ticket) return;  // (the multi-device path finished in Fill)
+        const int rc = mzd_stream_wait(stream_, sl.ticket, sl.status.data(), sl.out_len.data(), sl.out_off.data());
+        sl.ticket = 0;
+        if (rc >= MZD_ERR_DEVICE) throw Error(rc, "mzd_stream_wait");
     }
     size_t lookahead_;
     std::vector<int> devices_;
     mzd_ctx *ctx_;
-    std::vector<Source> pending_;
-    size_t pending_head_ = 0;
-    std::vector<Decoded> ready_, inflight_;
-    size_t ready_pos_ = 0;
+    unsigned gather_threads_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Source> pending_;               // (under mu_)
+    std::vector<int> ready_, free_ = {3, 2, 1, 0};  // decoded slots in order / slots the worker may fill (under mu_)
+    int busy_ = 0;                              // batches taken from pending_ and not yet in ready_ (under mu_)
+    bool stop_ = false, dead_ = false;
+    int error_ = MZD_OK;
+    std::string what_;
     std::thread worker_;
-    int inflight_error_ = MZD_OK;
-    std::string inflight_what_;
-    std::vector<uint8_t> buffer_;
-    size_t pos_ = 0;
+    mzd_stream *stream_ = nullptr;
+    Slot slots_[kSlots];
+    int serving_ = -1;
+    size_t ready_pos_ = 0;
+    const uint8_t *cur_ = nullptr;
+    size_t cur_len_ = 0, pos_ = 0;
     bool have_ = false;
     int status_ = MZD_OK;
 };

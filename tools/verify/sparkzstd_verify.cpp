@@ -60,6 +60,62 @@ int main(int argc, char **argv)
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         first = argc;
     }
+    if (argc > first + 3 && std::string(argv[first]) == "--bench") {
+        // --bench <file of concatenated frames> <frames to serve> <lookahead> [read|view]: host-to-host throughput of the reader that
+        // batches (framereader.go:35-109 consumer shape: one reader, Reset per frame, the frame consumed whole).  The file's frames are
+        // served round robin until the count is reached (content repeats, every frame is decoded again); "read" = Read into a 64 KiB
+        // buffer like the reference harness (a copy per byte), "view" = the bytes lent in place.  Every frame's regenerated length is
+        // checked against the first pass's, its bytes by a running 64-bit sum that must repeat with the file.
+        std::ifstream zf(argv[first + 1], std::ios::binary);
+        std::vector<uint8_t> blob((std::istreambuf_iterator<char>(zf)), std::istreambuf_iterator<char>());
+        const size_t total_frames = (size_t)atoll(argv[first + 2]), look = (size_t)atoi(argv[first + 3]);
+        const bool view = argc > first + 4 && std::string(argv[first + 4]) == "view";
+        std::vector<uint64_t> off(1 << 20), len(1 << 20), bound(1 << 20);
+        uint32_t nf = 0;
+        uint64_t tot = 0;
+        const int rc = mzd_split_frames(blob.data(), blob.size(), off.data(), len.data(), bound.data(), (uint32_t)off.size(), &nf, &tot);
+        if (rc != MZD_OK || nf == 0 || nf > off.size()) {
+            printf("bench: cannot split %s (rc %d, %u frames)\n", argv[first + 1], rc, nf);
+            return 1;
+        }
+        sparkzstd::BatchFrameReader br(look);
+        std::vector<uint64_t> sums(nf, 0), lens(nf, 0);
+        std::vector<uint8_t> buf(1 << 16);
+        uint64_t in_bytes = 0;
+        bool ok = true;
+        // warm-up, untimed: four batches -- every slot of the reader has its pinned buffers (hipHostMalloc of a gigabyte takes a
+        // fifth of a second: a reader lives longer than that) and the context its kernels
+        const size_t warm = std::min<size_t>(4 * look, total_frames);
+        for (size_t i = 0; i < warm; i++) br.EnqueueView(blob.data() + off[i % nf], (size_t)len[i % nf]);
+        for (size_t i = 0; i < warm; i++) ok = br.Reset() && ok;
+        for (size_t i = 0; i < total_frames; i++) br.EnqueueView(blob.data() + off[i % nf], (size_t)len[i % nf]);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < total_frames; i++) {
+            if (!br.Reset()) { ok = false; break; }
+            uint64_t sum = 0, n_out = 0;
+            if (view) {
+                const auto v = br.View();
+                n_out = v.second;
+                // (touch what was lent: a word per 4 KiB page -- the consumer's own pass over the bytes is not the reader's cost)
+                for (size_t k = 0; k + 8 <= v.second; k += 4096) { uint64_t w; std::memcpy(&w, v.first + k, 8); sum += w; }
+            } else {
+                while (const size_t n = br.Read(buf.data(), buf.size())) {
+                    n_out += n;
+                    for (size_t k = 0; k + 8 <= n; k += 4096) { uint64_t w; std::memcpy(&w, buf.data() + k, 8); sum += w; }
+                }
+            }
+            bytes += n_out;
+            in_bytes += len[i % nf];
+            if (i < nf) { sums[i] = sum; lens[i] = n_out; }
+            else if (sums[i % nf] != sum || lens[i % nf] != n_out) ok = false;
+        }
+        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("{\"bench\": \"BatchFrameReader over mzd_stream_*\", \"mode\": \"%s\", \"frames\": %zu, \"distinct_frames\": %u, \"lookahead\": %zu, "
+               "\"seconds\": %.4f, \"frames_per_s\": %.0f, \"out_GBs\": %.2f, \"in_GBs\": %.2f, \"out_bytes\": %llu, \"consistent\": %s}\n",
+               view ? "view" : "read", total_frames, nf, look, seconds, total_frames / seconds, bytes / seconds / 1e9, in_bytes / seconds / 1e9,
+               (unsigned long long)bytes, ok ? "true" : "false");
+        return ok ? 0 : 1;
+    }
     if (argc > first + 1 && std::string(argv[first]) == "--batch-reader") {
         // --batch-reader N: the harness's own loop (one reader, Reset per file, Read until EOF) over a reader that decodes N
         // frames per device batch and reads ahead
