@@ -112,6 +112,27 @@ class BatchStats(ctypes.Structure):
 _lib = None
 
 
+TEST_LIB_PATH = os.environ.get("MZD_TEST_LIB") or os.path.join(HERE, "libmzd_test.so")
+_test_lib = None
+
+
+def needs_test_kernels(seq_variant=0, huf_variant=0, exec_variant=0) -> bool:
+    """The second implementations the parity tests force (k_seq 1, k_seq_pipe 3; k_huf_seg 2; k_exec_b 2, 3) are compiled into
+    libmzd_test.so only (round 6: the release library has one kernel per stage)."""
+    return seq_variant in (1, 3) or huf_variant == 2 or exec_variant in (2, 3)
+
+
+def load_test():
+    """libmzd_test.so: the release library + the parity tests' second implementations (-DMZD_TEST_KERNELS).  Test scaffolding:
+    a Context that asks for one of those variants loads it (api.Context); nothing else does."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise ImportError(f"{TEST_LIB_PATH} not built (make -C sparkzstd_amd/csrc): it holds the kernel variants of the parity tests")
+        _test_lib = _open(TEST_LIB_PATH)
+    return _test_lib
+
+
 def load():
     """Returns the loaded library; raises if libmzd.so is missing (build it: python -c
     'import __graft_entry__ as g; g.build()' or make -C sparkzstd_amd/csrc)."""
@@ -121,7 +142,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: the sparkzstd_amd hot path is HIP only, "
                           "there is no fallback. Run `make -C sparkzstd_amd/csrc`.")
-    L = ctypes.CDLL(LIB_PATH)
+    _lib = _open(LIB_PATH)
+    return _lib
+
+
+def _open(path):
+    L = ctypes.CDLL(path)
     vp, i32, u32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
     sig = {
         "mzd_abi_version": (i32, []),
@@ -178,6 +204,5 @@ def load():
         fn.restype = res
         fn.argtypes = args
     if L.mzd_abi_version() != MZD_ABI_VERSION:
-        raise ImportError("libmzd.so ABI version mismatch")
-    _lib = L
+        raise ImportError(f"{path}: ABI version mismatch")
     return L

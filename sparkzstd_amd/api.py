@@ -226,8 +226,11 @@ class Context:
 
     def __init__(self, device: int = 0, seq_variant: int = 0, exec_threads: int = 0, exec_chunk: int = 0,
                  huf_min_lds: int = 0, no_split: bool = False, assume_cus: int = 0, verify_checksum: bool = False,
-                 seq_window_kib: int = 0, huf_variant: int = 0, exec_variant: int = 0):
-        self._L = _lib.load()
+                 seq_window_kib: int = 0, huf_variant: int = 0, exec_variant: int = 0, library: str = None):
+        # (a kernel variant that is a second implementation for the parity tests lives in libmzd_test.so: round 6; `library` =
+        # "release" / "test" overrides the choice -- the tests of the split itself)
+        want_test = library == "test" or (library is None and _lib.needs_test_kernels(seq_variant, huf_variant, exec_variant))
+        self._L = _lib.load_test() if want_test else _lib.load()
         self._mu = threading.RLock()  # one thread at a time inside the library per context (see _ctx_locked)
         opt = Options()
         opt.seq_variant = seq_variant

@@ -1570,6 +1570,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     uint32_t exec_cap = ctx->opt.exec_chunk ? ctx->opt.exec_chunk : 8192;
     exec_cap = std::min<uint32_t>(std::max<uint32_t>(exec_cap & ~1023u, 4096), kBlockMax);
     const size_t seq_lds = (size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16;
+    (void)seq_lds;  // (k_seq's: libmzd_test.so)
     size_t exec_lds = (size_t)exec_cap + 32 + (exec_cap / 32 + 4) * 4 + 16;
     if (const char *e = exp_env("MZD_EXEC_MIN_LDS")) exec_lds = std::max<size_t>(exec_lds, (size_t)atoi(e));  // experiment: residency cap
     // k_huf residency cap: with every stream resident at once the active cache lines (one per lane)
@@ -1577,16 +1578,18 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // number of resident wavefronts (opt.huf_min_lds bytes; 0, the default, = no cap: the same value on the sorted class launches below)
     const size_t huf_lds = std::max<size_t>((size_t)kHufQuads * db->huf_slot_cells * 2, ctx->opt.huf_min_lds);
     if (!ctx->attr_set) {
+#ifdef MZD_TEST_KERNELS
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((size_t)kSeqChains16 * kSeqCellsPerChain * 2 + kSeqExtraLds16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_pipe, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kPipeFixedLds + kPipeMaxChains * kSeqCellsPerChain * 2));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_seg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_seq_q4, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kQ4FixedLds + kQ4MaxChains * kSeqCellsPerChain * 2));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_exec, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kBlockMax + 32 + (kBlockMax / 32 + 4) * 4 + 16)));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 2 + 16 + kHufTStageBytes));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_seg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_huf_w, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 4 * kHwWaveBytes));
         ctx->attr_set = true;
     }
@@ -1597,6 +1600,15 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // seq_variant 0 (default) and 2: k_seq_q4; 1: k_seq, the two-wavefront kernel; 3: k_seq_pipe.  k_seq_q4 and
     // k_seq_pipe address the bitstreams with 32-bit offsets from a window of the blob (larger blobs: window by window).
     if (ctx->opt.seq_variant > 3 || ctx->opt.huf_variant > 4 || ctx->opt.exec_variant > 5) return MZD_ERR_INVALID_ARG;
+#ifndef MZD_TEST_KERNELS
+    // The release library has ONE kernel per stage (+ k_exec for frames of 4 GiB and more): the second implementations the parity tests
+    // force -- k_seq (seq_variant 1), k_seq_pipe (3), k_huf_seg (huf_variant 2), k_exec_b (exec_variant 2, 3) -- are compiled into
+    // libmzd_test.so (-DMZD_TEST_KERNELS) only
+    if (ctx->opt.seq_variant == 1 || ctx->opt.seq_variant == 3 || ctx->opt.huf_variant == 2 || ctx->opt.exec_variant == 2 || ctx->opt.exec_variant == 3) {
+        ctx->last_error = "this kernel variant is a second implementation for the parity tests: it is in libmzd_test.so, not in the release library";
+        return MZD_ERR_UNSUPPORTED;
+    }
+#endif
     const uint32_t sv = ctx->opt.seq_variant ? ctx->opt.seq_variant : 2u;
     const bool pipe = sv != 1;  // the kernels that address a window of the blob
     const bool q4 = sv == 2;
@@ -1633,6 +1645,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // k_exec_b takes opt.exec_chunk as EXTRA dynamic LDS on top of its 7.7 KiB (a residency cap), k_exec as its LDS chunk: a value that
     // suits k_exec (up to 128 KiB) must not make the k_exec_b launch fail -- clamped to what the default 64 KiB limit leaves
     const uint32_t xb_extra_lds = std::min<uint32_t>(ctx->opt.exec_chunk, 64u * 1024u - (uint32_t)sizeof(XbLds) - 256u);
+    (void)xb_extra_lds;
     // Block mode (mzd_exec_blk.hip): every block its own job, NP passes and a fix-up walk -- for batches whose largest frame is a
     // longer serial job than NP passes over everything.  The model: a frame's workgroup alone makes a 128 KiB block in ~0.42 ms,
     // the chip 5 120 of them in ~0.85 ms; a fix-up step is ~6 us.  (exec_variant 3 forces it: the parity tests.)
@@ -1786,12 +1799,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 k_seq_q4<<<(count + per_wg - 1) / per_wg, kQ4Threads, q4_lds(per_wg), s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base,
                     db->seq_cells[0], db->seq_cells[1], db->seq_cells[2]);
+#ifdef MZD_TEST_KERNELS
             else
                 k_seq_pipe<<<(count + per_wg - 1) / per_wg, 256, kPipeFixedLds + (size_t)per_wg * kSeqCellsPerChain * 2, s>>>(
                     db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums, per_wg, base);
+#endif
         } else {
+#ifdef MZD_TEST_KERNELS
             k_seq<<<(count + kSeqChains16 - 1) / kSeqChains16, 128, seq_lds, s>>>(
                 db->d_in, db->d_seq_tasks + first, count, db->d_fse_entries, db->d_recs, db->d_tiles, db->d_sums);
+#endif
         }
     };
     // Sequence decode of the frames [f0, f1).  k_seq_pipe addresses the bitstreams with 32-bit offsets from the
@@ -1845,8 +1862,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         while (g < f1) {
             uint64_t lo;
             uint32_t e = cut(g, limit, lo);
-            if (e == g) {  // one frame wider than the window
-                launch_seq_tasks(db->frame_seq_task[g], db->frame_seq_task[g + 1] - db->frame_seq_task[g], false, 0);
+            if (e == g) {  // one frame wider than the window: k_seq_q4 with a window per WORKGROUP (round 6; k_seq_pipe has none: k_seq)
+                launch_seq_tasks(db->frame_seq_task[g], db->frame_seq_task[g + 1] - db->frame_seq_task[g], q4, q4 ? ~0ull : 0);
                 e = g + 1;
             } else {
                 launch_seq_tasks(db->frame_seq_task[g], db->frame_seq_task[e] - db->frame_seq_task[g], true, lo == ~0ull ? 0 : lo);
@@ -1890,9 +1907,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 if (blk_xc)
                     k_exec_c<true, 8192><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
                                                              db->d_status, db->d_out_len, nullptr, 0u, bk);
+#ifdef MZD_TEST_KERNELS
                 else
                     k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
                                                                         db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
+#endif
             }
             // fix-up workgroups per frame: all of a frame's must be resident together (they wait for each other)
             // (frames whose blocks reach back -- 64 x 128 MiB, 8 / 16 / 32 per frame: 113.8 / 103.7 / 114.8 ms per pass; one frame of
@@ -1958,12 +1977,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                                                                      db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
+#ifdef MZD_TEST_KERNELS
         if (exec_b) {
             // (opt.exec_chunk: extra dynamic LDS per frame = a residency cap; frames in flight vs cache footprint of their slabs)
             k_exec_b<false><<<count, 64, xb_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
                                                                    db->d_litbuf, db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
             return;
         }
+#endif
         k_exec<<<count, exec_threads, exec_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums,
                                                      db->d_recs, db->d_tiles, db->d_litbuf, db->d_status,
                                                      db->d_out_len, exec_cap, db->d_frame_order, first);
@@ -2029,13 +2050,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const bool seg = hv == 2 || hv == 4 || (hv == 0 && db->huf_out_bytes / streams >= 2048 &&
                                      (streams < seg_below || (db->huf_slot_cells > 32 && db->n_seq_tasks == 0)));
         const uint32_t seg_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 15) & ~(size_t)15);
+        (void)seg_tbl;
         // k_huf_w (round 6, mzd_huf_w.hip): k_huf_seg's method with whole lines between the CU and memory -- what `seg` means from
         // now on; huf_variant 2 keeps k_huf_seg itself alive for the parity tests, 4 forces k_huf_w wherever there are streams
         const bool hw = hv != 2;
         const uint32_t hw_tbl = (uint32_t)(((size_t)db->huf_slot_cells * 2 + 63) & ~(size_t)63);
         const size_t hw_lds = (size_t)hw_tbl + 4 * (size_t)kHwWaveBytes;
+#ifdef MZD_TEST_KERNELS
         size_t seg_lds = (size_t)seg_tbl + kHufSegStripBytes;
         if (const char *e = exp_env("MZD_HUF_SEG_LDS")) seg_lds = std::max<size_t>(seg_lds, (size_t)atoi(e));  // experiment: residency cap
+#endif
         const hipStream_t hs = huf_first ? s : s2;
         if (db->huf_sorted && !seg) {
             // one launch per table-size class: a wavefront's LDS is 16 tables of the CLASS's size, not of the batch's largest
@@ -2052,13 +2076,16 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                     if (nl) {
                         const uint32_t cells = std::min(db->huf_slot_cells, kClassCells[c]);
                         const uint32_t tbl = (uint32_t)(((size_t)cells * 2 + 15) & ~(size_t)15);
+                        (void)tbl;
                         const uint32_t wtbl = (uint32_t)(((size_t)cells * 2 + 63) & ~(size_t)63);
                         if (hw)
                             k_huf_w<<<nl, 256, (size_t)wtbl + 4 * (size_t)kHwWaveBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, 4 * nl, db->d_huf_entries,
                                                                                           db->d_litbuf, db->d_out, db->d_sums, wtbl);
+#ifdef MZD_TEST_KERNELS
                         else
                         k_huf_seg<<<nl, 256, (size_t)tbl + kHufSegStripBytes, hs>>>(db->d_in, db->d_huf_tasks + 4 * (size_t)q0, 4 * nl, db->d_huf_entries,
                                                                                   db->d_litbuf, db->d_out, db->d_sums, tbl);
+#endif
                         q0 += nl;
                     }
                 }
@@ -2081,9 +2108,11 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         if (seg && hw)
             k_huf_w<<<db->n_huf_tasks / 4, 256, hw_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                           db->d_litbuf, db->d_out, db->d_sums, hw_tbl);
+#ifdef MZD_TEST_KERNELS
         else if (seg)
             k_huf_seg<<<db->n_huf_tasks / 4, 256, seg_lds, huf_first ? s : s2>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks, db->d_huf_entries,
                                                                db->d_litbuf, db->d_out, db->d_sums, seg_tbl);
+#endif
         else if (huf_first) {
             const uint32_t tstage = (uint32_t)((huf_lds + 15) & ~(size_t)15);
             k_huf<<<(db->n_huf_tasks + 63) / 64, 64, tstage + kHufTStageBytes, s>>>(db->d_in, db->d_huf_tasks, db->n_huf_tasks,

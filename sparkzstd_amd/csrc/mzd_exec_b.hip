@@ -166,6 +166,7 @@ struct XbBlk {
     uint8_t *planes;
 };
 
+#ifdef MZD_TEST_KERNELS  /* round 6: a second implementation for the parity tests (libmzd_test.so); the helpers above are k_exec_c's too */
 template <bool BM>
 __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in, uint8_t *out_blob, const DFrame *__restrict__ frames,
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
@@ -572,5 +573,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
         frame_out_len[fidx] = outPos;
     }
 }
+
+#endif  // MZD_TEST_KERNELS
 
 }  // namespace mzd

@@ -709,6 +709,7 @@ __global__ __launch_bounds__(64) void k_huf(const uint8_t *__restrict__ in, cons
     if (status != MZD_OK) atomicMin(&sums[t.block].huf_err, ((tid & 3u) << 8) | (uint32_t)status);
 }
 
+#ifdef MZD_TEST_KERNELS  /* round 6: k_huf_w (mzd_huf_w.hip) took this kernel's place; kept for the parity tests (libmzd_test.so) */
 // ------------------------------------------------------------------------------------------
 // k_huf_seg: Huffman literal streams with INTRA-STREAM parallelism (huffman.go:221-264, same results
 // and same end conditions as k_huf).  A stream is one serial chain of table lookups, so a batch of few
@@ -1187,6 +1188,7 @@ __global__ __launch_bounds__(256) void k_huf_seg(const uint8_t *__restrict__ in,
     else huf_seg_stream<3>(in, t, tbl, strip, obase, sums, tid & 3u, lane);
 }
 
+#endif  // MZD_TEST_KERNELS (k_huf_seg)
 // ------------------------------------------------------------------------------------------
 // k_seq: FSE sequence decode.  One wavefront per workgroup, lane = one block's chain.
 //
@@ -1246,6 +1248,7 @@ __device__ __forceinline__ uint32_t top_bits(uint64_t T, uint32_t n)
     return __builtin_amdgcn_ubfe((uint32_t)(T >> 32), 32u - n, n);
 }
 
+#ifdef MZD_TEST_KERNELS  /* round 6: second implementations of the sequence stage for the parity tests (libmzd_test.so) */
 // LDS after the cell slots and the constant table.  The decode wavefront hands every decoded
 // sequence to the helper wavefront through `queue` (all chains of a wavefront are at the same step
 // index, so one head / tail pair serves the whole wavefront).
@@ -1546,6 +1549,8 @@ __global__ __launch_bounds__(128) void k_seq(const uint8_t *__restrict__ in, con
     }
 }
 
+#endif  // MZD_TEST_KERNELS (k_seq)
+
 // ------------------------------------------------------------------------------------------
 // k_seq_pipe: the sequence decode as a THREE-STAGE PIPELINE ACROSS THE SIMDs OF ONE CU.
 //
@@ -1649,6 +1654,7 @@ __device__ __forceinline__ uint32_t sub_sat(uint32_t a, uint32_t b)  // max(0, a
     return r;
 }
 
+#ifdef MZD_TEST_KERNELS
 __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in, const SeqTask *__restrict__ tasks,
                                                   uint32_t n_tasks, const uint32_t *__restrict__ fse_entries,
                                                   uint64_t *__restrict__ recs, TileBase *__restrict__ tiles,
@@ -2436,6 +2442,8 @@ __global__ __launch_bounds__(256) void k_seq_pipe(const uint8_t *__restrict__ in
         if (st != MZD_OK) atomicCAS(&sums[t.block].status, MZD_OK, st);
     }
 }
+
+#endif  // MZD_TEST_KERNELS (k_seq_pipe)
 
 // ------------------------------------------------------------------------------------------
 // k_exec: sequence execution + Raw/RLE blocks.  One workgroup per frame, several per CU.

@@ -157,6 +157,10 @@ __global__ __launch_bounds__(kQ4Threads) void k_seq_q4(const uint8_t *__restrict
     const uint32_t ch = chainw ? (quad < (uint32_t)kQ4ChainsPerWave ? (uint32_t)wave * kQ4ChainsPerWave + quad : (uint32_t)kQ4Cols - 1u) : (uint32_t)lane;
     const uint32_t tid = blockIdx.x * nch + ch;
     const bool has = ch < nch && tid < n_tasks;
+    // in_base == ~0 (round 6): the window is the WORKGROUP's -- from its first chain's bitstream on: the chains of a workgroup are
+    // consecutive blocks of a list in frame order, a few MB apart at most, wherever in a blob of any size they lie (what used to send
+    // a frame whose bitstreams span more than 4 GiB to the older kernel)
+    if (in_base == ~0ull) in_base = tasks[min(blockIdx.x * nch, n_tasks - 1)].in_off;
     SeqTask t;
     if (has) {
         t = tasks[tid];

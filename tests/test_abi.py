@@ -67,6 +67,26 @@ def test_product_does_not_link_oracle():
     assert b"orc_decode_frame" not in so and b"sparkzstd_oracle" not in so
 
 
+def test_release_library_has_one_kernel_per_stage():
+    """Round 6: the second implementations the parity tests force -- k_seq, k_seq_pipe (sequence stage), k_huf_seg
+    (Huffman), k_exec_b (execution) -- are test scaffolding: compiled into libmzd_test.so (-DMZD_TEST_KERNELS), absent from the release
+    library, which keeps one kernel per stage (k_huf / k_huf_w by the batch, k_seq_q4, k_exec_c) + k_exec for frames of 4 GiB and more;
+    both libraries export the same ABI.  (The kernels' mangled names stand in the libraries' device code objects.)"""
+    rel = open(_lib.LIB_PATH, "rb").read()
+    test = open(_lib.TEST_LIB_PATH, "rb").read()
+    for name in (b"k_seq_pipe", b"k_huf_seg", b"k_exec_b", b"3mzd5k_seqE"):
+        assert name not in rel, name
+        assert name in test, name
+    for name in (b"k_seq_q4", b"k_exec_c", b"k_huf_w", b"3mzd5k_hufE", b"3mzd6k_execE", b"k_copy_blocks", b"k_parse"):
+        assert name in rel and name in test, name
+    T = _lib.load_test()
+    assert T.mzd_abi_version() == _lib.MZD_ABI_VERSION and T.mzd_build_id().endswith(b"+test") and not _lib.load().mzd_build_id().endswith(b"+test")
+    for name in _lib.EXPORTS:
+        assert hasattr(T, name), name
+    assert _lib.needs_test_kernels(seq_variant=1) and _lib.needs_test_kernels(huf_variant=2) and _lib.needs_test_kernels(exec_variant=3)
+    assert not _lib.needs_test_kernels(0, 3, 5) and not _lib.needs_test_kernels(2, 4, 4) and not _lib.needs_test_kernels(0, 0, 1)
+
+
 def test_release_library_reads_no_environment_variable():
     """The experiment hooks of the kernels' A/B runs (MZD_EXEC_MIN_LDS, MZD_SEQ_NCH, MZD_DEBUG_SEQ_ONLY, ...) exist only in builds
     made with -DMZD_EXPERIMENTS: the shipped libmzd.so must not change behaviour on ambient environment variables."""

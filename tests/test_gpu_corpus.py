@@ -1137,9 +1137,10 @@ def test_stream_refuses_overcommit_and_small_output(corpus, ctx):
 
 @pytest.mark.parametrize("window_kib,device_plan", [(64, False), (64, True), (300, True), (1, False)])
 def test_input_blob_decoded_window_by_window(corpus, ctx, oracle, window_kib, device_plan):
-    """k_seq_pipe addresses bitstreams with 32-bit offsets from a window of the blob; blobs of 4 GiB and more
+    """k_seq_q4 addresses bitstreams with 32-bit offsets from a window of the blob; blobs of 4 GiB and more
     are decoded window by window.  With the window shrunk to a few KiB the corpus + synthetic batch takes many
-    launches, and frames wider than a window take the two-wavefront kernel: same bytes either way."""
+    launches, and a frame wider than a window is decoded with a window per WORKGROUP (round 6: from the workgroup's first chain on;
+    it used to fall back to the two-wavefront kernel, which the release library no longer has): same bytes either way."""
     from tools import synth_binding as sb
     blob, off, ln, _, _ = sb.make_batch(4, 31, 24, threads=4)
     frames = [comp for _, comp, *_ in corpus] + [bytes(blob[o:o + l]) for o, l in zip(off, ln)]

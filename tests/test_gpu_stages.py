@@ -227,6 +227,28 @@ def _check_stage_boundaries(c, corpus, oracle):
         c.close()
 
 
+def test_release_library_refuses_the_test_kernels(corpus):
+    """The release library has one kernel per stage: a context that forces a second implementation (k_seq, k_seq_pipe, k_huf_seg,
+    k_exec_b) on it gets MZD_ERR_UNSUPPORTED from the pass -- not a silent substitute --; the same context on libmzd_test.so (what
+    z.Context picks for such variants by itself) decodes, and the test library's DEFAULT path gives the release library's bytes."""
+    frames = [comp for _, comp, *_ in corpus[:12]]
+    for kw in ({"seq_variant": 1}, {"seq_variant": 3}, {"huf_variant": 2}, {"exec_variant": 2}, {"exec_variant": 3}):
+        c = z.Context(0, library="release", **kw)
+        with pytest.raises(z.MzdError) as e:
+            z.decode_frames(frames, c)
+        assert e.value.code == 16, kw
+        c.close()
+        c = z.Context(0, **kw)
+        assert c._L is _lib.load_test()
+        outs, sts = z.decode_frames(frames, c)
+        assert sts == [0] * len(frames)
+        c.close()
+    ct, cr = z.Context(0, library="test"), z.Context(0)
+    assert z.decode_frames(frames, ct) == z.decode_frames(frames, cr)
+    ct.close()
+    cr.close()
+
+
 # ---- k_huf_seg: one wavefront per Huffman stream, segments decoded in parallel (self-synchronising codes)
 
 @pytest.mark.parametrize("huf_variant", [2, 3, 4])
