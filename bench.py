@@ -34,8 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # the files libmzd.so is made of, in the order sparkzstd_amd/csrc/Makefile hashes them into mzd_build_id()
-LIBRARY_SOURCES = ("mzd_api.hip", "mzd_device.h", "mzd_exec_b.hip", "mzd_exec_blk.hip", "mzd_exec_c.hip", "mzd_huf_w.hip", "mzd_kernels.hip", "mzd_parse.hip",
-                   "mzd_seq_q4.hip", "planner.cpp", "../../include/mzd.h")
+LIBRARY_SOURCES = ("mzd_api.hip", "mzd_device.h", "mzd_exec.hip", "mzd_exec_b.hip", "mzd_exec_blk.hip", "mzd_exec_c.hip", "mzd_huf.hip", "mzd_huf_w.hip",
+                   "mzd_kernels.hip", "mzd_parse.hip", "mzd_seq.hip", "mzd_seq_q4.hip", "mzd_util.hip", "planner.cpp", "../../include/mzd.h")
 
 
 def library_src_sha16():

@@ -16,6 +16,10 @@
 
 // unity build: the kernels live in their own file but are compiled in this translation unit
 #include "mzd_kernels.hip"
+#include "mzd_huf.hip"
+#include "mzd_seq.hip"
+#include "mzd_exec.hip"
+#include "mzd_util.hip"
 #include "mzd_huf_w.hip"
 #include "mzd_seq_q4.hip"
 #include "mzd_exec_b.hip"
@@ -1732,7 +1736,9 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // (block mode too, round 4: the frames' literals are not needed before the passes -- one 64 MiB frame 5.18 -> 4.77 ms, 100 frames of
     // the reference's corpus, which take block mode, 12.5 -> 10.2 ms, 64 x 128 MiB 83.3 -> 82.9; profiles/r4_huf_beside_block_mode.txt)
     const bool huf_het_beside = serial && ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && !exp_env("MZD_EXP_HET_HUF_FIRST");
-    const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 || (ctx->opt.huf_variant == 4 && db->n_seq_tasks > 0) ||
+    // (no sequences in the batch -- BASELINE config 3: nothing to run the Huffman kernel beside; on the caller's stream the pass is three
+    // launches in a row instead of two hand-overs between streams, 10-20 us each of a 0.4 ms pass)
+    const bool huf_first = (serial && !huf_het_beside) || ctx->opt.huf_variant == 3 || (ctx->opt.huf_variant == 4 && db->n_seq_tasks > 0) || db->n_seq_tasks == 0 ||
                            (ctx->opt.huf_variant == 0 && db->n_seq_tasks > 0 && db->huf_slot_cells <= 32 &&
                             db->n_huf_tasks >= 64u * (uint32_t)std::max(ctx->num_cus, 1) &&
                             // ... and more chains than one round of the sequence stage: with a single round (the 8 192-frame shard

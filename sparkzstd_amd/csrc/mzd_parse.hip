@@ -527,7 +527,10 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                         const int used = p_read_fse_description(base + q, lim - q, sc.prob, nsym, al);
                         if (used < 0) P_FAIL(-used);
                         if (al > kPMaxLog[kind]) P_FAIL(MZD_ERR_UNSUPPORTED);
-                        if (nsym > kPMaxSym[kind] + 1) P_FAIL(MZD_ERR_FSE_TABLE);
+                        // (as the host planner: a description that runs on in zeros beyond the kind's codes is the table without them; one
+                        // that gives such a symbol cells is outside what the code tables translate -- a documented limit, fse.go:219-224)
+                        while (nsym > kPMaxSym[kind] + 1 && sc.prob[nsym - 1] == 0) nsym--;
+                        if (nsym > kPMaxSym[kind] + 1) P_FAIL(MZD_ERR_UNSUPPORTED);
                         const uint32_t ncell = ((uint32_t)nsym + 1) / 2;
                         if (PASS == 1) {
                             FseBuildDesc fd{};

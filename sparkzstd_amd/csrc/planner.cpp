@@ -324,7 +324,14 @@ struct FrameParser {
             int used = read_fse_description(base + p, lim - p, nc);
             if (used < 0) return used;
             if (nc.acc_log > kMaxLog[kind]) return -MZD_ERR_UNSUPPORTED;
-            if ((int)nc.prob.size() > kMaxSym[kind] + 1) return -MZD_ERR_FSE_TABLE;
+            // More symbols than the kind has codes (LL 36 / OF 32 / ML 53).  The reference builds such a table all the same: a symbol
+            // beyond its translation array stays untranslated, with no extra bits (fse.go:219-224, `if len(symbolTranslation) > symbol`).
+            // Symbols of probability 0 never get a cell: a description that merely RUNS ON in zeros is the table without them (what the
+            // reference decodes it as).  One that gives such a symbol cells is not zstd (libzstd rejects it) and is outside what the
+            // device's code tables translate: MZD_ERR_UNSUPPORTED, a documented limit -- not MZD_ERR_FSE_TABLE, which would claim that
+            // the reference fails it too (found by the soak of round 6, seed 6: an ML table whose symbol 53 is "less than one").
+            while ((int)nc.prob.size() > kMaxSym[kind] + 1 && nc.prob.back() == 0) nc.prob.pop_back();
+            if ((int)nc.prob.size() > kMaxSym[kind] + 1) return -MZD_ERR_UNSUPPORTED;
             std::vector<mzd_fse_entry> cells;
             if (device_tables) {
                 // counts only: two int16 per cell; read_fse_description has checked that they sum to the

@@ -2,6 +2,7 @@
 CPU oracle (bit-exact)."""
 import ctypes
 import io
+import os
 
 import numpy as np
 import pytest
@@ -952,6 +953,13 @@ def test_device_planner_block_by_block_corpus_and_fuzz(corpus, oracle):
             (_,), (sd,) = z.decode_frames([comp[:cut]], c, device_plan=True)
             (_,), (sh,) = z.decode_frames([comp[:cut]], c)
             assert sd == sh != 0, (cut, sd, sh)
+        # a table with a symbol beyond its kind's codes (tests/golden/fuzz_ml_symbol_53.zst, the soak of round 6): MZD_ERR_UNSUPPORTED from both
+        # planners, the device's block by block and as one lane, like the host's (tests/test_planner.py)
+        ml53 = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_ml_symbol_53.zst"), "rb").read()
+        for on in (True, False):
+            _plan_by_blocks(c, on)
+            assert z.decode_frames([ml53], c, device_plan=True)[1] == [16] and z.decode_frames([ml53], c)[1] == [16]
+        _plan_by_blocks(c)
         # ... and cut INSIDE its content checksum (fewer than four bytes behind the last block): the frame's last unit must say
         # whether the four bytes were there -- with verification on, both planners leave the flag clear, the frame decodes, and
         # nobody reports the failure of a checksum that is not there (the block-by-block route used to)

@@ -291,6 +291,34 @@ def test_huf_seg_literal_heavy_frames_of_every_size(oracle):
         assert rc == 0 and ref == w
 
 
+def test_huf_w_segments_that_make_more_symbols_than_a_lane_keeps(oracle):
+    """k_huf_w sizes a stream's segments by its AVERAGE code length (a lane keeps 104 symbols in registers); a stream whose code
+    lengths change along the way -- incompressible bytes, then one byte over and over: 8 bits a symbol, then 1 -- makes segments with
+    several times that: the round is run again with half the segment until every lane's symbols fit.  Literal-only and full frames,
+    the long stretch first / last / in the middle, streams of one and of several rounds; against the oracle and the content."""
+    from tools import synth_binding as sb
+    rng = np.random.default_rng(77)
+    datas = []
+    for n, order in ((120000, 0), (131072, 1), (60000, 2), (9000, 0), (131072, 3)):
+        noise = rng.integers(0, 256, n // 3, dtype=np.uint8).tobytes()
+        flat = bytes([65]) * (n - len(noise) - n // 10) + bytes(rng.integers(65, 68, n // 10, dtype=np.uint8))
+        parts = [noise, flat] if order == 0 else [flat, noise] if order == 1 else [flat[:len(flat) // 2], noise, flat[len(flat) // 2:]]
+        if order == 3:
+            parts = [sb.generate(sb.TEXT, 5, n // 2), flat[:n - n // 2]]
+        datas.append(b"".join(parts)[:n])
+    frames = [sb.compress(d, sb.MODE_LITERALS)[0] for d in datas] + [sb.compress(d, sb.MODE_FULL)[0] for d in datas]
+    want = datas + datas
+    for hv in (4, 0, 3):
+        c = z.Context(0, huf_variant=hv)
+        outs, sts = z.decode_frames(frames, c)
+        assert sts == [0] * len(frames), (hv, sts)
+        assert outs == want, hv
+        c.close()
+    for f, w in zip(frames, want):
+        rc, ref, _, _ = oracle.decode_frame(f, cap=len(w) + 64)
+        assert rc == 0 and ref == w
+
+
 def test_huf_seg_reports_the_lane_kernels_status_on_damaged_streams(corpus, oracle):
     """End conditions of huffman.go:248-261 / literals.go:320-366 under damage: every corpus frame and literal-heavy
     synthetic frames, mutated (seeded byte flips) -- k_huf_seg and k_huf must give the SAME status and bytes frame for

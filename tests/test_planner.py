@@ -282,3 +282,19 @@ def test_planner_tables_equal_the_oracles_cell_for_cell(oracle, corpus):
     assert n_fse > 500 and bd.n_huf_tables > 300
     ph.close()
     pd.close()
+
+
+def test_fse_table_with_a_symbol_beyond_its_kind_is_a_documented_limit(oracle):
+    """A mutation the soak of round 6 found (tests/golden/fuzz_ml_symbol_53.zst: a corpus-derived frame, 175 bytes): its match-length
+    table gives symbol 53 -- one beyond ML's 53 codes -- the probability "less than one".  The reference builds the table anyway, the
+    symbol untranslated and without extra bits (fse.go:219-224), and the oracle, which follows it, decodes the frame; libzstd rejects it.
+    The planner reports MZD_ERR_UNSUPPORTED (16, a documented limit: the device's code tables translate the format's codes only),
+    not MZD_ERR_FSE_TABLE (5), which would claim the reference fails the frame too."""
+    import os
+    f = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_ml_symbol_53.zst"), "rb").read()
+    rc, out, _, _ = oracle.decode_frame(f, cap=1 << 20)
+    assert rc == 0 and len(out) == 37338
+    for dt in (False, True):
+        p = z.Plan(device_tables=dt)
+        assert p.add_frame(f)[0] == 16
+        p.close()

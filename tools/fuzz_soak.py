@@ -6,7 +6,7 @@ be one the oracle decodes to the same bytes; a frame the oracle rejects must car
 Two pools of base frames, batches alternate between them:
   small   frames that regenerate at most 128 KiB (what BASELINE's configs are made of): the library's own choice for such a
           batch is k_huf first, k_seq_q4, k_exec_c; contexts: the default, k_seq / k_seq_pipe with k_exec_c (exec_variant 5),
-          k_exec_b, k_exec
+          k_exec_b, k_exec, k_huf_w for every stream (round 6; the variants that are second implementations come from libmzd_test.so)
   mixed   everything, frames of up to 1.2 MiB in several blocks: 8-byte records, the serial walk and block mode (exec_variant
           3, 4; 4 also with mzd_debug_force_fixup_bail: the rescue launch of the fix-up walk on damaged input)
 Both pools hold PERIODIC content too (runs that feed themselves at periods of 1 to 40 bytes: the in-pass resolver of
@@ -68,10 +68,12 @@ for i in range(4):
 
 ctx_small = [("default", z.Context(0)), ("k_seq + k_exec_c", z.Context(0, seq_variant=1, exec_variant=5)),
              ("k_seq_pipe + k_huf_seg + k_exec_c", z.Context(0, seq_variant=3, huf_variant=2, exec_variant=5)),
-             ("k_exec_b", z.Context(0, exec_variant=2)), ("k_exec + checksum", z.Context(0, exec_variant=1, verify_checksum=True))]
+             ("k_exec_b", z.Context(0, exec_variant=2)), ("k_exec + checksum", z.Context(0, exec_variant=1, verify_checksum=True)),
+             ("k_huf_w for every stream", z.Context(0, huf_variant=4))]
 ctx_mixed = [("default + checksum", z.Context(0, verify_checksum=True)), ("k_seq", z.Context(0, seq_variant=1)), ("k_huf first", z.Context(0, huf_variant=3)),
              ("k_exec_c", z.Context(0, exec_variant=5)), ("k_exec_b", z.Context(0, exec_variant=2)), ("block mode", z.Context(0, exec_variant=3)),
-             ("block mode, jobs of four", z.Context(0, exec_variant=4, huf_variant=2)), ("block mode, fix-up rescue", z.Context(0, exec_variant=4))]
+             ("block mode, jobs of four", z.Context(0, exec_variant=4, huf_variant=2)), ("k_huf_w for every stream", z.Context(0, huf_variant=4)),
+             ("block mode, fix-up rescue", z.Context(0, exec_variant=4))]
 bail_ctx = ctx_mixed[-1][1]
 
 
