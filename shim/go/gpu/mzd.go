@@ -45,6 +45,10 @@ var (
 // (decompression imports gpu), so the decompression package registers them at init time (reader_gpu.go: init()).
 var Sentinels = map[int]error{}
 
+// BuildID names the library the process runs on: the first 16 hex digits of the sha256 of the sources it was built from (mzd_build_id,
+// ABI 8).
+func BuildID() string { return C.GoString(C.mzd_build_id()) }
+
 // SentinelFor turns a per-frame status of the device into the Go error the reference would have returned
 // (INTEGRATION.md section 2, table "Mapping of statuses"); nil for MZD_OK.
 func SentinelFor(status int32) error {

@@ -527,6 +527,22 @@ def test_cpp_frame_reader_verify_cli(corpus, flags):
     assert "Found no diffs in any files" in r.stdout and "Found no unexpected errors" in r.stdout
 
 
+@pytest.mark.parametrize("lookahead", [1, 7, 64])
+def test_cpp_batch_frame_reader_on_the_streaming_path(corpus, lookahead):
+    """sparkzstd::BatchFrameReader (round 6: a worker thread, pinned buffers, two batches in flight on mzd_stream_*) beyond the happy
+    path, in C++ (`sparkzstd_verify --reader-selftest`): Read and View against DecodeFrames' bytes, a frame cut in half (its error at
+    ITS read, the frames behind it served), a wrong magic number (Reset's error, framereader.go:35-49), sources enqueued while the
+    reader is being served, a reader destroyed with batches in flight."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "verify", "sparkzstd_verify")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tools", "verify")])
+    d = os.path.join(root, "tests", "golden", "decodecorpus")
+    files = [os.path.join(d, name + ".zst") for name, *_ in corpus]
+    r = subprocess.run([exe, "--reader-selftest", str(lookahead)] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "reader selftest ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_batch_frame_reader_serves_frames_in_order(corpus):
     """BatchFrameReader: the reference harness's pattern (ONE reader, Reset per frame: framereader.go:35,
     cmd/sparkzstd/main.go:59,126) with the frames to come known to the reader -- it reads ahead, decodes `lookahead` frames per

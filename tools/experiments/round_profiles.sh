@@ -2,7 +2,7 @@
 # traffic + SQ counters + the bench line (quoting them) for BASELINE config 4, the real-data workload, config 3 and the 8192-frame
 # shard of configs[4]; the config-2 bench line; few large frames (block mode) with kernel stats; the readers; the streaming path; the
 # shard table.  usage: bash tools/experiments/round_profiles.sh r5 [quick]     (quick: config 4 only)
-TAG=${1:-r5}
+TAG=${1:-r6}
 QUICK=${2:-}
 cd ${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p gpurun_out
@@ -29,6 +29,7 @@ timeout 900 python bench.py --cpu-seconds 0 --no-ceiling --steps 2 --warmup 1 --
 timeout 900 python bench.py --cpu-seconds 0 --no-ceiling --steps 3 --warmup 1 --frames 8192 --frame-bytes 1048576 2>/dev/null | tee gpurun_out/${TAG}_large_8192x1MiB_bench.json | pick "8192 x 1 MiB"
 timeout 600 python tools/stream_bench.py 8192 12 1,2,3 2>/dev/null | tail -3 | tee gpurun_out/${TAG}_stream.json
 timeout 600 python tools/reader_bench.py 1024 67108864 2>/dev/null | tail -6 | tee gpurun_out/${TAG}_reader.txt
+timeout 600 python tools/reader_bench_cpp.py 2048 32768 2>/dev/null | tee gpurun_out/${TAG}_reader_cpp.jsonl | cut -c1-200
 bash tools/experiments/large_reader.sh 2>&1 | tee gpurun_out/${TAG}_large_frame_reader.txt
 for n in 65536 32768 16384 8192; do timeout 300 python bench.py --cpu-seconds 0 --no-ceiling --frames $n 2>/dev/null | tee gpurun_out/${TAG}_shard_${n}_1gpu.json | pick "shard $n"; done
 ls gpurun_out | grep "^${TAG}" | head -80

@@ -3,7 +3,7 @@
 # Outputs under gpurun_out/<tag>_cfg<N>_pmc{A,B,C}; tools/summarize_counters.py <tag> <cfg> <steps> prints / writes the table.
 # usage: tools/profile_counters.sh <tag> <config> [extra bench flags]
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r5}
+TAG=${1:-r6}
 CFG=${2:-4}
 shift $(( $# < 2 ? $# : 2 ))
 EXTRA="$@"

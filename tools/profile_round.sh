@@ -7,7 +7,7 @@
 # Copy what is to be kept into profiles/ (gpurun_out/ is scratch).
 # usage: tools/profile_round.sh <tag> <config> [extra bench flags]
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r5}
+TAG=${1:-r6}
 CFG=${2:-4}
 shift $(( $# < 2 ? $# : 2 ))
 EXTRA="$@"

@@ -60,6 +60,83 @@ int main(int argc, char **argv)
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         first = argc;
     }
+    if (argc > first + 2 && std::string(argv[first]) == "--reader-selftest") {
+        // --reader-selftest <lookahead> <x.zst> ...: BatchFrameReader's behaviour beyond the happy path (framereader.go:35-109): every
+        // frame equals DecodeFrames' bytes through Read AND through View; a frame cut in half raises at ITS read and the frames behind it
+        // are served; a wrong magic number raises at Reset; sources enqueued while the reader is being served are served; a reader that
+        // is destroyed with batches in flight shuts down.
+        const size_t look = (size_t)atoi(argv[first + 1]);
+        std::vector<std::vector<uint8_t>> frames;
+        for (int i = first + 2; i < argc; i++) {
+            std::ifstream z(argv[i], std::ios::binary);
+            frames.emplace_back(std::istreambuf_iterator<char>(z), std::istreambuf_iterator<char>());
+        }
+        int fails = 0;
+        auto check = [&](bool ok, const char *what, size_t i) {
+            if (!ok) {
+                printf("selftest FAILED: %s (frame %zu)\n", what, i);
+                fails++;
+            }
+        };
+        std::vector<int> st;
+        const auto want = sparkzstd::DecodeFrames(frames, &st);
+        const size_t n = frames.size(), cut_at = n / 3, magic_at = 2 * n / 3;
+        {
+            sparkzstd::BatchFrameReader br(look);
+            for (size_t i = 0; i < n / 2; i++) {
+                if (i == cut_at) br.Enqueue(std::vector<uint8_t>(frames[i].begin(), frames[i].begin() + (long)(frames[i].size() / 2)));
+                else br.EnqueueView(frames[i].data(), frames[i].size());
+            }
+            std::vector<uint8_t> buf(50000), got;
+            for (size_t i = 0; i < n; i++) {
+                if (i == n / 2)  // the second half becomes known while the first is being served
+                    for (size_t k = n / 2; k < n; k++) {
+                        if (k == magic_at) br.Enqueue(std::vector<uint8_t>{0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+                        else br.Enqueue(frames[k]);
+                    }
+                bool threw = false;
+                try {
+                    if (!br.Reset()) {
+                        check(false, "reader ran out of frames", i);
+                        break;
+                    }
+                } catch (const sparkzstd::Error &e) {
+                    threw = true;
+                    check(i == magic_at && e.code() == MZD_ERR_MAGIC, "Reset threw", i);
+                }
+                if (i == magic_at) {
+                    check(threw, "a wrong magic number must raise at Reset", i);
+                    continue;
+                }
+                got.clear();
+                try {
+                    if (i % 2) {
+                        const auto v = br.View();
+                        got.assign(v.first, v.first + v.second);
+                        check(br.Read(buf.data(), buf.size()) == 0, "EOF behind View", i);
+                    } else {
+                        while (const size_t k = br.Read(buf.data(), buf.size())) got.insert(got.end(), buf.begin(), buf.begin() + (long)k);
+                    }
+                    check(i != cut_at, "a frame cut in half must raise at its read", i);
+                    check(st[i] == MZD_OK && got == want[i], "bytes differ from DecodeFrames", i);
+                } catch (const sparkzstd::Error &e) {
+                    check(i == cut_at, "Read threw", i);
+                }
+            }
+            check(!br.Reset(), "EOF: no frame left", n);
+            check(br.FramesServed == n, "frames served", br.FramesServed);
+        }
+        {
+            // destroyed with batches in flight: the destructor stops the worker and frees the pinned buffers
+            sparkzstd::BatchFrameReader br(look);
+            for (size_t rep = 0; rep < 6; rep++)
+                for (auto &f : frames) br.EnqueueView(f.data(), f.size());
+            check(br.Reset(), "first frame", 0);
+        }
+        if (fails) printf("reader selftest: %d failure(s)\n", fails);
+        else printf("reader selftest ok (%zu frames, lookahead %zu)\n", n, look);
+        return fails ? 1 : 0;
+    }
     if (argc > first + 3 && std::string(argv[first]) == "--bench") {
         // --bench <file of concatenated frames> <frames to serve> <lookahead> [read|view]: host-to-host throughput of the reader that
         // batches (framereader.go:35-109 consumer shape: one reader, Reset per frame, the frame consumed whole).  The file's frames are
