@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MZD_ABI_VERSION 8
+#define MZD_ABI_VERSION 9
 
 /* ------------------------------------------------------------------ status codes
  * Per-frame status mirrors the reference's sentinel errors (file:line of the
@@ -90,8 +90,18 @@ typedef struct mzd_frame_desc {
     uint64_t window_size;   /* frame.go:28-36 / framedecompressor.go:358-360; informational + limit check */
     uint32_t checksum;      /* the 4 bytes after the last block (low half of XXH64(content, 0)) when flags say so */
     uint32_t flags;         /* MZD_FRAME_* */
+    /* ABI 9 -- a CHUNK of a frame (MZD_FRAME_CONTINUES): the blocks listed are not the frame's first.  The slab then BEGINS with
+     * `start` bytes the frame regenerated before them -- at least its last window_size bytes: ringbuffer.go:36-49 keeps exactly
+     * that much -- and the chunk's output follows at slab byte `start`; out_capacity counts from the slab's beginning, the reported
+     * length includes `start`; hist is the offset history behind the blocks before (framedecompressor.go:23), {1, 4, 8} if the
+     * frame had no sequences yet.  Both are ignored without the flag. */
+    uint64_t start;
+    int32_t hist[3];
+    uint32_t reserved;
 } mzd_frame_desc;
 #define MZD_FRAME_HAS_CHECKSUM 1u /* Content_Checksum_flag set (frame.go:106-108) and the 4 bytes were there */
+#define MZD_FRAME_CONTINUES 2u    /* the description is a chunk of a frame: `start`, `hist` (ABI 9); a batch that holds one keeps the
+                                     offset history behind every frame's last block for the chunk after it (mzd_fstream_next) */
 #define MZD_FRAME_PLAN_STATUS_SHIFT 8 /* bits 8..15: the MZD_ERR_* with which the planner gave the frame up (it then has no
                                         blocks); 0 = planned.  The device reports it as the frame's status. */
 
@@ -453,6 +463,56 @@ int mzd_plan_add_frames(mzd_plan *p, const uint8_t *blob, const uint64_t *frame_
 const mzd_batch *mzd_plan_finalize(mzd_plan *p);
 /* planning status of frame i (MZD_OK if it parsed) */
 int mzd_plan_frame_status(const mzd_plan *p, uint32_t i);
+
+
+/* ------------------------------------------------------------------ one frame in chunks (ABI 9)
+ * The reference decodes a frame block by block into a ring of the frame's WINDOW size and its reader hands the bytes on as they
+ * come (framedecompressor.go:198-303 DecodeNextBlock, ringbuffer.go:36-49, framereader.go:51-109): it never holds a frame
+ * whole, in or out.  A batch of whole frames does (every frame's output has a slab).  These entry points are the reference's
+ * shape for ONE frame: the frame goes through the device as a sequence of CHUNKS of whole blocks; the device keeps the window,
+ * the offset history and nothing else between two chunks.  So a frame may be larger than the device's memory, its source may
+ * arrive piecewise, and its first bytes are out before its last ones are in.
+ *
+ * Host half -- the cursor: walks the frame's blocks as their bytes arrive and describes each chunk as a batch of one frame
+ * (MZD_FRAME_CONTINUES, `start`, `hist`), with the tables in force at the chunk's start (framedecompressor.go:283-294) in it. */
+typedef struct mzd_cursor mzd_cursor;
+mzd_cursor *mzd_cursor_create(void);
+void mzd_cursor_destroy(mzd_cursor *c);
+/* `src` / `len`: the frame's bytes that no earlier call consumed (magic number first on the first call).  Takes the whole blocks
+ * that are there, as long as what they can regenerate stays within max_out (one block at least, whatever max_out), and describes
+ * them: *chunk is a batch whose `in` is `src` itself (valid until the next call on the cursor; `src` must stay where it is while
+ * the batch is used), with out_capacity = start + the blocks' bound.  `start` and `hist` go into the frame description as they
+ * are (hist NULL: {1, 4, 8}).  *consumed: bytes of src that are done with.  *chunk == NULL with MZD_OK: no whole block in src yet
+ * -- come back with more bytes (the unconsumed ones first).  *last: the chunk holds the frame's last block; the 4 bytes of a
+ * content checksum are not consumed, like the reference's reader leaves them (framereader.go:84-94).  After the last block:
+ * MZD_ERR_OUT_OF_BLOCKS (framedecompressor.go:196).  A parse error is returned and sticks. */
+int mzd_cursor_next(mzd_cursor *c, const uint8_t *src, uint64_t len, uint64_t max_out, uint64_t start, const int32_t hist[3],
+                    uint64_t *consumed, const mzd_batch **chunk, int *last);
+/* from the frame header, once a call has consumed it: Window_Size (frame.go:28-36; the content size of a single-segment frame),
+ * Frame_Content_Size or MZD_UNKNOWN_SIZE; the content checksum if the frame has one and its bytes were in sight: returns 1 */
+uint64_t mzd_cursor_window(const mzd_cursor *c);
+uint64_t mzd_cursor_content_size(const mzd_cursor *c);
+int mzd_cursor_checksum(const mzd_cursor *c, uint32_t *checksum);
+
+/* Device half -- mzd_fstream: the cursor + two slabs of (window + chunk) bytes on the device.  A chunk is decoded behind the
+ * window bytes of the chunks before it, by the same kernels as a batch (block mode for a large chunk); its bytes go to the
+ * caller, the last window_size bytes and the history stay.  Replaces FrameDecompressor.DecodeNextBlock + Ringbuffer for one
+ * frame (framedecompressor.go:198-303, ringbuffer.go) and is what FrameReader.Read sits on (framereader.go:51-109). */
+typedef struct mzd_fstream mzd_fstream;
+/* chunk_out: bytes a chunk may regenerate (0: 64 MiB; at least one block).  The device memory the frame needs is
+ * 2 x (window + chunk_out) + the chunk's scratch, whatever its length. */
+int mzd_fstream_open(mzd_ctx *ctx, uint64_t chunk_out, mzd_fstream **fs);
+/* Decodes the next chunk.  src / len as for mzd_cursor_next; dst: host memory for the chunk's bytes, dst_cap >= 128 KiB (a
+ * chunk's bound is min(chunk_out, dst_cap)).  *consumed / *produced: bytes of src used, bytes written to dst; both zero with
+ * MZD_OK: src holds no whole block yet.  *done: the frame's last block has been decoded (then, if the header declared a content
+ * size and the frame regenerated another: MZD_ERR_DST_FULL).  A frame whose window does not fit beside a chunk in 2 GiB:
+ * MZD_ERR_UNSUPPORTED.  Errors stick. */
+int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t *dst, uint64_t dst_cap, uint64_t *consumed,
+                     uint64_t *produced, int *done);
+/* bytes regenerated so far; the cursor (header fields) */
+uint64_t mzd_fstream_total_out(const mzd_fstream *fs);
+const mzd_cursor *mzd_fstream_cursor(const mzd_fstream *fs);
+void mzd_fstream_close(mzd_fstream *fs);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MZD_LIB") or os.path.join(HERE, "libmzd.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
-MZD_ABI_VERSION = 8
+MZD_ABI_VERSION = 9
 MZD_UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 MZD_IN_PAD = 64
 MZD_BATCH_IN_ON_DEVICE = 1
@@ -26,6 +26,8 @@ EXPORTS = [
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
     "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
     "mzd_batch_last_pass", "mzd_batch_trim", "mzd_debug_plan_unit_bytes",
+    "mzd_cursor_create", "mzd_cursor_destroy", "mzd_cursor_next", "mzd_cursor_window", "mzd_cursor_content_size", "mzd_cursor_checksum",
+    "mzd_fstream_open", "mzd_fstream_next", "mzd_fstream_total_out", "mzd_fstream_cursor", "mzd_fstream_close",
 ]
 MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT, MZD_PASS_TWO_GROUPS = 2, 4, 8, 16, 32
 
@@ -44,10 +46,12 @@ class FrameDesc(ctypes.Structure):
     _fields_ = [("first_block", ctypes.c_uint32), ("n_blocks", ctypes.c_uint32),
                 ("out_offset", ctypes.c_uint64), ("out_capacity", ctypes.c_uint64),
                 ("content_size", ctypes.c_uint64), ("window_size", ctypes.c_uint64),
-                ("checksum", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+                ("checksum", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("start", ctypes.c_uint64), ("hist", ctypes.c_int32 * 3), ("reserved", ctypes.c_uint32)]  # ABI 9: a chunk of a frame
 
 
 MZD_FRAME_HAS_CHECKSUM = 1
+MZD_FRAME_CONTINUES = 2
 MZD_ERR_CHECKSUM = 18
 
 
@@ -198,6 +202,17 @@ def _open(path):
         "mzd_batch_last_pass": (u32, [vp]),
         "mzd_batch_trim": (i32, [vp, vp]),
         "mzd_debug_plan_unit_bytes": (i32, [vp, u64]),
+        "mzd_cursor_create": (vp, []),
+        "mzd_cursor_destroy": (None, [vp]),
+        "mzd_cursor_next": (i32, [vp, vp, u64, u64, u64, vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.POINTER(Batch)), ctypes.POINTER(i32)]),
+        "mzd_cursor_window": (u64, [vp]),
+        "mzd_cursor_content_size": (u64, [vp]),
+        "mzd_cursor_checksum": (i32, [vp, ctypes.POINTER(u32)]),
+        "mzd_fstream_open": (i32, [vp, u64, ctypes.POINTER(vp)]),
+        "mzd_fstream_next": (i32, [vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(i32)]),
+        "mzd_fstream_total_out": (u64, [vp]),
+        "mzd_fstream_cursor": (vp, [vp]),
+        "mzd_fstream_close": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

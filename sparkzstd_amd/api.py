@@ -451,6 +451,93 @@ class Stream:
             pass
 
 
+class Cursor:
+    """The host half of a frame in chunks (mzd_cursor_*, ABI 9): walks the frame's blocks as their bytes arrive and describes every
+    chunk of whole blocks as a batch of one frame (framedecompressor.go:198-303 walks them one by one)."""
+
+    def __init__(self):
+        self._L = _lib.load()
+        self._c = self._L.mzd_cursor_create()
+        self._src = None
+
+    def next(self, src, max_out: int, start: int = 0, hist=None):
+        """src: the frame's bytes not yet consumed (a uint8 array; kept alive while the chunk is in use).
+        -> (status, consumed, batch or None, last)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        self._src = src
+        consumed = ctypes.c_uint64()
+        bp = ctypes.POINTER(Batch)()
+        last = ctypes.c_int()
+        h = (ctypes.c_int32 * 3)(*hist) if hist is not None else None
+        rc = self._L.mzd_cursor_next(self._c, src.ctypes.data if src.size else None, src.size, max_out, start, h, ctypes.byref(consumed),
+                                     ctypes.byref(bp), ctypes.byref(last))
+        return rc, consumed.value, (bp.contents if bp else None), bool(last.value)
+
+    @property
+    def window(self) -> int:
+        return self._L.mzd_cursor_window(self._c)
+
+    @property
+    def content_size(self) -> int:
+        return self._L.mzd_cursor_content_size(self._c)
+
+    def close(self):
+        if self._c:
+            self._L.mzd_cursor_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        self.close()
+
+
+class FrameStream:
+    """One frame through the device in chunks of whole blocks (mzd_fstream_*, ABI 9): the device keeps the frame's window and its
+    offset history between two chunks and nothing else, so the frame may be larger than the device's memory, its source may arrive
+    piecewise and its first bytes are out before its last ones are in -- FrameDecompressor.DecodeNextBlock + Ringbuffer
+    (framedecompressor.go:198-303, ringbuffer.go:36-49) for one frame."""
+
+    def __init__(self, ctx: "Context" = None, chunk_bytes: int = 0):
+        self.ctx = ctx or default_context()
+        h = ctypes.c_void_p()
+        rc = self.ctx._L.mzd_fstream_open(self.ctx._c, chunk_bytes, ctypes.byref(h))
+        if rc:
+            raise MzdError(rc, "mzd_fstream_open")
+        self._h = h
+        self.done = False
+
+    @_ctx_locked
+    def next(self, src: np.ndarray, dst: np.ndarray):
+        """src: the frame's bytes not yet consumed; dst: where the chunk's bytes go (uint8 arrays; dst at least 128 KiB).
+        -> (consumed, produced); both 0: src holds no whole block yet.  self.done after the frame's last block."""
+        consumed, produced, done = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+        rc = self.ctx._L.mzd_fstream_next(self._h, src.ctypes.data if src.size else None, src.size, dst.ctypes.data, dst.size,
+                                          ctypes.byref(consumed), ctypes.byref(produced), ctypes.byref(done))
+        if rc:
+            raise MzdError(rc, "mzd_fstream_next: " + self.ctx.last_error())
+        self.done = bool(done.value)
+        return consumed.value, produced.value
+
+    @property
+    def total_out(self) -> int:
+        return self.ctx._L.mzd_fstream_total_out(self._h)
+
+    @property
+    def window(self) -> int:
+        return self.ctx._L.mzd_cursor_window(self.ctx._L.mzd_fstream_cursor(self._h))
+
+    @_ctx_locked
+    def close(self):
+        if self._h:
+            self.ctx._L.mzd_fstream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def declared_frame_cost(frame) -> int:
     """Compressed + declared decompressed bytes of one frame (the C + D a device pass moves for it), from the frame
     header alone (frame.go:23-61: descriptor byte, window descriptor, dictionary id, Frame_Content_Size).  A frame that

@@ -102,6 +102,8 @@ struct mzd_dbatch {
     uint64_t in_size = 0;
     uint8_t *d_out = nullptr;
     bool own_out = false;
+    bool has_chunks = false;          // a frame description of the batch is a CHUNK of a frame (MZD_FRAME_CONTINUES)
+    int32_t *d_frame_hist = nullptr;  // ... then: the offset history behind every frame's last block, three per frame
     DFrame *d_frames = nullptr;
     DBlock *d_blocks = nullptr;
     BlockSum *d_sums = nullptr;
@@ -438,6 +440,7 @@ void mzd_batch_free(mzd_ctx *ctx, mzd_dbatch *db)
     (void)hipFree(db->d_bframes);
     (void)hipFree(db->d_fixdone);
     (void)hipFree(db->d_walk);
+    (void)hipFree(db->d_frame_hist);
     (void)hipFree(db->d_planes);
     (void)hipFree(db->d_pat);
     free_parse_temps(db->tmp);
@@ -567,6 +570,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     mzd_batch_stats st{};
     auto in_range = [&](uint64_t off, uint64_t n) { return off <= b->in_size && n <= b->in_size - off; };
     std::vector<uint32_t> frame_seq_task(b->n_frames + 1, 0);
+    bool has_chunks = false;
     std::vector<uint64_t> frame_in_lo(b->n_frames, ~0ull), frame_in_hi(b->n_frames, 0);
     for (uint32_t f = 0; f < b->n_frames; f++) {
         frame_seq_task[f] = (uint32_t)seq_tasks.size();
@@ -580,7 +584,23 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
         df.plan_status = MZD_OK;
         df.checksum = fd.checksum;
         df.has_checksum = (fd.flags & MZD_FRAME_HAS_CHECKSUM) ? 1 : 0;
+        // a chunk of a frame (ABI 9): its slab begins with `start` bytes of the frame's window
+        const bool continues = (fd.flags & MZD_FRAME_CONTINUES) != 0;
+        df.continues = continues ? 1u : 0u;
+        df.start = continues ? fd.start : 0;
+        df.hist[0] = continues ? fd.hist[0] : 1;
+        df.hist[1] = continues ? fd.hist[1] : 4;
+        df.hist[2] = continues ? fd.hist[2] : 8;
         df.pad = 0;
+        if (continues) {
+            has_chunks = true;
+            // (positions in a slab are 32-bit for the kernels that take chunks; a history of positive offsets is what every block leaves)
+            if (fd.start > fd.out_capacity || fd.out_capacity >= (1ull << 32) - 65536 || fd.hist[0] <= 0 || fd.hist[1] <= 0 || fd.hist[2] <= 0) {
+                df.plan_status = MZD_ERR_INVALID_ARG;
+                df.n_blocks = 0;
+                continue;
+            }
+        }
         if ((uint64_t)fd.first_block + fd.n_blocks > b->n_blocks || (fd.out_offset & 15) ||
             fd.out_offset > b->out_size || fd.out_capacity > b->out_size - fd.out_offset) {
             df.plan_status = MZD_ERR_INVALID_ARG;
@@ -593,12 +613,12 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
             continue;
         }
         st.out_capacity_bytes += fd.out_capacity;
-        bool seen_seq = false;
+        bool seen_seq = continues;  // (a chunk's first block with sequences starts from the history it was handed, not from {1, 4, 8})
         uint64_t in_lo = ~0ull, in_hi = 0;
         // where the block's output starts in the frame, as long as every earlier block's regenerated size is known
         // without decoding (Raw / RLE blocks, compressed blocks without sequences: their output IS their literals)
         bool pos_known = true;
-        uint64_t out_pos = 0;
+        uint64_t out_pos = df.start;
         for (uint32_t k = 0; k < fd.n_blocks && df.plan_status == MZD_OK; k++) {
             const uint32_t bi = fd.first_block + k;
             const mzd_block_desc &bd = b->blocks[bi];
@@ -750,6 +770,7 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     db->n_blocks = b->n_blocks;
     db->n_huf_tasks = (uint32_t)huf_tasks.size();
     db->n_seq_tasks = (uint32_t)seq_tasks.size();
+    db->has_chunks = has_chunks;
     for (int k = 0; k < 3; k++) db->seq_cells[k] = 1u << std::min<uint32_t>(seq_logs[k], k == 2 ? 8u : 9u);
     db->huf_slot_cells = 1u << max_huf_bits;
     db->seq_sorted = seq_sorted;
@@ -922,6 +943,13 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
     HIP_OR_FAIL(hipMalloc((void **)&db->d_status, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
     HIP_OR_FAIL(hipMalloc((void **)&db->d_out_len, std::max<size_t>(b->n_frames, 1) * sizeof(uint64_t)));
     HIP_OR_FAIL(hipMemset(db->d_status, 0xFF, std::max<size_t>(b->n_frames, 1) * sizeof(int32_t)));
+    if (db->has_chunks) {
+        // (a batch without sequences launches nothing that writes it: it holds the frames' own history from the start)
+        std::vector<int32_t> h(3 * (size_t)b->n_frames);
+        for (uint32_t f = 0; f < b->n_frames; f++)
+            for (int k = 0; k < 3; k++) h[3 * (size_t)f + k] = frames[f].hist[k];
+        TRY_OR_FAIL(upload_vec(ctx, h, &db->d_frame_hist));
+    }
     HIP_OR_FAIL(hipMemset(db->d_out_len, 0, std::max<size_t>(b->n_frames, 1) * sizeof(uint64_t)));
 #undef TRY_OR_FAIL
 #undef HIP_OR_FAIL
@@ -1645,6 +1673,14 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
     // (both keep frame positions in 32 bits: a frame of 4 GiB or more -- also under a forced variant -- takes k_exec)
     for (uint32_t f = 0; (exec_c || exec_b) && f < db->n_frames; f++)
         if (db->frame_out_cap[f] >= (1ull << 32) - 65536) exec_c = exec_b = false;
+    if (db->has_chunks) {
+        // chunks of frames (ABI 9): k_exec_c and block mode with its passes know what a slab that begins with the frame's window is
+        if (ctx->opt.exec_variant != 0 && ctx->opt.exec_variant != 4 && ctx->opt.exec_variant != 5) {
+            ctx->last_error = "a batch with a chunk of a frame (MZD_FRAME_CONTINUES) takes exec_variant 0, 4 or 5";
+            return MZD_ERR_UNSUPPORTED;
+        }
+        exec_c = true;  // (also without sequences: blocks of literals only)
+    }
     const bool exec_b_serial = exec_b;  // the choice without block mode
     // k_exec_b takes opt.exec_chunk as EXTRA dynamic LDS on top of its 7.7 KiB (a residency cap), k_exec as its LDS chunk: a value that
     // suits k_exec (up to 128 KiB) must not make the k_exec_b launch fail -- clamped to what the default 64 KiB limit leaves
@@ -1726,7 +1762,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             (void)hipGetLastError();
             blk = false;
             exec_b = exec_b_serial || ctx->opt.exec_variant >= 3;
-            exec_c = ctx->opt.exec_variant == 0;
+            exec_c = ctx->opt.exec_variant == 0 || db->has_chunks;
         }
     }
     const bool serial = db->seq_sorted || db->huf_sorted || db->d_frame_order != nullptr || blk;
@@ -1886,7 +1922,8 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             const uint64_t stride = (db->out_size + 255) & ~(uint64_t)255, pstride = (blk_maxcap + 64 + 255) & ~(uint64_t)255;
             (void)hipMemsetAsync(db->d_heads, 0, 4, st);
             (void)hipMemsetAsync(db->d_walk, 0, 4, st);
-            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads, db->d_walk);
+            k_blk_scan<<<db->n_frames, 64, 0, st>>>(db->d_frames, db->d_blocks, db->d_sums, db->d_jobs, db->d_bframes, blk_gs, db->d_heads, db->d_walk,
+                                                    db->d_frame_hist);
             if (db->pat_n != (uint32_t)(blk_maxcap + 64) || db->pat_np != blk_np) {
                 k_blk_pattern<<<(uint32_t)((blk_maxcap + 64 + 1023) / 1024), 256, 0, st>>>(db->d_pat, pstride, (uint32_t)(blk_maxcap + 64), blk_np);
                 db->pat_n = (uint32_t)(blk_maxcap + 64);
@@ -1904,7 +1941,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             if (fused) {
                 const XbBlk bk{db->d_jobs, db->d_heads, db->d_bframes, db->d_pat, 0u, blk_np, pstride, stride, db->d_planes};
                 k_exec_c<true, 8192><<<db->n_blocks * blk_np, 64, 0, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
-                                                                  db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk);
+                                                                  db->d_litbuf, db->d_status, db->d_out_len, nullptr, 0u, bk, nullptr);
             }
             for (uint32_t p = 0; p < (fused ? 0u : blk_np); p++) {
                 uint8_t *plane = p == 0 ? db->d_out : db->d_planes + (size_t)(p - 1) * stride;
@@ -1912,7 +1949,7 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
                 // (as many wavefronts as blocks: the ones beyond the job list exit)
                 if (blk_xc)
                     k_exec_c<true, 8192><<<db->n_blocks, 64, 0, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
-                                                             db->d_status, db->d_out_len, nullptr, 0u, bk);
+                                                             db->d_status, db->d_out_len, nullptr, 0u, bk, nullptr);
 #ifdef MZD_TEST_KERNELS
                 else
                     k_exec_b<true><<<db->n_blocks, 64, xb_extra_lds, st>>>(db->d_in, plane, db->d_frames, db->d_blocks, db->d_sums, db->d_recs,
@@ -1977,10 +2014,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
             if (const char *e = exp_env("MZD_EXP_XC_WIN")) win8 = atoi(e) == 8192;
             if (win8)
                 k_exec_c<false, 8192><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
-                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
+                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{}, db->d_frame_hist);
             else
                 k_exec_c<false, 4096><<<count, 64, xc_extra_lds, st>>>(db->d_in, db->d_out, db->d_frames, db->d_blocks, db->d_sums, db->d_recs, db->d_litbuf,
-                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{});
+                                                                     db->d_status, db->d_out_len, db->d_frame_order, first, XbBlk{}, db->d_frame_hist);
             return;
         }
 #ifdef MZD_TEST_KERNELS
@@ -2584,6 +2621,133 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
     st->n_huf_built = db->n_huf_built;
     st->fse_build_ms = db->fse_build_ms;
     st->parse_ms = db->parse_ms;
+    return MZD_OK;
+}
+
+// ---- one frame in chunks (ABI 9; include/mzd.h): the cursor (planner.cpp) + the window and the offset history kept on the device.
+// Two slabs of (window + chunk) bytes.  A chunk is decoded into the slab whose beginning holds the bytes the frame regenerated
+// before it (`keep` of them: all, until there are more than the window); its own bytes go to the caller; when slab and window no
+// longer hold what is there, the last window_size bytes move to the other slab's beginning (ringbuffer.go:36-49 keeps as much).
+struct mzd_fstream {
+    mzd_ctx *ctx = nullptr;
+    mzd_cursor *cur = nullptr;
+    uint64_t chunk_out = 0;
+    uint8_t *slab[2] = {nullptr, nullptr};
+    uint64_t slab_bytes = 0;
+    int at = 0;         // the slab in use
+    uint64_t keep = 0;  // bytes of the frame at its beginning
+    uint64_t window = 0;
+    int32_t hist[3] = {1, 4, 8};  // framedecompressor.go:48,59
+    uint64_t total = 0;
+    bool sized = false, done = false;
+    int status = MZD_OK;
+};
+
+int mzd_fstream_open(mzd_ctx *ctx, uint64_t chunk_out, mzd_fstream **out)
+{
+    if (!ctx || !out) return MZD_ERR_INVALID_ARG;
+    *out = nullptr;
+    mzd_fstream *fs = new mzd_fstream();
+    fs->ctx = ctx;
+    fs->cur = mzd_cursor_create();
+    fs->chunk_out = std::max<uint64_t>(chunk_out ? chunk_out : (64ull << 20), kBlockMax);
+    *out = fs;
+    return MZD_OK;
+}
+
+void mzd_fstream_close(mzd_fstream *fs)
+{
+    if (!fs) return;
+    if (fs->ctx) (void)hipSetDevice(fs->ctx->device);
+    (void)hipFree(fs->slab[0]);
+    (void)hipFree(fs->slab[1]);
+    mzd_cursor_destroy(fs->cur);
+    delete fs;
+}
+
+uint64_t mzd_fstream_total_out(const mzd_fstream *fs) { return fs ? fs->total : 0; }
+const mzd_cursor *mzd_fstream_cursor(const mzd_fstream *fs) { return fs ? fs->cur : nullptr; }
+
+int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t *dst, uint64_t dst_cap, uint64_t *consumed,
+                     uint64_t *produced, int *done)
+{
+    if (!fs || (!src && len) || !dst || !consumed || !produced || dst_cap < kBlockMax) return MZD_ERR_INVALID_ARG;
+    *consumed = *produced = 0;
+    if (done) *done = fs->done ? 1 : 0;
+    if (fs->status) return fs->status;
+    if (fs->done) return MZD_ERR_OUT_OF_BLOCKS;  // framedecompressor.go:196
+    mzd_ctx *ctx = fs->ctx;
+    const uint64_t max_out = std::min(fs->chunk_out, dst_cap);
+    const mzd_batch *chunk = nullptr;
+    int last = 0;
+    int rc = mzd_cursor_next(fs->cur, src, len, max_out, fs->keep, fs->hist, consumed, &chunk, &last);
+    if (rc) return fs->status = rc;
+    if (!chunk) return MZD_OK;  // no whole block in src yet
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!fs->sized) {
+        fs->window = mzd_cursor_window(fs->cur);
+        // (a slab's positions are 32-bit and block mode takes slabs below 2 GiB)
+        if (fs->window > (1ull << 31) - fs->chunk_out - (1ull << 20)) {
+            ctx->last_error = "mzd_fstream: the frame's window and a chunk do not fit a slab of 2 GiB";
+            return fs->status = MZD_ERR_UNSUPPORTED;
+        }
+        fs->slab_bytes = ((fs->window + 255) & ~255ull) + fs->chunk_out + 1024;
+        for (int k = 0; k < 2; k++) {
+            const hipError_t e = hipMalloc((void **)&fs->slab[k], fs->slab_bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->last_error = std::string("mzd_fstream: hipMalloc of a slab failed: ") + hipGetErrorString(e);
+                return fs->status = MZD_ERR_DEVICE;
+            }
+        }
+        fs->sized = true;
+    }
+    mzd_batch b = *chunk;
+    b.out = fs->slab[fs->at];
+    b.out_size = fs->slab_bytes;
+    b.flags |= MZD_BATCH_OUT_ON_DEVICE;
+    mzd_dbatch *db = nullptr;
+    rc = mzd_batch_upload(ctx, &b, &db);
+    if (rc) return fs->status = rc;
+    rc = mzd_batch_run(ctx, db, nullptr);
+    int32_t st = MZD_OK;
+    uint64_t olen = 0;
+    if (rc == MZD_OK) rc = mzd_batch_download(ctx, db, nullptr, &st, &olen);
+    if (rc == MZD_OK && st) rc = st;
+    if (rc == MZD_OK && (olen < fs->keep || olen - fs->keep > dst_cap)) rc = MZD_ERR_DST_FULL;
+    uint64_t n = 0;
+    if (rc == MZD_OK) {
+        n = olen - fs->keep;
+        rc = mzd_batch_read_out(ctx, db, fs->keep, dst, n);
+    }
+    if (rc == MZD_OK && db->d_frame_hist) {
+        const hipError_t e = hipMemcpy(fs->hist, db->d_frame_hist, sizeof(fs->hist), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("mzd_fstream: reading the offset history failed: ") + hipGetErrorString(e);
+            rc = MZD_ERR_DEVICE;
+        }
+    }
+    mzd_batch_free(ctx, db);
+    if (rc) return fs->status = rc;
+    fs->total += n;
+    *produced = n;
+    if (last) {
+        fs->done = true;
+        if (done) *done = 1;
+        const uint64_t content = mzd_cursor_content_size(fs->cur);
+        if (content != MZD_UNKNOWN_SIZE && content != fs->total) return fs->status = MZD_ERR_DST_FULL;
+        return MZD_OK;
+    }
+    // what the next chunk finds in front of it
+    const uint64_t have = fs->keep + n;
+    if (have <= fs->window && ((have + 255) & ~255ull) + fs->chunk_out + 1024 <= fs->slab_bytes) {
+        fs->keep = have;  // (the frame so far is within its window and the slab has room behind it: it stays where it is)
+    } else {
+        const uint64_t nk = std::min(fs->window, have);
+        if (nk) HIP_TRY(ctx, hipMemcpy(fs->slab[fs->at ^ 1], fs->slab[fs->at] + (have - nk), nk, hipMemcpyDeviceToDevice));
+        fs->at ^= 1;
+        fs->keep = nk;
+    }
     return MZD_OK;
 }
 

@@ -27,7 +27,7 @@ namespace mzd {
 // ---- scan: a wavefront per frame, 64 blocks per round (their summaries loaded side by side, then walked in order)
 __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ frames, const DBlock *__restrict__ blocks,
                                                  const BlockSum *__restrict__ sums, BJob *__restrict__ jobs, BFrame *__restrict__ bframes,
-                                                 uint32_t gs, uint32_t *__restrict__ heads, uint32_t *__restrict__ walk)
+                                                 uint32_t gs, uint32_t *__restrict__ heads, uint32_t *__restrict__ walk, int32_t *frame_hist)
 {
     // heads: [0] a counter (zero at launch), [1 ...] the blocks where a job starts, in no particular order
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
@@ -35,6 +35,12 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
     int error = fr.plan_status;
     uint64_t outPos = 0;
     int H0 = 1, H1 = 4, H2 = 8;  // framedecompressor.go:48,59
+    if (fr.continues) {  // a chunk of a frame: behind the window bytes its slab begins with, with the history of the blocks before
+        outPos = fr.start;
+        H0 = fr.hist[0];
+        H1 = fr.hist[1];
+        H2 = fr.hist[2];
+    }
     uint32_t n_ok = error == MZD_OK ? fr.n_blocks : 0u;
     bool prev_direct = true;  // (the block before the frame's first: a job starts there anyway)
     uint32_t reach = 0;       // the largest offset code of the frame's blocks (BlockSum::reach; ~0 when the sequence kernel does not say)
@@ -181,6 +187,11 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
         bf.high = reach > (1u << 23) ? 1u : 0u;
         bf.pad = 0;
         bframes[f] = bf;
+        if (frame_hist) {  // the history behind the frame's last good block: what the next chunk starts with
+            frame_hist[3 * f] = H0;
+            frame_hist[3 * f + 1] = H1;
+            frame_hist[3 * f + 2] = H2;
+        }
     }
 }
 

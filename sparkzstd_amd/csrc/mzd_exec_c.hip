@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
                                                   const DBlock *__restrict__ blocks, const BlockSum *__restrict__ sums,
                                                   const uint64_t *__restrict__ recs, const uint8_t *__restrict__ litbuf,
                                                   int32_t *frame_status, uint64_t *frame_out_len,
-                                                  const uint32_t *__restrict__ order, uint32_t first, XbBlk bk)
+                                                  const uint32_t *__restrict__ order, uint32_t first, XbBlk bk, int32_t *frame_hist)
 {
     constexpr uint32_t kXcWin = WIN;
     constexpr int kXcNear = (int)WIN - (int)kXcPass;  // a window match this close to its pass is served by the ring
@@ -242,8 +242,10 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
         // the pass of the position's high bits is for frames whose matches may reach back 8 MiB or more (k_blk_scan)
         if (bk.pass == 3 && !bk.bframes[fidx].high) return;
     }
-    const uint32_t S = BM ? jb.start : 0u;  // the segment's first byte (block mode)
-    const uint8_t *const pat = bk.pat;
+    // the segment's first byte (block mode); a chunk of a frame starts behind the window bytes its slab begins with (DFrame::start)
+    const uint32_t S = BM ? jb.start : (fr.continues ? (uint32_t)fr.start : 0u);
+    // (block mode: what lies before a chunk's FIRST job is not a pattern but those bytes themselves, the same in every pass)
+    const uint8_t *const pat = BM && bi0 == 0 && fr.continues ? (const uint8_t *)out : bk.pat;
 
     int error = BM ? (int)MZD_OK : fr.plan_status;
     uint32_t outPos = S;         // bytes of this frame produced so far (frames of 4 GiB and more take k_exec)
@@ -254,6 +256,10 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
         H0 = jb.H0;
         H1 = jb.H1;
         H2 = jb.H2;
+    } else if (fr.continues) {
+        H0 = fr.hist[0];
+        H1 = fr.hist[1];
+        H2 = fr.hist[2];
     }
     // LDS addresses of the areas the predicated stores go to (the kernel's only shared object: its offset is what the
     // compiler assigned, normally 0; the region arithmetic below is relative to it)
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
     for (int i = lane; i < 132; i += 64) sh.table[i] = 0u;
     if (lane < (int)(kXcStretch / 32)) sh.bits[lane] = 0u;
     if (BM && S > 0 && !(jb.flags & kBjDirect)) xc_reload_window<WIN>(sh.win, pat, S, lane);  // the ring's view of the frame before the segment
+    if (!BM && S > 0) xc_reload_window<WIN>(sh.win, out, S, lane);                              // ... before the chunk
     uint32_t bi = bi0;
     // constants of the passes, in VGPRs (a vector instruction with a literal or scalar operand issues at half rate)
     uint32_t vwmask = kXcWin - 1;
@@ -763,6 +770,11 @@ __global__ __launch_bounds__(64, WIN == 4096 ? 5 : 4) void k_exec_c(const uint8_
         if (e == MZD_OK && fr.content_size != MZD_UNKNOWN_SIZE && outPos != fr.content_size) e = MZD_ERR_DST_FULL;
         frame_status[fidx] = e;
         frame_out_len[fidx] = outPos;
+        if (frame_hist) {  // (batches with a chunk of a frame in them: what the next chunk starts with)
+            frame_hist[3 * fidx] = H0;
+            frame_hist[3 * fidx + 1] = H1;
+            frame_hist[3 * fidx + 2] = H2;
+        }
     }
 }
 
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(256) void k_copy_blocks(const uint8_t *__restrict__
     const DFrame fr = frames[fidx];
     uint8_t *out = out_blob + fr.out_offset;
     int error = fr.plan_status;
-    uint64_t outPos = 0;
+    uint64_t outPos = fr.continues ? fr.start : 0;
     for (uint32_t bi = 0; bi < fr.n_blocks && error == MZD_OK; bi++) {
         const DBlock b = blocks[fr.first_block + bi];
         if (b.type == MZD_BLOCK_COMPRESSED) {  // (not in such a batch; a frame that has one is not this kernel's)

@@ -495,27 +495,19 @@ struct FrameParser {
         return MZD_OK;
     }
 
-    void run()
+    // magic + frame header (framedecompressor.go:130-150,306-374; frame.go) at p; p ends behind it
+    int parse_header(uint64_t &p, uint8_t &fhd)
     {
-        out.src_begin = begin;
-        uint64_t p = begin;
-        auto fail = [&](int code) {
-            out.status = code;
-            out.blocks.clear();
-            out.consumed = p - begin;
-        };
-        // magic + frame header (framedecompressor.go:130-150,306-374; frame.go)
-        if (end - p < 5) return fail(MZD_ERR_TRUNCATED);
-        if (!(base[p] == 0x28 && base[p + 1] == 0xB5 && base[p + 2] == 0x2F && base[p + 3] == 0xFD))
-            return fail(MZD_ERR_MAGIC);
-        const uint8_t fhd = base[p + 4];
+        if (end - p < 5) return MZD_ERR_TRUNCATED;
+        if (!(base[p] == 0x28 && base[p + 1] == 0xB5 && base[p + 2] == 0x2F && base[p + 3] == 0xFD)) return MZD_ERR_MAGIC;
+        fhd = base[p + 4];
         p += 5;
         const bool single = (fhd >> 5) & 1;
         static const int kDict[4] = {0, 1, 2, 4};
         const int dict_bytes = kDict[fhd & 3];
         const int fcs_flag = fhd >> 6;
         const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
-        if (end - p < (uint64_t)(!single) + dict_bytes + fcs_bytes) return fail(MZD_ERR_TRUNCATED);
+        if (end - p < (uint64_t)(!single) + dict_bytes + fcs_bytes) return MZD_ERR_TRUNCATED;
         if (!single) {
             const uint8_t wd = base[p++];
             const uint64_t wbase = 1ull << (10 + (wd >> 3));
@@ -530,41 +522,60 @@ struct FrameParser {
             p += fcs_bytes;
             if (single) out.window_size = v;
         }
-        // blocks (block.go:33-55, framedecompressor.go:198-303)
+        return MZD_OK;
+    }
+
+    // one block (block.go:33-55, framedecompressor.go:198-303) at p: appended to out.blocks, p ends behind it
+    int parse_block(uint64_t &p, bool &last, uint64_t &bound)
+    {
+        if (end - p < 3) return MZD_ERR_TRUNCATED;
+        const uint32_t h = base[p] | ((uint32_t)base[p + 1] << 8) | ((uint32_t)base[p + 2] << 16);
+        p += 3;
+        last = h & 1;
+        const int type = (h >> 1) & 3;
+        const uint32_t size = h >> 3;
+        if (type == 3) return MZD_ERR_BLOCK_TYPE;
+        if (size > kBlockMax) return MZD_ERR_BLOCK_SIZE;
+        mzd_block_desc bd{};
+        bd.type = (uint8_t)type;
+        bd.size = size;
+        bd.huf_table = bd.ll_table = bd.of_table = bd.ml_table = MZD_NO_TABLE;
+        if (type == MZD_BLOCK_RAW) {
+            if (end - p < size) return MZD_ERR_TRUNCATED;
+            bd.src_off = p;
+            p += size;
+            bound += size;
+        } else if (type == MZD_BLOCK_RLE) {
+            if (end - p < 1) return MZD_ERR_TRUNCATED;
+            bd.src_off = p;
+            p += 1;
+            bound += size;
+        } else {
+            if (end - p < size) return MZD_ERR_TRUNCATED;
+            int rc = parse_compressed_block(p, size, bd);
+            if (rc) return rc;
+            p += size;
+            bound += kBlockMax;
+        }
+        out.blocks.push_back(bd);
+        return MZD_OK;
+    }
+
+    void run()
+    {
+        out.src_begin = begin;
+        uint64_t p = begin;
+        auto fail = [&](int code) {
+            out.status = code;
+            out.blocks.clear();
+            out.consumed = p - begin;
+        };
+        uint8_t fhd = 0;
+        if (int rc = parse_header(p, fhd)) return fail(rc);
         bool last = false;
         uint64_t bound = 0;
-        while (!last) {
-            if (end - p < 3) return fail(MZD_ERR_TRUNCATED);
-            const uint32_t h = base[p] | ((uint32_t)base[p + 1] << 8) | ((uint32_t)base[p + 2] << 16);
-            p += 3;
-            last = h & 1;
-            const int type = (h >> 1) & 3;
-            const uint32_t size = h >> 3;
-            if (type == 3) return fail(MZD_ERR_BLOCK_TYPE);
-            if (size > kBlockMax) return fail(MZD_ERR_BLOCK_SIZE);
-            mzd_block_desc bd{};
-            bd.type = (uint8_t)type;
-            bd.size = size;
-            bd.huf_table = bd.ll_table = bd.of_table = bd.ml_table = MZD_NO_TABLE;
-            if (type == MZD_BLOCK_RAW) {
-                if (end - p < size) return fail(MZD_ERR_TRUNCATED);
-                bd.src_off = p;
-                p += size;
-                bound += size;
-            } else if (type == MZD_BLOCK_RLE) {
-                if (end - p < 1) return fail(MZD_ERR_TRUNCATED);
-                bd.src_off = p;
-                p += 1;
-                bound += size;
-            } else {
-                if (end - p < size) return fail(MZD_ERR_TRUNCATED);
-                int rc = parse_compressed_block(p, size, bd);
-                if (rc) return fail(rc);
-                p += size;
-                bound += kBlockMax;
-            }
-            out.blocks.push_back(bd);
-        }
+        while (!last)
+            if (int rc = parse_block(p, last, bound)) return fail(rc);
         out.consumed = p - begin;
         // the content checksum is not part of what the reference consumes (framereader.go:84-94); it is
         // recorded for the optional device-side verification
@@ -661,6 +672,52 @@ struct mzd_plan {
         frame_bound.push_back(fp.status ? 0 : fp.out_bound);
     }
 };
+
+// ---- one frame in CHUNKS of whole blocks (ABI 9).  The reference decodes a frame block by block into a ring of the frame's window
+// size and hands the bytes on as they come (framedecompressor.go:198-303, ringbuffer.go:36-49, framereader.go:51-109); what carries
+// from a block to the next is the window, the offset history (framedecompressor.go:23) and the tables last used
+// (framedecompressor.go:283-294).  The cursor is the host's part of that: it walks the frame's blocks as their bytes arrive and cuts
+// them into batches of ONE frame description each -- a chunk -- whose tables include the ones in force at its start.  The window and
+// the history are the device's part (mzd_frame_desc.start / .hist, MZD_FRAME_CONTINUES; mzd_fstream_* in mzd_api.hip).
+struct mzd_cursor {
+    mzd_plan plan;    // the current chunk's batch
+    FramePart carry;  // the tables in force behind the last chunk: what Repeat / Treeless of the next one refer to
+    uint32_t prev_huf = MZD_NO_TABLE, prev_ll = MZD_NO_TABLE, prev_of = MZD_NO_TABLE, prev_ml = MZD_NO_TABLE;  // indices into carry, kPredef*, or none
+    bool header_done = false, last_done = false, has_checksum = false, checksum_seen = false;
+    uint64_t window = 0, content = MZD_UNKNOWN_SIZE, blocks_done = 0, bound_done = 0;
+    uint32_t checksum = 0;
+    int status = MZD_OK;
+};
+
+namespace {
+
+// the table `idx` of `from` appended to `to`; -> its index there (sentinels pass through)
+uint32_t carry_fse(const FramePart &from, uint32_t idx, FramePart &to)
+{
+    if (idx == MZD_NO_TABLE || idx >= kPredefLL) return idx;
+    mzd_fse_table_desc d = from.fse_tables[idx];
+    const uint32_t n = 1u << d.acc_log;
+    const uint32_t off = d.entries_off;
+    d.entries_off = (uint32_t)to.fse_entries.size();
+    to.fse_entries.insert(to.fse_entries.end(), from.fse_entries.begin() + off, from.fse_entries.begin() + off + n);
+    to.fse_tables.push_back(d);
+    return (uint32_t)to.fse_tables.size() - 1;
+}
+
+uint32_t carry_huf(const FramePart &from, uint32_t idx, FramePart &to)
+{
+    if (idx == MZD_NO_TABLE) return idx;
+    mzd_huf_table_desc d = from.huf_tables[idx];
+    const uint32_t n = 1u << (d.max_bits & 0xFFu);
+    const uint32_t off = d.entries_off;
+    if (to.huf_entries.size() & 1) to.huf_entries.push_back(mzd_huf_entry{0, 0});
+    d.entries_off = (uint32_t)to.huf_entries.size();
+    to.huf_entries.insert(to.huf_entries.end(), from.huf_entries.begin() + off, from.huf_entries.begin() + off + n);
+    to.huf_tables.push_back(d);
+    return (uint32_t)to.huf_tables.size() - 1;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -835,6 +892,100 @@ int mzd_split_frames(const uint8_t *blob, uint64_t size, uint64_t *frame_off, ui
     *n_frames = n;  // frames found before the end / the defect; more than `cap`: call again with larger arrays
     if (out_total) *out_total = total;
     return rc;
+}
+
+// ---- the cursor's C entry points (include/mzd.h)
+mzd_cursor *mzd_cursor_create(void) { return new mzd_cursor(); }
+void mzd_cursor_destroy(mzd_cursor *c) { delete c; }
+
+int mzd_cursor_next(mzd_cursor *c, const uint8_t *src, uint64_t len, uint64_t max_out, uint64_t start, const int32_t hist[3],
+                    uint64_t *consumed, const mzd_batch **chunk, int *last_out)
+{
+    if (!c || (!src && len) || !consumed || !chunk) return MZD_ERR_INVALID_ARG;
+    *consumed = 0;
+    *chunk = nullptr;
+    if (last_out) *last_out = 0;
+    if (c->status) return c->status;
+    if (c->last_done) return MZD_ERR_OUT_OF_BLOCKS;  // framedecompressor.go:196
+    uint64_t p = 0;
+    FramePart part;
+    FrameParser fp(src, 0, len, part, false);
+    if (!c->header_done) {
+        uint8_t fhd = 0;
+        const int rc = fp.parse_header(p, fhd);
+        if (rc == MZD_ERR_TRUNCATED) return MZD_OK;  // not all of the header yet (at most 18 bytes): nothing consumed
+        if (rc) return c->status = rc;
+        c->header_done = true;
+        c->window = part.window_size;
+        c->content = part.content_size;
+        c->has_checksum = (fhd >> 2) & 1;
+    }
+    // the tables in force at the chunk's start come first in its batch
+    fp.prev_ll = carry_fse(c->carry, c->prev_ll, part);
+    fp.prev_of = carry_fse(c->carry, c->prev_of, part);
+    fp.prev_ml = carry_fse(c->carry, c->prev_ml, part);
+    fp.prev_huf = carry_huf(c->carry, c->prev_huf, part);
+    bool last = false;
+    uint64_t bound = 0;
+    while (!last) {
+        // the next block, if all of it is here and the chunk has room for what it can regenerate (a chunk takes one block at least)
+        if (len - p < 3) break;
+        const uint32_t h = src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+        const int type = (h >> 1) & 3;
+        const uint32_t size = h >> 3;
+        if (type != 3 && size <= kBlockMax) {
+            if (len - p - 3 < (type == MZD_BLOCK_RLE ? 1u : size)) break;
+            if (!part.blocks.empty() && bound + (type == MZD_BLOCK_COMPRESSED ? kBlockMax : size) > max_out) break;
+        }
+        const int rc = fp.parse_block(p, last, bound);
+        if (rc) return c->status = rc;
+    }
+    *consumed = p;
+    if (part.blocks.empty()) return MZD_OK;  // (the header at most: the caller comes back with more bytes)
+    if (last) {
+        c->last_done = true;
+        if (c->has_checksum && len - p >= 4) {  // recorded, not consumed (framereader.go:84-94)
+            c->checksum = src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16) | ((uint32_t)src[p + 3] << 24);
+            c->checksum_seen = true;
+        }
+    }
+    // what the next chunk's Repeat / Treeless blocks will mean
+    {
+        FramePart nc;
+        c->prev_ll = carry_fse(part, fp.prev_ll, nc);
+        c->prev_of = carry_fse(part, fp.prev_of, nc);
+        c->prev_ml = carry_fse(part, fp.prev_ml, nc);
+        c->prev_huf = carry_huf(part, fp.prev_huf, nc);
+        c->carry = std::move(nc);
+    }
+    c->blocks_done += part.blocks.size();
+    c->bound_done += bound;
+    part.window_size = c->window;
+    part.content_size = MZD_UNKNOWN_SIZE;  // (of the whole frame: the caller checks it at the frame's end)
+    part.out_bound = start + bound;
+    part.consumed = p;
+    c->plan = mzd_plan();
+    c->plan.ext_blob = src;
+    c->plan.ext_size = p;
+    c->plan.merge(part, 0);
+    mzd_frame_desc &fd = c->plan.frames[0];
+    fd.start = start;
+    fd.flags |= MZD_FRAME_CONTINUES;  // (the frame's first chunk too: the library then reports the history behind it)
+    fd.hist[0] = hist ? hist[0] : 1;
+    fd.hist[1] = hist ? hist[1] : 4;
+    fd.hist[2] = hist ? hist[2] : 8;
+    *chunk = mzd_plan_finalize(&c->plan);
+    if (last_out) *last_out = last ? 1 : 0;
+    return MZD_OK;
+}
+
+uint64_t mzd_cursor_window(const mzd_cursor *c) { return c && c->header_done ? c->window : 0; }
+uint64_t mzd_cursor_content_size(const mzd_cursor *c) { return c && c->header_done ? c->content : MZD_UNKNOWN_SIZE; }
+int mzd_cursor_checksum(const mzd_cursor *c, uint32_t *checksum)
+{
+    if (!c || !c->checksum_seen) return 0;
+    if (checksum) *checksum = c->checksum;
+    return 1;
 }
 
 }  // extern "C"

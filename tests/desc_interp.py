@@ -54,13 +54,21 @@ def huf_decode(cells, max_bits, data, want):
     return bytes(out)
 
 
-def run_batch(batch, blob: bytes):
-    """-> list of output bytes per frame"""
+def run_batch(batch, blob: bytes, prefixes=None, hists_out=None):
+    """-> list of output bytes per frame.  A frame description that is a CHUNK of a frame (MZD_FRAME_CONTINUES, ABI 9) starts behind
+    `prefixes[f]` -- the `start` bytes its slab begins with -- from the history it names; what is returned is the chunk's own bytes.
+    hists_out: a list that receives the offset history behind every frame's last block."""
     outs = []
     for f in range(batch.n_frames):
         fd = batch.frames[f]
         out = bytearray()
         hist = [1, 4, 8]
+        start = 0
+        if fd.flags & 2:
+            out += prefixes[f]
+            assert len(out) == fd.start, (len(out), fd.start)
+            start = fd.start
+            hist = list(fd.hist)
         for bi in range(fd.first_block, fd.first_block + fd.n_blocks):
             b = batch.blocks[bi]
             if b.type == 0:
@@ -140,5 +148,7 @@ def run_batch(batch, blob: bytes):
                 if rb.cursor != -1:
                     raise ValueError("sequence bits left over")
             out += lits[lit_pos:]
-        outs.append(bytes(out))
+        outs.append(bytes(out[start:]))
+        if hists_out is not None:
+            hists_out.append(hist)
     return outs

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_struct_layouts_match_header():
     # sizes the header implies (natural alignment, little endian)
-    assert ctypes.sizeof(_lib.FrameDesc) == 48
+    assert ctypes.sizeof(_lib.FrameDesc) == 72 and _lib.FrameDesc.start.offset == 48 and _lib.FrameDesc.hist.offset == 56  # ABI 9
     assert ctypes.sizeof(_lib.BlockDesc) == 80
     assert ctypes.sizeof(_lib.FseEntry) == 4
     assert ctypes.sizeof(_lib.FseTableDesc) == 8
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
 
 def test_identity_and_errors():
     L = _lib.load()
-    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 8
+    assert L.mzd_abi_version() == _lib.MZD_ABI_VERSION == 9
     assert L.mzd_backend() == b"hip-gfx950"
     assert b"Magicnum" in L.mzd_strerror(2)
     assert L.mzd_device_count() >= 0

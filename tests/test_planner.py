@@ -298,3 +298,78 @@ def test_fse_table_with_a_symbol_beyond_its_kind_is_a_documented_limit(oracle):
         p = z.Plan(device_tables=dt)
         assert p.add_frame(f)[0] == 16
         p.close()
+
+
+def _chunked_on_cpu(comp: bytes, max_out: int, piece: int):
+    """The frame through the cursor, its source arriving `piece` bytes at a time, every chunk run by the descriptor interpreter behind
+    the window bytes of the chunks before it -- what mzd_fstream_next does with the device (mzd_api.hip), on the CPU.
+    -> (output, chunks, consumed)"""
+    cur = z.Cursor()
+    src = np.frombuffer(comp, dtype=np.uint8)
+    pos = have = 0
+    out = bytearray()
+    keep = b""
+    hist = [1, 4, 8]
+    chunks = 0
+    while True:
+        have = min(len(comp), have + piece)
+        rc, used, b, last = cur.next(src[pos:have], max_out, len(keep), hist)
+        assert rc == 0, rc
+        if b is None:
+            pos += used
+            assert have < len(comp), "the cursor wants bytes behind the frame's end"
+            continue
+        assert b.n_frames == 1 and b.frames[0].start == len(keep) and b.frames[0].flags & _lib.MZD_FRAME_CONTINUES
+        assert b.frames[0].out_capacity >= len(keep) and b.in_size == used
+        hs = []
+        got = run_batch(b, _blob_of(b), prefixes=[keep], hists_out=hs)[0]
+        assert len(got) <= max(max_out, 128 * 1024)
+        out += got
+        hist = hs[0]
+        pos += used
+        chunks += 1
+        w = cur.window
+        keep = bytes(out[max(0, len(out) - w):]) if w else b""
+        if last:
+            break
+    rc, used, b, last = cur.next(src[pos:], max_out, len(keep), hist)
+    assert rc == 17 and b is None  # MZD_ERR_OUT_OF_BLOCKS (framedecompressor.go:196)
+    cs = cur.content_size
+    assert cs == _lib.MZD_UNKNOWN_SIZE or cs == len(out)
+    cur.close()
+    return bytes(out), chunks, pos
+
+
+@pytest.mark.parametrize("max_out,piece", [(128 * 1024, 1 << 30), (128 * 1024, 777), (512 * 1024, 65536), (1 << 30, 1 << 30)])
+def test_cursor_chunks_regenerate_the_frames(corpus, max_out, piece):
+    """ABI 9, the host half of a frame in chunks: whatever the chunk size and however the source arrives, the chunks -- each with the
+    tables in force at its start (Repeat / Treeless across a chunk boundary: framedecompressor.go:283-294), the window bytes and the
+    offset history of the chunks before it -- regenerate the frame; everything up to the content checksum is consumed."""
+    small = [c for c in corpus if c[2] <= 300000]
+    picked = sorted(small, key=lambda c: -c[2])[:6] + small[:6]
+    many = 0
+    for name, comp, length, sha, exp in picked:
+        got, chunks, used = _chunked_on_cpu(comp, max_out, piece)
+        check_expected(name, got, length, sha, exp)
+        assert used == len(comp) - 4
+        many += chunks > 1
+    assert (many > 0) == (max_out < (1 << 30))
+
+
+def test_cursor_errors_stick_and_a_cut_frame_wants_more():
+    cur = z.Cursor()
+    rc, used, b, last = cur.next(np.frombuffer(b"\x28\xb5\x2f", dtype=np.uint8), 1 << 20)
+    assert (rc, used, b) == (0, 0, None)  # not all of the header yet
+    rc, used, b, last = cur.next(np.frombuffer(b"\x00\x00\x00\x00\x00\x00", dtype=np.uint8), 1 << 20)
+    assert rc == 2 and b is None  # MZD_ERR_MAGIC
+    assert cur.next(np.frombuffer(b"\x28\xb5\x2f\xfd\x20\x00\x01\x00\x00", dtype=np.uint8), 1 << 20)[0] == 2  # ... sticks
+    cur.close()
+    # a Raw block of 5 bytes, then the last (RLE) block -- handed over with its payload cut
+    frame = b"\x28\xb5\x2f\xfd\x00\x48" + b"\x28\x00\x00hello" + b"\x1b\x00\x00z"
+    cur = z.Cursor()
+    rc, used, b, last = cur.next(np.frombuffer(frame[:-1], dtype=np.uint8), 1 << 20)
+    assert rc == 0 and b is not None and b.n_blocks == 1 and not last and used == 6 + 8 and cur.window == 1 << 19
+    rc, used2, b, last = cur.next(np.frombuffer(frame[used:], dtype=np.uint8), 1 << 20, 5, [1, 4, 8])
+    assert rc == 0 and last and used2 == 4 and b.blocks[0].type == 1 and b.blocks[0].size == 3
+    assert b.frames[0].start == 5 and b.frames[0].flags & _lib.MZD_FRAME_CONTINUES and b.frames[0].out_capacity == 8
+    cur.close()
