@@ -15,6 +15,7 @@
 #include <istream>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <ostream>
 #include <stdexcept>
@@ -233,69 +234,31 @@ inline std::vector<std::vector<uint8_t>> DecodeFramesOn(const std::vector<int> &
     return res;
 }
 
-// NewFrameDecompressor(s io.Reader, t io.Writer) -- framedecompressor.go:55
-class FrameDecompressor {
-  public:
-    FrameDecompressor(std::istream *source, std::ostream *target, mzd_ctx *ctx = nullptr) : ctx_(ctx) { Reset(source, target); }
-    void Reset(std::istream *newsource, std::ostream *newtarget)  // framedecompressor.go:42-52
-    {
-        source_ = newsource;
-        target_ = newtarget;
-        done_ = false;
-        BlockCounter = 0;
-        head_.clear();
-    }
-    void CheckMagicnum()  // framedecompressor.go:130-150
-    {
-        char m[4];
-        source_->read(m, 4);
-        head_.assign(m, m + source_->gcount());
-        if (head_.size() < 4) throw Error(MZD_ERR_TRUNCATED, "CheckMagicnum");
-        static const unsigned char magic[4] = {0x28, 0xB5, 0x2F, 0xFD};
-        if (std::memcmp(head_.data(), magic, 4) != 0) throw Error(MZD_ERR_MAGIC, "CheckMagicnum");
-    }
-    // Decompress decompresses the whole frame and writes the whole output to the target (:153-170)
-    void Decompress()
-    {
-        if (done_) throw Error(MZD_ERR_OUT_OF_BLOCKS, "Decompress");
-        std::vector<uint8_t> frame(head_.begin(), head_.end());
-        frame.insert(frame.end(), std::istreambuf_iterator<char>(*source_), std::istreambuf_iterator<char>());
-        std::vector<int> st;
-        auto out = DecodeFrames({frame}, &st, ctx_);
-        if (st[0] != MZD_OK) throw Error(st[0], "Decompress");
-        target_->write(reinterpret_cast<const char *>(out[0].data()), (std::streamsize)out[0].size());
-        done_ = true;
-    }
-    // DecodeNextBlock (:198-244): all blocks of the frame come out of one device batch
-    void DecodeNextBlock()
-    {
-        if (done_) throw Error(MZD_ERR_OUT_OF_BLOCKS, "DecodeNextBlock");
-        Decompress();
-    }
-    bool Verbose = false;
-    int BlockCounter = 0;
-
-  private:
-    std::istream *source_ = nullptr;
-    std::ostream *target_ = nullptr;
-    mzd_ctx *ctx_ = nullptr;
-    std::vector<char> head_;
-    bool done_ = false;
-};
-
 // NewFrameReader(source io.Reader) -- framereader.go:17
 class FrameReader {
   public:
-    explicit FrameReader(std::istream *source = nullptr, mzd_ctx *ctx = nullptr) : ctx_(ctx)
+    // chunk_bytes > 0 (ABI 9): the frame goes through the device in CHUNKS of whole blocks that regenerate up to so many bytes each
+    // (mzd_fstream_*): the source is read piece by piece as the chunks need it, Read returns bytes as soon as the chunk that holds
+    // them is decoded, and the device keeps the frame's WINDOW between two chunks, not the frame -- the reference's own shape
+    // (framereader.go:51-109 over DecodeNextBlock and a ring of the window's size), for frames larger than the device's memory and
+    // for sources that arrive slowly.  0: the frame is read and decoded whole at the first Read (faster for a frame that fits).
+    explicit FrameReader(std::istream *source = nullptr, mzd_ctx *ctx = nullptr, uint64_t chunk_bytes = 0)
+        : ctx_(ctx), chunk_bytes_(chunk_bytes ? std::max<uint64_t>(chunk_bytes, 128 * 1024) : 0)
     {
         if (source) Reset(source);
     }
     FrameReader(const FrameReader &) = delete;
     FrameReader &operator=(const FrameReader &) = delete;
-    ~FrameReader() { release(); }
+    ~FrameReader()
+    {
+        release();
+        if (cbuf_) mzd_host_free(cbuf_);
+    }
     void Reset(std::istream *source)  // framereader.go:35-49: magic number + frame header are checked here
     {
         release();
+        pend_.clear();
+        pend_lo_ = clo_ = chi_ = 0;
         pos_ = len_ = off_ = 0;
         decoded_ = false;
         source_ = source;
@@ -315,6 +278,14 @@ class FrameReader {
     // memory is released with the last byte.
     size_t Read(uint8_t *p, size_t n)
     {
+        if (chunk_bytes_) {
+            if (clo_ >= chi_ && !next_chunk()) return 0;
+            n = (size_t)std::min<uint64_t>(n, chi_ - clo_);
+            std::memcpy(p, cbuf_ + clo_, n);
+            clo_ += n;
+            readTotal_ += n;
+            return n;
+        }
         if (!decoded_) decode();
         n = std::min<uint64_t>(n, len_ - pos_);
         if (n == 0) return 0;
@@ -338,12 +309,82 @@ class FrameReader {
         if (pos_ >= len_) release();
         return n;
     }
+    // (for FrameDecompressor: a source whose magic number CheckMagicnum has read and checked already)
+    void ResetBehindMagic(std::istream *source, const std::vector<char> &head)
+    {
+        Reset(nullptr);
+        source_ = source;
+        head_ = head;
+    }
+    // chunk mode: the frame's last block has been decoded and all of its bytes handed out
+    bool Finished() const { return decoded_ && clo_ >= chi_; }
+    // chunk mode: the chunk at the reader's position in place -- its bytes not yet read, valid until the next Read / View / Reset
+    // (DecodeNextBlock's hand-over without Read's copy); {nullptr, 0} behind the frame's last block
+    std::pair<const uint8_t *, size_t> ViewChunk()
+    {
+        if (!chunk_bytes_) throw Error(MZD_ERR_INVALID_ARG, "ViewChunk: the reader is not in chunk mode");
+        if (clo_ >= chi_ && !next_chunk()) return {nullptr, 0};
+        const std::pair<const uint8_t *, size_t> v{cbuf_ + clo_, (size_t)(chi_ - clo_)};
+        readTotal_ += v.second;
+        clo_ = chi_;
+        return v;
+    }
     bool PrintStatus = false;
 
   private:
-    static constexpr size_t kDirect = (size_t)1 << 20, kWindow = (size_t)4 << 20;
+    static constexpr size_t kDirect = (size_t)1 << 20, kWindow = (size_t)4 << 20, kPiece = (size_t)4 << 20;
+    // chunk mode: the next chunk's bytes into cbuf_[clo_, chi_); false behind the frame's last block
+    bool next_chunk()
+    {
+        if (decoded_) return false;
+        if (!ctx_) ctx_ = default_context();
+        if (!fs_) {
+            const int rc = mzd_fstream_open(ctx_, chunk_bytes_, &fs_);
+            if (rc != MZD_OK) throw Error(rc, "mzd_fstream_open");
+            if (!cbuf_) cbuf_ = static_cast<uint8_t *>(mzd_host_alloc(chunk_bytes_));  // pinned: the chunk's copy-out at the link's rate
+            if (!cbuf_) throw Error(MZD_ERR_DEVICE, "mzd_host_alloc");
+            pend_.assign(head_.begin(), head_.end());  // (the magic number Reset has read)
+            pend_lo_ = 0;
+        }
+        for (;;) {
+            uint64_t used = 0, made = 0;
+            int done = 0;
+            const int rc = mzd_fstream_next(fs_, pend_.data() + pend_lo_, pend_.size() - pend_lo_, cbuf_, chunk_bytes_, &used, &made, &done);
+            if (rc != MZD_OK) {
+                const std::string why = mzd_last_error(ctx_);
+                release();
+                throw Error(rc, "Read (" + why + ")");
+            }
+            pend_lo_ += used;
+            if (done) {
+                release();  // (window and history leave the device with the frame's last chunk)
+                decoded_ = true;
+            }
+            if (made) {
+                clo_ = 0;
+                chi_ = made;
+                return true;
+            }
+            if (done) return false;
+            if (used == 0) {  // no whole block in what is here: more of the source
+                pend_.erase(pend_.begin(), pend_.begin() + (long)pend_lo_);
+                pend_lo_ = 0;
+                const size_t at = pend_.size();
+                pend_.resize(at + kPiece);
+                source_->read(reinterpret_cast<char *>(pend_.data() + at), (std::streamsize)kPiece);
+                const size_t got = (size_t)source_->gcount();
+                pend_.resize(at + got);
+                if (got == 0) {
+                    release();
+                    throw Error(MZD_ERR_TRUNCATED, "Read");  // io.ErrUnexpectedEOF: the source ended inside the frame
+                }
+            }
+        }
+    }
     void release()
     {
+        if (fs_) mzd_fstream_close(fs_);
+        fs_ = nullptr;
         if (db_) mzd_batch_free(ctx_, db_);
         db_ = nullptr;
         win_lo_ = win_hi_ = 0;
@@ -398,6 +439,86 @@ class FrameReader {
     std::vector<uint8_t> window_;
     uint64_t off_ = 0, len_ = 0, pos_ = 0, win_lo_ = 0, win_hi_ = 0, readTotal_ = 0;
     bool decoded_ = false;
+    // chunk mode
+    uint64_t chunk_bytes_ = 0, clo_ = 0, chi_ = 0;
+    mzd_fstream *fs_ = nullptr;
+    uint8_t *cbuf_ = nullptr;
+    std::vector<uint8_t> pend_;  // source bytes no chunk has consumed yet, from pend_lo_ on
+    size_t pend_lo_ = 0;
+};
+
+// NewFrameDecompressor(s io.Reader, t io.Writer) -- framedecompressor.go:55
+class FrameDecompressor {
+  public:
+    // chunk_bytes > 0: DecodeNextBlock decodes the frame's next CHUNK of whole blocks and writes it to the target
+    // (framedecompressor.go:198-303 with a chunk for a block; FrameReader's chunk mode underneath)
+    FrameDecompressor(std::istream *source, std::ostream *target, mzd_ctx *ctx = nullptr, uint64_t chunk_bytes = 0)
+        : ctx_(ctx), chunk_bytes_(chunk_bytes)
+    {
+        Reset(source, target);
+    }
+    void Reset(std::istream *newsource, std::ostream *newtarget)  // framedecompressor.go:42-52
+    {
+        chunked_.reset();
+        source_ = newsource;
+        target_ = newtarget;
+        done_ = false;
+        BlockCounter = 0;
+        head_.clear();
+    }
+    void CheckMagicnum()  // framedecompressor.go:130-150
+    {
+        char m[4];
+        source_->read(m, 4);
+        head_.assign(m, m + source_->gcount());
+        if (head_.size() < 4) throw Error(MZD_ERR_TRUNCATED, "CheckMagicnum");
+        static const unsigned char magic[4] = {0x28, 0xB5, 0x2F, 0xFD};
+        if (std::memcmp(head_.data(), magic, 4) != 0) throw Error(MZD_ERR_MAGIC, "CheckMagicnum");
+    }
+    // Decompress decompresses the whole frame and writes the whole output to the target (:153-170)
+    void Decompress()
+    {
+        if (done_) throw Error(MZD_ERR_OUT_OF_BLOCKS, "Decompress");
+        if (chunk_bytes_) {
+            while (!done_) DecodeNextBlock();
+            return;
+        }
+        std::vector<uint8_t> frame(head_.begin(), head_.end());
+        frame.insert(frame.end(), std::istreambuf_iterator<char>(*source_), std::istreambuf_iterator<char>());
+        std::vector<int> st;
+        auto out = DecodeFrames({frame}, &st, ctx_);
+        if (st[0] != MZD_OK) throw Error(st[0], "Decompress");
+        target_->write(reinterpret_cast<const char *>(out[0].data()), (std::streamsize)out[0].size());
+        done_ = true;
+    }
+    // DecodeNextBlock (:198-244): all blocks of the frame come out of one device batch
+    void DecodeNextBlock()
+    {
+        if (done_) throw Error(MZD_ERR_OUT_OF_BLOCKS, "DecodeNextBlock");
+        if (!chunk_bytes_) return Decompress();
+        if (!chunked_) {
+            if (head_.empty()) CheckMagicnum();
+            chunked_.reset(new FrameReader(nullptr, ctx_, chunk_bytes_));
+            chunked_->ResetBehindMagic(source_, head_);
+        }
+        const auto v = chunked_->ViewChunk();
+        if (v.second) {
+            target_->write(reinterpret_cast<const char *>(v.first), (std::streamsize)v.second);
+            BlockCounter++;
+        }
+        if (chunked_->Finished()) done_ = true;
+    }
+    bool Verbose = false;
+    int BlockCounter = 0;
+
+  private:
+    std::istream *source_ = nullptr;
+    std::ostream *target_ = nullptr;
+    mzd_ctx *ctx_ = nullptr;
+    std::vector<char> head_;
+    bool done_ = false;
+    uint64_t chunk_bytes_ = 0;
+    std::unique_ptr<FrameReader> chunked_;
 };
 
 // A FrameReader that BATCHES.  The reference's harness feeds many frames through ONE reader, Reset per frame

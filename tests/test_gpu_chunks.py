@@ -91,3 +91,209 @@ def test_large_frame_in_chunks_with_a_bounded_window(chunk_mib, window_log):
     outs, sts = z.decode_frames([comp], ctx)
     assert sts == [0] and outs[0] == d
     ctx.close()
+
+
+def test_matches_that_reach_back_more_than_8_mib_across_chunks():
+    """The frame of test_block_mode_matches_that_reach_back_more_than_8_mib (an incompressible head matched again 10 MiB and 22 MiB
+    later) with a window of 32 MiB, in chunks of 4 MiB: the slab holds up to 36 MiB, the passes spell origins with four planes, and
+    the bytes the late matches want lie in the window the chunks before left."""
+    from tools import synth_binding as sb
+    A = sb.generate(sb.RANDOM, 99, 200000)
+    T = sb.generate(sb.TEXT, 98, 3 << 20)
+    far = A + bytes(10 << 20) + A[:150000] + T + bytes(9 << 20) + A[50000:] + T[:1 << 20]
+    comp = with_window(sb.compress(far, sb.MODE_FULL)[0], 25)
+    ctx = z.Context(0)
+    for chunk in (4 * MIB, 13 * MIB):
+        got, chunks, used, w = stream_decode(comp, ctx, chunk)
+        assert w == 1 << 25 and chunks >= len(far) // chunk and got == far, chunk
+    # declared with a window of 8 MiB the frame is not valid zstd: the late matches reach behind what a decoder has to keep.  The
+    # reference's ring wraps and hands out newer bytes (ringbuffer.go:198-225); the chunks report the offset
+    bad = with_window(sb.compress(far, sb.MODE_FULL)[0], 23)
+    with pytest.raises(z.MzdError) as e:
+        stream_decode(bad, ctx, 4 * MIB)
+    assert e.value.code == 14  # MZD_ERR_OFFSET
+    ctx.close()
+
+
+@pytest.mark.parametrize("exec_variant", [4, 5])
+def test_chunks_with_the_execution_kernel_forced(corpus, exec_variant):
+    """k_exec_c on every chunk (5), block mode with jobs of four blocks on every chunk (4) -- the corpus in chunks of 1 MiB and a
+    text-like frame of 6 MiB in chunks of 1 MiB -- and the variants that do not know chunks refuse them."""
+    from tools import synth_binding as sb
+    ctx = z.Context(0, exec_variant=exec_variant)
+    for name, comp, length, sha, exp in corpus[::3]:
+        got, chunks, used, w = stream_decode(comp, ctx, MIB)
+        check_expected(name, got, length, sha, exp)
+    d = sb.generate(sb.TEXT, 77, 6 * MIB + 99)
+    comp = sb.compress(d, sb.MODE_FULL)[0]
+    got, chunks, used, w = stream_decode(comp, ctx, MIB, piece=300000)
+    assert got == d and chunks >= 6 and w == len(d)  # (single segment: the window is the content)
+    ctx.close()
+    ctx = z.Context(0, exec_variant=1, library="release")
+    with pytest.raises(z.MzdError) as e:
+        stream_decode(comp, ctx, MIB)
+    assert e.value.code == 16  # MZD_ERR_UNSUPPORTED
+    ctx.close()
+
+
+def test_chunk_errors_are_the_frames_errors_and_stick(corpus):
+    """A frame damaged in its fifth block: the chunks before it come out, the chunk that holds it fails with the status the whole
+    frame gets, and the stream stays failed.  A source that ends inside a block: nothing is consumed, nothing produced.  A header
+    that declares another content size than the blocks make: MZD_ERR_DST_FULL at the last block, as for a whole frame."""
+    from tools import synth_binding as sb
+    from tests.frame_splice import frame_blocks, splice_frame
+    ctx = z.Context(0)
+    d = sb.generate(sb.TEXT, 5, 9 * 131072)
+    comp = sb.compress(d, sb.MODE_FULL)[0]
+    blocks = frame_blocks(comp)
+    assert len(blocks) >= 8
+    typ, payload, size = blocks[4]
+    hurt = bytearray(payload)
+    hurt[-3] ^= 0x5A
+    hurt[-2] ^= 0xA5  # (the head of the sequence bitstream: its initial states)
+    blocks[4] = (typ, bytes(hurt), size)
+    bad = splice_frame(blocks)
+    outs, sts = z.decode_frames([bad], ctx)
+    assert sts[0] != 0
+    fs = z.FrameStream(ctx, 128 * KIB)
+    src, dst = np.frombuffer(bad, dtype=np.uint8), np.empty(128 * KIB, dtype=np.uint8)
+    pos, out = 0, bytearray()
+    with pytest.raises(z.MzdError) as e:
+        while not fs.done:
+            used, made = fs.next(src[pos:], dst)
+            pos += used
+            out += dst[:made].tobytes()
+    assert e.value.code == sts[0] and bytes(out) == d[:len(out)] and len(out) == 4 * 131072
+    with pytest.raises(z.MzdError) as e2:
+        fs.next(src[pos:], dst)
+    assert e2.value.code == sts[0]
+    fs.close()
+    # a source that ends inside the last block
+    cut = len(comp) - len(blocks[-1][1]) // 2
+    fs = z.FrameStream(ctx, 128 * KIB)
+    src = np.frombuffer(comp[:cut], dtype=np.uint8)
+    pos = n = 0
+    while True:
+        used, made = fs.next(src[pos:], dst)
+        if used == 0 and made == 0:
+            break
+        pos += used
+        n += made
+    assert not fs.done and n == (len(blocks) - 1) * 131072 and pos < cut
+    fs.close()
+    with pytest.raises(z.MzdError) as e3:  # a destination below one block
+        z.FrameStream(ctx, 128 * KIB).next(src, np.empty(1000, dtype=np.uint8))
+    assert e3.value.code == 101
+    # the declared content size (4 bytes here) one byte off
+    assert comp[4] >> 6 == 2 and comp[4] & 0x20
+    lied = comp[:5] + (int.from_bytes(comp[5:9], "little") + 1).to_bytes(4, "little") + comp[9:]
+    assert z.decode_frames([lied], ctx)[1] == [15]
+    with pytest.raises(z.MzdError) as e4:
+        stream_decode(lied, ctx, 256 * KIB)
+    assert e4.value.code == 15  # MZD_ERR_DST_FULL
+    ctx.close()
+
+
+def test_a_frame_larger_than_the_memory_it_is_given():
+    """A frame of 192 MiB with a window of 8 MiB in chunks of 8 MiB: between two chunks the device holds two slabs of window + chunk
+    -- 32 MiB -- whatever the frame's length (the whole-frame path holds the output and three planes of it: 768 MiB)."""
+    import torch
+    from tools import synth_binding as sb
+    n = 192 * MIB
+    sb.set_max_offset(1 << 23)
+    try:
+        blob, off, ln, ck, ns = sb.make_batch(4, 91, 1, frame_bytes=n, threads=8)
+    finally:
+        sb.set_max_offset(0)
+    comp = with_window(blob[int(off[0]):int(off[0] + ln[0])].tobytes(), 23)
+    ctx = z.Context(0)
+
+    def used():
+        free, total = torch.cuda.mem_get_info(0)
+        return total - free
+
+    base = used()
+    seen = []
+    h = hashlib.sha256()
+    fs = z.FrameStream(ctx, 8 * MIB)
+    src, dst = np.frombuffer(comp, dtype=np.uint8), np.empty(8 * MIB, dtype=np.uint8)
+    pos = total = 0
+    while not fs.done:
+        u, m = fs.next(src[pos:pos + 6 * MIB], dst)
+        assert u or m
+        pos += u
+        total += m
+        h.update(dst[:m].tobytes())
+        seen.append(used() - base)
+    fs.close()
+    assert total == n and len(seen) >= 24
+    assert max(seen) <= 2 * (16 * MIB + 4096) + 32 * MIB, max(seen)  # (the allocator's granularity on top)
+    outs, sts = z.decode_frames([comp], ctx)
+    assert sts == [0] and hashlib.sha256(outs[0]).hexdigest() == h.hexdigest() and sb.checksum64(outs[0]) == int(ck[0])
+    ctx.close()
+
+
+class _Dribble:
+    """a source that is not seekable and hands out at most `k` bytes per read (a socket, a pipe)"""
+
+    def __init__(self, data, k):
+        self._d, self._p, self._k = data, 0, k
+
+    def read(self, n=-1):
+        n = self._k if n is None or n < 0 else min(n, self._k)
+        d = self._d[self._p:self._p + n]
+        self._p += len(d)
+        return d
+
+
+def test_readers_in_chunk_mode(corpus):
+    """FrameReader / FrameDecompressor with chunk_bytes (the reference's shape: framereader.go:51-109 over DecodeNextBlock): whole
+    reads, small Reads across chunk boundaries, readinto, a source that dribbles; a cut source ends in io.ErrUnexpectedEOF."""
+    import io
+    from tools import synth_binding as sb
+    from sparkzstd_amd.decompression import ZstdError
+    ctx = z.Context(0)
+    d = sb.generate(sb.TEXT, 321, 5 * MIB + 1234)
+    comp = sb.compress(d, sb.MODE_FULL)[0]
+    assert z.FrameReader(io.BytesIO(comp), ctx, chunk_bytes=MIB).read() == d
+    r = z.FrameReader(_Dribble(comp, 7777), ctx, chunk_bytes=512 * KIB)
+    got = bytearray()
+    while True:
+        part = r.Read(100003)
+        if not part:
+            break
+        assert len(part) <= 100003
+        got += part
+    assert bytes(got) == d and r.Read(10) == b""
+    r.Reset(io.BytesIO(comp))  # (the same reader, the next frame)
+    buf = bytearray(300000)
+    got = bytearray()
+    while True:
+        k = r.readinto(buf)
+        if not k:
+            break
+        got += buf[:k]
+    assert bytes(got) == d
+    r.close()
+    for name, comp2, length, sha, exp in corpus[:20]:
+        check_expected(name, z.FrameReader(_Dribble(comp2, 4096), ctx, chunk_bytes=128 * KIB).read(), length, sha, exp)
+    # FrameDecompressor: DecodeNextBlock = the next chunk
+    sink = io.BytesIO()
+    fd = z.FrameDecompressor(io.BytesIO(comp), sink, ctx, chunk_bytes=MIB)
+    fd.CheckMagicnum()
+    n = 0
+    while True:
+        try:
+            fd.DecodeNextBlock()
+        except ZstdError as e:
+            assert e.code == 17  # ErrOutOfBlocks (framedecompressor.go:196)
+            break
+        n += 1
+    assert sink.getvalue() == d and n == fd.BlockCounter and 5 <= n <= 7
+    sink = io.BytesIO()
+    z.FrameDecompressor(io.BytesIO(comp), sink, ctx, chunk_bytes=2 * MIB).Decompress()
+    assert sink.getvalue() == d
+    with pytest.raises(ZstdError) as e:
+        z.FrameReader(io.BytesIO(comp[:len(comp) // 2]), ctx, chunk_bytes=MIB).read()
+    assert e.value.code == 1
+    ctx.close()

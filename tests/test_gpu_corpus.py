@@ -509,16 +509,17 @@ def test_frame_reader_serves_reads_from_device_memory(ctx):
         assert rc != 0 and r._rb is None
 
 
-@pytest.mark.parametrize("flags", [[], ["--device-plan"], ["--devices", "0,0"], ["--device-plan", "--devices", "0,0,0"], ["--batch-reader", "7"]])
+@pytest.mark.parametrize("flags", [[], ["--device-plan"], ["--devices", "0,0"], ["--device-plan", "--devices", "0,0,0"], ["--batch-reader", "7"],
+                                   ["--chunk", "131072"], ["--chunk", "1000000"], ["--decompressor", "262144"]])
 def test_cpp_frame_reader_verify_cli(corpus, flags):
     """The C++ mirror of FrameReader (include/sparkzstd_frame.hpp) driven like the reference's own
-    harness cmd/sparkzstd/main.go: decode x.zst, compare byte for byte with x."""
+    harness cmd/sparkzstd/main.go: decode x.zst, compare byte for byte with x.  --chunk: the shared reader in chunk mode (ABI 9:
+    every frame through the device in chunks of whole blocks); --decompressor: FrameDecompressor.DecodeNextBlock, a chunk per call."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tools", "verify", "sparkzstd_verify")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tools", "verify")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tools", "verify")])
     d = os.path.join(root, "tests", "golden", "decodecorpus")
     files = [os.path.join(d, name + ".zst") for name, _, _, _, exp in corpus if exp is not None]
     assert len(files) >= 30
