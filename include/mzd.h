@@ -502,17 +502,26 @@ typedef struct mzd_fstream mzd_fstream;
 /* chunk_out: bytes a chunk may regenerate (0: 64 MiB; at least one block).  The device memory the frame needs is
  * 2 x (window + chunk_out) + the chunk's scratch, whatever its length. */
 int mzd_fstream_open(mzd_ctx *ctx, uint64_t chunk_out, mzd_fstream **fs);
-/* Decodes the next chunk.  src / len as for mzd_cursor_next; dst: host memory for the chunk's bytes, dst_cap >= 128 KiB (a
- * chunk's bound is min(chunk_out, dst_cap)).  *consumed / *produced: bytes of src used, bytes written to dst; both zero with
- * MZD_OK: src holds no whole block yet.  *done: the frame's last block has been decoded (then, if the header declared a content
- * size and the frame regenerated another: MZD_ERR_DST_FULL).  A frame whose window does not fit beside a chunk in 2 GiB:
- * MZD_ERR_UNSUPPORTED.  Errors stick. */
+/* One step: takes the next chunk of whole blocks from src (src / len as for mzd_cursor_next) and sends it to the device; hands
+ * out the bytes of the chunk the call BEFORE sent (a two-stage pipeline: the host describes chunk i while the device decodes
+ * chunk i - 1, and chunk i - 1 is copied out while chunk i runs).  dst: host memory for a chunk's bytes, dst_cap >= 128 KiB and
+ * the same from call to call (a chunk's bound is min(chunk_out, dst_cap)); pinned memory (mzd_host_alloc) copies at the link's
+ * rate.  *consumed: bytes of src used; *produced: bytes written to dst -- of an earlier part of the frame than the bytes just
+ * consumed.  Both zero with MZD_OK: src holds no whole block yet and nothing is on the device.  After the call that consumed the
+ * frame's last block one more call (src may be empty) hands out the last chunk: *done is set with it (then, if the header
+ * declared a content size and the frame regenerated another: MZD_ERR_DST_FULL).  A chunk's error is reported by the call that
+ * would hand out its bytes.  A frame whose window does not fit beside a chunk in 2 GiB: MZD_ERR_UNSUPPORTED.  Errors stick. */
 int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t *dst, uint64_t dst_cap, uint64_t *consumed,
                      uint64_t *produced, int *done);
 /* bytes regenerated so far; the cursor (header fields) */
 uint64_t mzd_fstream_total_out(const mzd_fstream *fs);
 const mzd_cursor *mzd_fstream_cursor(const mzd_fstream *fs);
 void mzd_fstream_close(mzd_fstream *fs);
+/* Measurement hook: host milliseconds the stream's calls have spent so far in {the cursor (header and section parsing, table
+ * construction), the chunk's upload and launch (allocations, copy-in, table build), waiting for the chunk before it (what of its
+ * pass the cursor's work did not cover) and freeing the scratch of the one before that, the copy-out of a chunk's bytes}; returns
+ * the number of entries written (4 at most). */
+int mzd_fstream_timing(const mzd_fstream *fs, double *ms, int cap);
 
 #ifdef __cplusplus
 }

@@ -507,8 +507,11 @@ class FrameStream:
 
     @_ctx_locked
     def next(self, src: np.ndarray, dst: np.ndarray):
-        """src: the frame's bytes not yet consumed; dst: where the chunk's bytes go (uint8 arrays; dst at least 128 KiB).
-        -> (consumed, produced); both 0: src holds no whole block yet.  self.done after the frame's last block."""
+        """src: the frame's bytes not yet consumed; dst: where a chunk's bytes go (uint8 arrays; dst at least 128 KiB, the same size
+        every call).  A step of a two-stage pipeline: the chunk taken from src goes to the device, the bytes that come back are those
+        of the chunk the call before took.  -> (consumed, produced); both 0: src holds no whole block yet and nothing is on the
+        device.  After the frame's last block has been consumed one more call (src may be empty) hands out the last chunk and sets
+        self.done."""
         consumed, produced, done = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
         rc = self.ctx._L.mzd_fstream_next(self._h, src.ctypes.data if src.size else None, src.size, dst.ctypes.data, dst.size,
                                           ctypes.byref(consumed), ctypes.byref(produced), ctypes.byref(done))
@@ -520,6 +523,12 @@ class FrameStream:
     @property
     def total_out(self) -> int:
         return self.ctx._L.mzd_fstream_total_out(self._h)
+
+    def timing(self) -> dict:
+        """host milliseconds spent so far per stage of a call (mzd_fstream_timing)"""
+        ms = (ctypes.c_double * 4)()
+        n = self.ctx._L.mzd_fstream_timing(self._h, ms, 4)
+        return dict(zip(("plan", "upload_and_launch", "wait_for_the_chunk_before", "copy_out")[:n], (round(ms[i], 3) for i in range(n))))
 
     @property
     def window(self) -> int:

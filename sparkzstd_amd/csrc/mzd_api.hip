@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -2628,27 +2629,45 @@ int mzd_batch_get_stats(mzd_dbatch *db, mzd_batch_stats *st)
 // Two slabs of (window + chunk) bytes.  A chunk is decoded into the slab whose beginning holds the bytes the frame regenerated
 // before it (`keep` of them: all, until there are more than the window); its own bytes go to the caller; when slab and window no
 // longer hold what is there, the last window_size bytes move to the other slab's beginning (ringbuffer.go:36-49 keeps as much).
+//
+// A call is one step of a two-stage pipeline: it describes chunk i on the host WHILE chunk i - 1 is on the device, waits for that
+// one (its length is where chunk i starts, its history what chunk i starts with), launches chunk i, and copies chunk i - 1 out
+// while chunk i runs: the bytes a call produces are those of the chunk the call before consumed.
 struct mzd_fstream {
     mzd_ctx *ctx = nullptr;
     mzd_cursor *cur = nullptr;
     uint64_t chunk_out = 0;
     uint8_t *slab[2] = {nullptr, nullptr};
     uint64_t slab_bytes = 0;
-    int at = 0;         // the slab in use
+    int at = 0;         // the slab the next chunk goes to
     uint64_t keep = 0;  // bytes of the frame at its beginning
     uint64_t window = 0;
     int32_t hist[3] = {1, 4, 8};  // framedecompressor.go:48,59
     uint64_t total = 0;
-    bool sized = false, done = false;
+    bool sized = false, planned_last = false, done = false;
     int status = MZD_OK;
+    // the chunk on the device
+    mzd_dbatch *fly = nullptr;
+    uint64_t fly_keep = 0, fly_bound = 0;
+    int fly_at = 0;
+    bool fly_last = false;
+    mzd_dbatch *spent = nullptr;  // the chunk before it: its scratch is freed when the device is idle anyway (hipFree waits for it)
+    hipStream_t s_copy = nullptr;
+    double ms[4] = {0, 0, 0, 0};  // mzd_fstream_timing: cursor, upload + launch, wait + free, copy-out
 };
 
 int mzd_fstream_open(mzd_ctx *ctx, uint64_t chunk_out, mzd_fstream **out)
 {
     if (!ctx || !out) return MZD_ERR_INVALID_ARG;
     *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     mzd_fstream *fs = new mzd_fstream();
     fs->ctx = ctx;
+    if (hipStreamCreateWithFlags(&fs->s_copy, hipStreamNonBlocking) != hipSuccess) {
+        delete fs;
+        ctx->last_error = "mzd_fstream_open: hipStreamCreateWithFlags failed";
+        return MZD_ERR_DEVICE;
+    }
     fs->cur = mzd_cursor_create();
     fs->chunk_out = std::max<uint64_t>(chunk_out ? chunk_out : (64ull << 20), kBlockMax);
     *out = fs;
@@ -2659,6 +2678,12 @@ void mzd_fstream_close(mzd_fstream *fs)
 {
     if (!fs) return;
     if (fs->ctx) (void)hipSetDevice(fs->ctx->device);
+    if (fs->fly) {
+        (void)hipStreamSynchronize(fs->ctx->stream);
+        mzd_batch_free(fs->ctx, fs->fly);
+    }
+    if (fs->spent) mzd_batch_free(fs->ctx, fs->spent);
+    if (fs->s_copy) (void)hipStreamDestroy(fs->s_copy);
     (void)hipFree(fs->slab[0]);
     (void)hipFree(fs->slab[1]);
     mzd_cursor_destroy(fs->cur);
@@ -2676,79 +2701,150 @@ int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t 
     if (done) *done = fs->done ? 1 : 0;
     if (fs->status) return fs->status;
     if (fs->done) return MZD_ERR_OUT_OF_BLOCKS;  // framedecompressor.go:196
+    if (fs->fly && dst_cap < fs->fly_bound) return MZD_ERR_INVALID_ARG;  // (the chunk on the device was sized for the call before's dst)
     mzd_ctx *ctx = fs->ctx;
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    auto lap = [&](int k) {
+        const auto t1 = clk::now();
+        fs->ms[k] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+    };
+    auto fail = [&](int code) {
+        fs->status = code;
+        return code;
+    };
+    // ---- the next chunk's description (host), while the chunk before it is on the device.  Where it starts and with which history
+    // is known when that one is done: both are put in below.
     const uint64_t max_out = std::min(fs->chunk_out, dst_cap);
     const mzd_batch *chunk = nullptr;
     int last = 0;
-    int rc = mzd_cursor_next(fs->cur, src, len, max_out, fs->keep, fs->hist, consumed, &chunk, &last);
-    if (rc) return fs->status = rc;
-    if (!chunk) return MZD_OK;  // no whole block in src yet
+    if (!fs->planned_last) {
+        const int rc = mzd_cursor_next(fs->cur, src, len, max_out, 0, nullptr, consumed, &chunk, &last);
+        if (rc) return fail(rc);
+        if (chunk && last) fs->planned_last = true;
+    }
+    lap(0);
+    if (!chunk && !fs->fly) return MZD_OK;  // no whole block in src yet, nothing on the device
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!fs->sized) {
-        fs->window = mzd_cursor_window(fs->cur);
-        // (a slab's positions are 32-bit and block mode takes slabs below 2 GiB)
-        if (fs->window > (1ull << 31) - fs->chunk_out - (1ull << 20)) {
-            ctx->last_error = "mzd_fstream: the frame's window and a chunk do not fit a slab of 2 GiB";
-            return fs->status = MZD_ERR_UNSUPPORTED;
-        }
-        fs->slab_bytes = ((fs->window + 255) & ~255ull) + fs->chunk_out + 1024;
-        for (int k = 0; k < 2; k++) {
-            const hipError_t e = hipMalloc((void **)&fs->slab[k], fs->slab_bytes);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                ctx->last_error = std::string("mzd_fstream: hipMalloc of a slab failed: ") + hipGetErrorString(e);
-                return fs->status = MZD_ERR_DEVICE;
-            }
-        }
-        fs->sized = true;
-    }
-    mzd_batch b = *chunk;
-    b.out = fs->slab[fs->at];
-    b.out_size = fs->slab_bytes;
-    b.flags |= MZD_BATCH_OUT_ON_DEVICE;
-    mzd_dbatch *db = nullptr;
-    rc = mzd_batch_upload(ctx, &b, &db);
-    if (rc) return fs->status = rc;
-    rc = mzd_batch_run(ctx, db, nullptr);
-    int32_t st = MZD_OK;
-    uint64_t olen = 0;
-    if (rc == MZD_OK) rc = mzd_batch_download(ctx, db, nullptr, &st, &olen);
-    if (rc == MZD_OK && st) rc = st;
-    if (rc == MZD_OK && (olen < fs->keep || olen - fs->keep > dst_cap)) rc = MZD_ERR_DST_FULL;
+    // ---- the chunk on the device: wait for it; its length and the history behind it
     uint64_t n = 0;
-    if (rc == MZD_OK) {
-        n = olen - fs->keep;
-        rc = mzd_batch_read_out(ctx, db, fs->keep, dst, n);
-    }
-    if (rc == MZD_OK && db->d_frame_hist) {
-        const hipError_t e = hipMemcpy(fs->hist, db->d_frame_hist, sizeof(fs->hist), hipMemcpyDeviceToHost);
+    const bool had = fs->fly != nullptr;
+    if (had) {
+        mzd_dbatch *db = fs->fly;
+        int32_t st = MZD_OK;
+        uint64_t olen = 0;
+        hipError_t e = hipMemcpyAsync(&st, db->d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&olen, db->d_out_len, sizeof(olen), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && db->d_frame_hist) e = hipMemcpyAsync(fs->hist, db->d_frame_hist, sizeof(fs->hist), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        db->run_pending = false;
         if (e != hipSuccess) {
-            ctx->last_error = std::string("mzd_fstream: reading the offset history failed: ") + hipGetErrorString(e);
-            rc = MZD_ERR_DEVICE;
+            ctx->last_error = std::string("mzd_fstream_next: waiting for the chunk failed: ") + hipGetErrorString(e);
+            return fail(MZD_ERR_DEVICE);
+        }
+        if (st) return fail(st);
+        if (olen < fs->fly_keep || olen - fs->fly_keep > dst_cap) return fail(MZD_ERR_DST_FULL);
+        n = olen - fs->fly_keep;
+        // what the next chunk finds in front of it
+        const uint64_t have = fs->fly_keep + n;
+        if (fs->fly_last) {
+        } else if (have <= fs->window && ((have + 255) & ~255ull) + fs->chunk_out + 1024 <= fs->slab_bytes) {
+            fs->keep = have;  // (the frame so far is within its window and the slab has room behind it: it stays where it is)
+        } else {
+            const uint64_t nk = std::min(fs->window, have);
+            if (nk) HIP_TRY(ctx, hipMemcpyAsync(fs->slab[fs->fly_at ^ 1], fs->slab[fs->fly_at] + (have - nk), nk, hipMemcpyDeviceToDevice, ctx->stream));
+            fs->at = fs->fly_at ^ 1;
+            fs->keep = nk;
+        }
+        if (fs->spent) {
+            mzd_batch_free(ctx, fs->spent);
+            fs->spent = nullptr;
         }
     }
-    mzd_batch_free(ctx, db);
-    if (rc) return fs->status = rc;
-    fs->total += n;
-    *produced = n;
-    if (last) {
-        fs->done = true;
-        if (done) *done = 1;
-        const uint64_t content = mzd_cursor_content_size(fs->cur);
-        if (content != MZD_UNKNOWN_SIZE && content != fs->total) return fs->status = MZD_ERR_DST_FULL;
-        return MZD_OK;
+    lap(2);
+    // ---- the next chunk goes to the device
+    mzd_dbatch *next_db = nullptr;
+    uint64_t next_bound = 0;
+    if (chunk) {
+        if (!fs->sized) {
+            fs->window = mzd_cursor_window(fs->cur);
+            // (a slab's positions are 32-bit and block mode takes slabs below 2 GiB)
+            if (fs->window > (1ull << 31) - fs->chunk_out - (1ull << 20)) {
+                ctx->last_error = "mzd_fstream: the frame's window and a chunk do not fit a slab of 2 GiB";
+                return fail(MZD_ERR_UNSUPPORTED);
+            }
+            fs->slab_bytes = ((fs->window + 255) & ~255ull) + fs->chunk_out + 1024;
+            for (int k = 0; k < 2; k++) {
+                const hipError_t e = hipMalloc((void **)&fs->slab[k], fs->slab_bytes);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->last_error = std::string("mzd_fstream: hipMalloc of a slab failed: ") + hipGetErrorString(e);
+                    return fail(MZD_ERR_DEVICE);
+                }
+            }
+            fs->sized = true;
+        }
+        mzd_frame_desc fd = chunk->frames[0];
+        next_bound = fd.out_capacity;  // (described from position 0: the blocks' bound)
+        fd.start = fs->keep;
+        fd.out_capacity = fs->keep + next_bound;
+        for (int k = 0; k < 3; k++) fd.hist[k] = fs->hist[k];
+        mzd_batch b = *chunk;
+        b.frames = &fd;
+        b.out = fs->slab[fs->at];
+        b.out_size = fs->slab_bytes;
+        b.flags |= MZD_BATCH_OUT_ON_DEVICE;
+        int rc = mzd_batch_upload(ctx, &b, &next_db);
+        if (rc == MZD_OK) rc = mzd_batch_run(ctx, next_db, nullptr);
+        if (rc) {
+            if (next_db) mzd_batch_free(ctx, next_db);
+            return fail(rc);
+        }
     }
-    // what the next chunk finds in front of it
-    const uint64_t have = fs->keep + n;
-    if (have <= fs->window && ((have + 255) & ~255ull) + fs->chunk_out + 1024 <= fs->slab_bytes) {
-        fs->keep = have;  // (the frame so far is within its window and the slab has room behind it: it stays where it is)
-    } else {
-        const uint64_t nk = std::min(fs->window, have);
-        if (nk) HIP_TRY(ctx, hipMemcpy(fs->slab[fs->at ^ 1], fs->slab[fs->at] + (have - nk), nk, hipMemcpyDeviceToDevice));
-        fs->at ^= 1;
-        fs->keep = nk;
+    lap(1);
+    // ---- the bytes of the chunk that is done, while the next one runs
+    if (had) {
+        hipError_t e = n ? hipMemcpyAsync(dst, fs->slab[fs->fly_at] + fs->fly_keep, n, hipMemcpyDeviceToHost, fs->s_copy) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(fs->s_copy);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("mzd_fstream_next: the chunk's copy-out failed: ") + hipGetErrorString(e);
+            if (next_db) {
+                (void)hipStreamSynchronize(ctx->stream);
+                mzd_batch_free(ctx, next_db);
+            }
+            return fail(MZD_ERR_DEVICE);
+        }
+        fs->spent = fs->fly;
+        fs->total += n;
+        *produced = n;
+        if (fs->fly_last) {
+            fs->done = true;
+            if (done) *done = 1;
+            mzd_batch_free(ctx, fs->spent);
+            fs->spent = nullptr;
+            fs->fly = nullptr;
+            const uint64_t content = mzd_cursor_content_size(fs->cur);
+            if (content != MZD_UNKNOWN_SIZE && content != fs->total) return fail(MZD_ERR_DST_FULL);
+            lap(3);
+            return MZD_OK;
+        }
     }
+    lap(3);
+    fs->fly = next_db;
+    fs->fly_keep = fs->keep;
+    fs->fly_bound = next_bound;
+    fs->fly_at = fs->at;
+    fs->fly_last = last != 0;
     return MZD_OK;
+}
+
+int mzd_fstream_timing(const mzd_fstream *fs, double *ms, int cap)
+{
+    if (!fs || !ms) return 0;
+    const int n = std::max(0, std::min(cap, 4));
+    for (int i = 0; i < n; i++) ms[i] = fs->ms[i];
+    return n;
 }
 
 }  // extern "C"

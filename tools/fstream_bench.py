@@ -56,12 +56,14 @@ for c in chunks:
                 first = time.time() - t0
             peak = max(peak, used_mib() - base)
         t1 = time.time()
+        stages = fs.timing()
         fs.close()
         assert made_total == n and sb.checksum64(out.a[:n].tobytes()) == want
         best = min(best or 1e9, t1 - t0)
     print(json.dumps({"bench": "mzd_fstream_next", "frame_MiB": frame_mib, "compressed_MiB": round(len(comp) / 2 ** 20, 1), "window_log": wlog,
                       "chunk_MiB": c, "calls": calls, "seconds": round(best, 4), "out_GBs": round(n / best / 1e9, 2),
-                      "first_bytes_after_ms": round(first * 1e3, 2), "device_MiB_peak": round(peak, 1)}), flush=True)
+                      "first_bytes_after_ms": round(first * 1e3, 2), "device_MiB_between_calls": round(peak, 1),
+                      "host_ms_per_stage_last_run": stages}), flush=True)
     dst.free()
     out.free()
 if n <= (1 << 31) - (1 << 20):
