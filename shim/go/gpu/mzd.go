@@ -46,7 +46,7 @@ var (
 var Sentinels = map[int]error{}
 
 // BuildID names the library the process runs on: the first 16 hex digits of the sha256 of the sources it was built from (mzd_build_id,
-// ABI 8).
+// ABI 8; ABI 9 adds a frame in chunks: FrameStream).
 func BuildID() string { return C.GoString(C.mzd_build_id()) }
 
 // SentinelFor turns a per-frame status of the device into the Go error the reference would have returned
@@ -209,6 +209,62 @@ func (r *ResidentFrame) Free() {
 		C.mzd_batch_free(r.x.c, r.db)
 		r.x.mu.Unlock()
 		r.db = nil
+	}
+}
+
+// FrameStream is ONE frame going through the device in chunks of whole blocks (mzd_fstream_*, ABI 9): the device keeps the
+// frame's window and its offset history between two chunks and nothing else -- FrameDecompressor.DecodeNextBlock + Ringbuffer
+// (framedecompressor.go:198-303, ringbuffer.go:36-49) for one frame.  A frame may be larger than the device's memory, its source
+// may arrive piecewise, and its first bytes are out before its last ones are in.
+type FrameStream struct {
+	x    *Context
+	fs   *C.mzd_fstream
+	Done bool // the frame's last chunk has been handed out
+}
+
+// NewFrameStream: chunkOut = the bytes a chunk may regenerate (0: 64 MiB).
+func (x *Context) NewFrameStream(chunkOut uint64) (*FrameStream, error) {
+	x.mu.Lock()
+	defer x.mu.Unlock()
+	var fs *C.mzd_fstream
+	if rc := C.mzd_fstream_open(x.c, C.uint64_t(chunkOut), &fs); rc != C.MZD_OK {
+		return nil, errors.New("mzd_fstream_open: " + x.lastError())
+	}
+	return &FrameStream{x: x, fs: fs}, nil
+}
+
+// Next is one step of the stream's two-stage pipeline (include/mzd.h, mzd_fstream_next): the next chunk of whole blocks in src
+// goes to the device, the bytes that come back in dst (at least 128 KiB, the same size every call) are those of the chunk the
+// call before took.  consumed == 0 && produced == 0 && !Done: src holds no whole block yet.
+func (s *FrameStream) Next(src, dst []byte) (consumed, produced int, err error) {
+	s.x.mu.Lock()
+	defer s.x.mu.Unlock()
+	var used, made C.uint64_t
+	var done C.int
+	var sp *C.uint8_t
+	if len(src) > 0 {
+		sp = (*C.uint8_t)(unsafe.Pointer(&src[0]))
+	}
+	rc := C.mzd_fstream_next(s.fs, sp, C.uint64_t(len(src)), (*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), &used, &made, &done)
+	runtime.KeepAlive(src)
+	runtime.KeepAlive(dst)
+	if rc != C.MZD_OK {
+		if e := SentinelFor(int32(rc)); e != nil {
+			return int(used), 0, e
+		}
+		return int(used), 0, errors.New("mzd_fstream_next: " + s.x.lastError())
+	}
+	s.Done = done != 0
+	return int(used), int(made), nil
+}
+
+// Close releases the stream's device memory (idempotent).
+func (s *FrameStream) Close() {
+	if s.fs != nil {
+		s.x.mu.Lock()
+		C.mzd_fstream_close(s.fs)
+		s.x.mu.Unlock()
+		s.fs = nil
 	}
 }
 

@@ -1714,6 +1714,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
         const double t_blk = blk_np * chip * 1.12 + (double)db->out_size / (1u << 30) * 5.0 + (double)blk_maxcap / kBlockMax * 0.006 + 0.2;
         // (`profiles/r4_corpus_sizes.txt`: 1 GiB of the corpus 19.5 ms in block mode against 11.9 with the blocks in order)
         blk = blk_maxcap < (1ull << 31) - 65536 && (ctx->opt.exec_variant >= 3 || t_blk < 0.85 * t_serial);
+        // (a chunk of ONE frame: nothing else is there to fill the chip, and what its blocks cost a single wavefront is not only
+        // their sequences -- long matches far back are read from the slab 128 bytes at a time: chunks of 64 MiB of such content,
+        // few sequences per block, were walked in order at 0.4 GB/s, 170 ms each, where block mode takes 5; round 6)
+        if (db->has_chunks && db->n_frames == 1 && db->n_blocks >= 32 && blk_maxcap < (1ull << 31) - 65536) blk = true;
         if (blk) {
             exec_b = true;
             exec_c = false;

@@ -44,6 +44,8 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
     uint32_t n_ok = error == MZD_OK ? fr.n_blocks : 0u;
     bool prev_direct = true;  // (the block before the frame's first: a job starts there anyway)
     uint32_t reach = 0;       // the largest offset code of the frame's blocks (BlockSum::reach; ~0 when the sequence kernel does not say)
+    // (a chunk's repeat offsets may be the history it was handed: offsets no block of the chunk spells out)
+    if (fr.continues) reach = (uint32_t)max(max(fr.hist[0], fr.hist[1]), fr.hist[2]);
     for (uint32_t base = 0; base < fr.n_blocks; base += 64) {
         const uint32_t bi = base + lane;
         const bool valid = bi < fr.n_blocks;

@@ -300,3 +300,32 @@ def test_readers_in_chunk_mode(corpus):
         z.FrameReader(io.BytesIO(comp[:len(comp) // 2]), ctx, chunk_bytes=MIB).read()
     assert e.value.code == 1
     ctx.close()
+
+
+def test_repeat_offsets_from_the_chunk_before_reach_back_more_than_8_mib(oracle):
+    """Blocks that spell out no offset of their own: each copies 128 KiB from 12 MiB back through the REPEAT offset the block before
+    left (hand-made blocks of one sequence under the predefined tables).  A chunk made of such blocks inherits that offset with its
+    history -- block mode must take the pass for the position's high bits although none of the chunk's offset codes says so (found
+    with a 2.5 GiB frame in round 6: k_blk_scan now counts the history it is handed)."""
+    from tests.frame_splice import one_sequence_block, predefined_states, splice_frame
+    st = predefined_states(oracle)
+    rng = np.random.default_rng(12)
+    R = bytes(rng.integers(0, 256, size=12 * MIB, dtype=np.uint8))
+    blocks = [(0, R[i:i + 131072], 131072) for i in range(0, len(R), 131072)]
+    blocks.append(one_sequence_block(st, b"a", 1, 131071, 12 * MIB + 3))
+    for i in range(95):
+        blocks.append(one_sequence_block(st, bytes([98 + i % 20]), 1, 131071, 1))
+    frame = splice_frame(blocks)
+    rc, want, *_ = oracle.decode_frame(frame, cap=32 * MIB)
+    assert rc == 0 and len(want) == 24 * MIB
+    for ev, chunk in ((0, 4 * MIB), (4, MIB), (5, 2 * MIB)):
+        ctx = z.Context(0, exec_variant=ev)
+        outs, sts = z.decode_frames([frame], ctx)
+        assert sts == [0] and outs[0] == want, ev
+        got, chunks, used, w = stream_decode(frame, ctx, chunk)
+        assert chunks >= 24 * MIB // chunk and w == 128 * MIB
+        if got != want:
+            a, b = np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)
+            bad = np.nonzero(a[:min(len(a), len(b))] != b[:min(len(a), len(b))])[0]
+            raise AssertionError((ev, chunk, len(got), len(bad), bad[:6].tolist()))
+        ctx.close()
