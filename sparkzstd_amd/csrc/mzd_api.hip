@@ -1590,6 +1590,10 @@ int mzd_batch_run(mzd_ctx *ctx, mzd_dbatch *db, void *stream_)
 {
     if (!ctx || !db) return MZD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // (the launch checks below read the thread's LAST error: one that somebody else's call left there -- another library in the
+    // process probing a device that does not exist: "invalid device ordinal" in a pass that launched fine, round 6 -- is not this
+    // pass's)
+    (void)hipGetLastError();
     hipStream_t s = stream_ ? (hipStream_t)stream_ : ctx->stream;
     if (db->trimmed) {
         ctx->last_error = "mzd_batch_run on a batch that mzd_batch_trim has reduced to its output";
