@@ -410,6 +410,49 @@ def secondary_workloads(z, sb, torch, device, headline):
         measure(name, blob, off, ln, np.full(frames, frame_bytes, dtype=np.uint64),
                 lambda d_out, rb: verify_synth(torch, d_out, frames, frame_bytes, cks), **kw)
         out[name]["generate_s"] = round(gen, 2)
+        return blob, off, ln, cks
+
+    def in_chunks(name, frame, frame_bytes, ck, window_log=27, chunk_mib=64):
+        """HOST TO HOST (PCIe is in it: not a device pass like the entries above): one frame through mzd_fstream_* in chunks of whole
+        blocks -- the device keeps the frame's window (here 2^window_log bytes: the single-segment frame re-headed with a window
+        descriptor, frame.go:28-36) and the scratch of two chunks, not the frame; pinned buffers; the first pass copies every chunk
+        into one buffer and is checked against the generator's checksum, the second is the one timed."""
+        t_all = time.perf_counter()
+        ctx = z.Context(device)
+        src = dst = whole = None
+        try:
+            fhd = int(frame[4])
+            assert fhd & 0x20 and (fhd >> 6) >= 1
+            comp = np.concatenate([frame[:4], np.array([fhd & ~0x20 & 0xFF, (window_log - 10) << 3], dtype=np.uint8), frame[5:]])
+            src, dst, whole = z.PinnedBuffer(comp.size), z.PinnedBuffer(chunk_mib << 20), z.PinnedBuffer(frame_bytes)
+            src.a[:] = comp
+            secs, ok, calls, stages = None, False, 0, None
+            for timed in (False, True):
+                fs = z.FrameStream(ctx, chunk_mib << 20)
+                pos = total = calls = 0
+                t0 = time.perf_counter()
+                while not fs.done:
+                    used, made = fs.next(src.a[pos:], dst.a)
+                    if not timed:
+                        whole.a[total:total + made] = dst.a[:made]
+                    pos += used
+                    total += made
+                    calls += 1
+                secs = time.perf_counter() - t0
+                stages = fs.timing()
+                fs.close()
+                if not timed:
+                    ok = total == frame_bytes and sb.checksum64(whole.a[:frame_bytes]) == int(ck)
+            out[name] = {"host_to_host": True, "ms": round(secs * 1e3, 2), "out_GBs": round(frame_bytes / secs / 1e9, 2), "chunk_MiB": chunk_mib,
+                         "window_log": window_log, "calls": calls, "host_ms_per_stage": stages, "bit_exact": bool(ok),
+                         "wall_s": round(time.perf_counter() - t_all, 2)}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            for b in (src, dst, whole):
+                if b is not None:
+                    b.free()
+            ctx.close()
 
     synth("config2_4096_raw_rle_frames", 2, 4096, steps=20)
     synth("config3_4096_huffman_only_frames", 3, 4096, steps=20)
@@ -431,7 +474,9 @@ def secondary_workloads(z, sb, torch, device, headline):
             note=f"the reference's {len(corpus4['names'])} golden frames x {corpus4['reps']} replicas; sha256 of the first replica and one frame of every other")
     del cb, co, cl, ce
     synth("one_frame_256MiB_block_mode", 4, 1, 268435456, steps=3, warmup=1)
-    synth("one_frame_1GiB_block_mode", 4, 1, 1073741824, steps=3, warmup=1)  # (the reference's own usage: one big frame per reader)
+    blob, off, ln, cks = synth("one_frame_1GiB_block_mode", 4, 1, 1073741824, steps=3, warmup=1)  # (the reference's own usage: one big frame per reader)
+    # ... and the same frame the reference's way (ABI 9): block by block through a window, here chunk by chunk
+    in_chunks("one_frame_1GiB_in_chunks_of_64MiB_host_to_host", blob[int(off[0]):int(off[0] + ln[0])], 1073741824, cks[0])
     return out
 
 
