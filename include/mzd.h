@@ -488,6 +488,9 @@ void mzd_cursor_destroy(mzd_cursor *c);
  * MZD_ERR_OUT_OF_BLOCKS (framedecompressor.go:196).  A parse error is returned and sticks. */
 int mzd_cursor_next(mzd_cursor *c, const uint8_t *src, uint64_t len, uint64_t max_out, uint64_t start, const int32_t hist[3],
                     uint64_t *consumed, const mzd_batch **chunk, int *last);
+/* host threads a chunk's blocks are parsed on (ranges of blocks side by side, stitched in order: the same descriptions as one
+ * thread makes); 0, the default: up to eight; 1: the serial walk */
+void mzd_cursor_set_threads(mzd_cursor *c, uint32_t n_threads);
 /* from the frame header, once a call has consumed it: Window_Size (frame.go:28-36; the content size of a single-segment frame),
  * Frame_Content_Size or MZD_UNKNOWN_SIZE; the content checksum if the frame has one and its bytes were in sight: returns 1 */
 uint64_t mzd_cursor_window(const mzd_cursor *c);
@@ -513,6 +516,8 @@ int mzd_fstream_open(mzd_ctx *ctx, uint64_t chunk_out, mzd_fstream **fs);
  * would hand out its bytes.  A frame whose window does not fit beside a chunk in 2 GiB: MZD_ERR_UNSUPPORTED.  Errors stick. */
 int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t *dst, uint64_t dst_cap, uint64_t *consumed,
                      uint64_t *produced, int *done);
+/* mzd_cursor_set_threads of the stream's cursor */
+void mzd_fstream_set_threads(mzd_fstream *fs, uint32_t n_threads);
 /* bytes regenerated so far; the cursor (header fields) */
 uint64_t mzd_fstream_total_out(const mzd_fstream *fs);
 const mzd_cursor *mzd_fstream_cursor(const mzd_fstream *fs);

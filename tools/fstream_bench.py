@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: ONE large frame through mzd_fstream_* (a frame in chunks of whole blocks: the device keeps the frame's window and nothing
 else) against the whole-frame path on the same bytes -- host to host, pinned buffers -- with the device memory each of them takes.
-usage: python tools/fstream_bench.py [frame MiB = 1024] [window log = 23] [chunk MiB, ... = 16,64,256]"""
+usage: python tools/fstream_bench.py [frame MiB = 1024] [window log = 23] [chunk MiB, ... = 16,64,256] [cursor threads = 0]"""
 import json
 import os
 import sys
@@ -19,6 +19,7 @@ from tests.test_gpu_chunks import with_window  # noqa: E402
 frame_mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 wlog = int(sys.argv[2]) if len(sys.argv) > 2 else 23
 chunks = [int(c) for c in (sys.argv[3] if len(sys.argv) > 3 else "16,64,256").split(",")]
+cursor_threads = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # (0: the library's default, up to eight; 1: the serial walk)
 n = frame_mib << 20
 sb.set_max_offset(1 << wlog)
 blob, off, ln, ck, ns = sb.make_batch(4, 31, 1, frame_bytes=n, threads=8)
@@ -41,7 +42,7 @@ for c in chunks:
     out = z.PinnedBuffer(n)
     best, peak = None, 0.0
     for rep in range(3):
-        fs = z.FrameStream(ctx, c << 20)
+        fs = z.FrameStream(ctx, c << 20, threads=cursor_threads)
         t0 = time.time()
         pos = made_total = calls = 0
         first = None
@@ -61,7 +62,7 @@ for c in chunks:
         assert made_total == n and sb.checksum64(out.a[:n].tobytes()) == want
         best = min(best or 1e9, t1 - t0)
     print(json.dumps({"bench": "mzd_fstream_next", "frame_MiB": frame_mib, "compressed_MiB": round(len(comp) / 2 ** 20, 1), "window_log": wlog,
-                      "chunk_MiB": c, "calls": calls, "seconds": round(best, 4), "out_GBs": round(n / best / 1e9, 2),
+                      "chunk_MiB": c, "cursor_threads": cursor_threads, "calls": calls, "seconds": round(best, 4), "out_GBs": round(n / best / 1e9, 2),
                       "first_bytes_after_ms": round(first * 1e3, 2), "device_MiB_between_calls": round(peak, 1),
                       "host_ms_per_stage_last_run": stages}), flush=True)
     dst.free()
