@@ -1,7 +1,7 @@
 # The evidence of a round, parameterised by its tag (profiles/<tag>_*): the GPU suite, then rocprofv3 kernel stats + FETCH / WRITE
 # traffic + SQ counters + the bench line (quoting them) for BASELINE config 4, the real-data workload, config 3 and the 8192-frame
 # shard of configs[4]; the config-2 bench line; few large frames (block mode) with kernel stats; the readers; the streaming path; the
-# shard table.  usage: bash tools/experiments/round_profiles.sh r5 [quick]     (quick: config 4 only)
+# shard table; one frame in chunks.  usage: bash tools/experiments/round_profiles.sh r5 [quick]     (quick: config 4 only)
 TAG=${1:-r6}
 QUICK=${2:-}
 cd ${GRAFT_REPO_ROOT:-$PWD}
@@ -31,5 +31,7 @@ timeout 600 python tools/stream_bench.py 8192 12 1,2,3 2>/dev/null | tail -3 | t
 timeout 600 python tools/reader_bench.py 1024 67108864 2>/dev/null | tail -6 | tee gpurun_out/${TAG}_reader.txt
 timeout 600 python tools/reader_bench_cpp.py 2048 32768 2>/dev/null | tee gpurun_out/${TAG}_reader_cpp.jsonl | cut -c1-200
 bash tools/experiments/large_reader.sh 2>&1 | tee gpurun_out/${TAG}_large_frame_reader.txt
+# one frame in chunks (mzd_fstream_*, ABI 9): 1 GiB with a window of 8 MiB, 2.5 GiB (beyond block mode's whole frames) with one of 128 MiB
+(timeout 600 python tools/fstream_bench.py 1024 23 4,16,64,256; timeout 900 python tools/fstream_bench.py 2560 27 64,256) 2>/dev/null | tee gpurun_out/${TAG}_fstream.jsonl | cut -c1-330
 for n in 65536 32768 16384 8192; do timeout 300 python bench.py --cpu-seconds 0 --no-ceiling --frames $n 2>/dev/null | tee gpurun_out/${TAG}_shard_${n}_1gpu.json | pick "shard $n"; done
 ls gpurun_out | grep "^${TAG}" | head -80
