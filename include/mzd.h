@@ -112,7 +112,10 @@ typedef struct mzd_block_desc {
     uint8_t type;            /* MZD_BLOCK_* */
     uint8_t lit_type;        /* MZD_LIT_* (compressed blocks) */
     uint8_t lit_streams;     /* 1 or 4 (MZD_LIT_HUF) */
-    uint8_t reserved0;
+    uint8_t seq_status;      /* n_seq == 0 only: what the reference's DecodeSequences makes of a block whose Number_of_Sequences is zero in
+                                its TWO-byte form (0x80 0x00: modes, tables and a bitstream follow all the same; it reads the padding and
+                                the three initial states and wants the stream used up, sequences.go:126-208) -- MZD_OK, MZD_ERR_BAD_PADDING
+                                or MZD_ERR_SEQ_BITS; reported where the sequence stage's status would be.  0 for every other block */
     uint32_t size;           /* Raw/RLE: regenerated size (Block_Size). Compressed: Block_Size (informational) */
     uint64_t src_off;        /* Raw: payload. RLE: the byte to repeat. */
     uint64_t lit_off;        /* Raw literals: the bytes; RLE literals: the byte; HUF: first stream */

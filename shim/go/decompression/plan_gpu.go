@@ -141,6 +141,15 @@ func (fd *FrameDecompressor) planCompressed(p *gpuPlan, src *bufio.Reader, block
 		return err
 	}
 	cb.NSeq = uint32(ss.Header.NumberOfSequences)
+	if cb.NSeq == 0 && len(ss.Data) > 0 {
+		// Zero sequences in the TWO-byte form (0x80 0x00): modes, tables and a bitstream follow all the same, and DecodeSequences
+		// (sequences.go:126-208) reads the padding and the three initial states and wants the stream used up.  The device's sequence
+		// stage has no chain to run for such a block: the verdict travels in mzd_block_desc.seq_status (ABI 9) and the execution
+		// stage reports it in the stage's place.  Here the reference's own function gives it.
+		if _, err := ss.DecodeSequences(); err != nil {
+			cb.SeqStatus = gpu.StatusFor(err) // ErrBadPadding -> 8, ErrNotAllBitsUsed -> 11
+		}
+	}
 	if cb.NSeq > 0 {
 		cb.SeqPayload = ss.Data
 		var err error

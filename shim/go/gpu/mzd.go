@@ -49,6 +49,17 @@ var Sentinels = map[int]error{}
 // ABI 8; ABI 9 adds a frame in chunks: FrameStream).
 func BuildID() string { return C.GoString(C.mzd_build_id()) }
 
+// StatusFor is SentinelFor's inverse for the errors a binding has to hand DOWN (mzd_block_desc.seq_status): 0 if the error is none
+// of the registered sentinels.
+func StatusFor(err error) uint8 {
+	for code, e := range Sentinels {
+		if e == err {
+			return uint8(code)
+		}
+	}
+	return 0
+}
+
 // SentinelFor turns a per-frame status of the device into the Go error the reference would have returned
 // (INTEGRATION.md section 2, table "Mapping of statuses"); nil for MZD_OK.
 func SentinelFor(status int32) error {
@@ -546,6 +557,7 @@ type CompressedBlock struct {
 	LitStreamSize             [4]uint32 // literals.go:46-62 (jump table + computed 4th)
 	HufTable                  uint32
 	NSeq                      uint32 // sequences.go:378-400
+	SeqStatus                 uint8  // NSeq == 0 in its two-byte form: what DecodeSequences made of the section (0, 8, 11); mzd_block_desc.seq_status
 	SeqPayload                []byte // the sequence bitstream (ss.Data)
 	LLTable, OFTable, MLTable uint32
 }
@@ -553,7 +565,7 @@ type CompressedBlock struct {
 func (b *Batch) AddCompressedBlock(cb *CompressedBlock) {
 	d := C.mzd_block_desc{_type: C.MZD_BLOCK_COMPRESSED, lit_type: C.uint8_t(cb.LitType), lit_streams: C.uint8_t(cb.LitStreams),
 		size: C.uint32_t(cb.BlockSize), lit_regen: C.uint32_t(cb.LitRegen), lit_off: C.uint64_t(b.Append(cb.LitPayload)),
-		huf_table: C.uint32_t(cb.HufTable), n_seq: C.uint32_t(cb.NSeq),
+		huf_table: C.uint32_t(cb.HufTable), n_seq: C.uint32_t(cb.NSeq), seq_status: C.uint8_t(cb.SeqStatus),
 		ll_table: C.uint32_t(cb.LLTable), of_table: C.uint32_t(cb.OFTable), ml_table: C.uint32_t(cb.MLTable)}
 	for i := 0; i < 4; i++ {
 		d.lit_stream_size[i] = C.uint32_t(cb.LitStreamSize[i])

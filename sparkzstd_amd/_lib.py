@@ -57,7 +57,7 @@ MZD_ERR_CHECKSUM = 18
 
 class BlockDesc(ctypes.Structure):
     _fields_ = [("type", ctypes.c_uint8), ("lit_type", ctypes.c_uint8), ("lit_streams", ctypes.c_uint8),
-                ("reserved0", ctypes.c_uint8), ("size", ctypes.c_uint32), ("src_off", ctypes.c_uint64),
+                ("seq_status", ctypes.c_uint8), ("size", ctypes.c_uint32), ("src_off", ctypes.c_uint64),
                 ("lit_off", ctypes.c_uint64), ("lit_regen", ctypes.c_uint32),
                 ("lit_stream_size", ctypes.c_uint32 * 4), ("huf_table", ctypes.c_uint32),
                 ("n_seq", ctypes.c_uint32), ("seq_size", ctypes.c_uint32), ("seq_off", ctypes.c_uint64),

@@ -690,6 +690,10 @@ int mzd_batch_upload(mzd_ctx *ctx, const mzd_batch *b, mzd_dbatch **out)
                 break;
             }
             d.n_seq = bd.n_seq;
+            // (a Number_of_Sequences of zero in its two-byte form still has modes, tables and a bitstream, which the reference reads --
+            // padding and initial states -- and wants used up, sequences.go:126-208: what that comes to is the planner's to say,
+            // mzd_block_desc.seq_status; the execution stage reports it where the sequence stage's own status would stand)
+            d.pad[1] = bd.n_seq == 0 ? bd.seq_status : 0;
             if (bd.n_seq == 0) out_pos += bd.lit_regen;
             else pos_known = false;
             if (bd.n_seq > 0) {
@@ -2761,6 +2765,7 @@ int mzd_fstream_next(mzd_fstream *fs, const uint8_t *src, uint64_t len, uint8_t 
         // what the next chunk finds in front of it
         const uint64_t have = fs->fly_keep + n;
         if (fs->fly_last) {
+            // (the frame's last chunk: nothing follows it)
         } else if (have <= fs->window && ((have + 255) & ~255ull) + fs->chunk_out + 1024 <= fs->slab_bytes) {
             fs->keep = have;  // (the frame so far is within its window and the slab has room behind it: it stays where it is)
         } else {

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(64, 5) void k_exec_b(const uint8_t *__restrict__ in
         const BlockSum bsum = sums[fr.first_block + bi];
         const uint32_t litTotal = bsum.lit_total, seqOut = bsum.out_total;
         int err = bsum.huf_err != 0xFFFFFFFFu ? (int)(bsum.huf_err & 0xFF) : bsum.status;
+        if (err == MZD_OK && b.n_seq == 0) err = b.pad[1];  // (zero sequences in the two-byte form: the planner's verdict, sequences.go:126-208)
         if (err == MZD_OK && litTotal > b.lit_regen) err = MZD_ERR_LITERALS;  // sequence_execution.go:27-29
         const uint32_t blockOut = seqOut + (b.lit_regen - min(litTotal, b.lit_regen));
         if (err == MZD_OK && blockOut > kBlockMax) err = MZD_ERR_CORRUPT_SIZES;

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void k_blk_scan(const DFrame *__restrict__ fram
                 const BlockSum *const sp = sums + fr.first_block + bi;
                 const uint32_t huf_err = sp->huf_err, lit_total = sp->lit_total, lit_regen = bp->lit_regen;
                 e = huf_err != 0xFFFFFFFFu ? (int)(huf_err & 0xFF) : sp->status;
+                if (e == MZD_OK && bp->n_seq == 0) e = bp->pad[1];  // (zero sequences in the two-byte form: the planner's verdict)
                 if (e == MZD_OK && lit_total > lit_regen) e = MZD_ERR_LITERALS;  // sequence_execution.go:27-29
                 bo = sp->out_total + (lit_regen - min(lit_total, lit_regen));
                 if (e == MZD_OK && bo > kBlockMax) e = MZD_ERR_CORRUPT_SIZES;

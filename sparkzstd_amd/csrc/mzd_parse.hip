@@ -555,6 +555,13 @@ __device__ void p_walk_frame(const uint8_t *base, uint64_t begin, uint64_t end, 
                 }
                 if (q > lim) P_FAIL(MZD_ERR_TRUNCATED);
                 if (q == lim) P_FAIL(MZD_ERR_BAD_PADDING);  // empty bitstream: the reference would spin at sequences.go:133
+                if (nseq == 0) {
+                    // zero sequences in the two-byte form (planner.cpp parse_compressed_block): padding + initial states must use the
+                    // bitstream up (sequences.go:126-208); the execution stage reports the verdict in the sequence stage's place
+                    const uint8_t top = base[lim - 1];
+                    const int used = (8 - (31 - __clz((int)max((uint32_t)top, 1u)))) + (int)use[MZD_FSE_LL].log + (int)use[MZD_FSE_OF].log + (int)use[MZD_FSE_ML].log;
+                    d.pad[1] = top == 0 ? (uint8_t)MZD_ERR_BAD_PADDING : ((long long)(lim - q) * 8 == (long long)used ? (uint8_t)MZD_OK : (uint8_t)MZD_ERR_SEQ_BITS);
+                }
                 d.n_seq = nseq;
                 d.rec_off = fb.rec0 + c.n_rec;
                 d.tile_off = fb.tile0 + c.n_tile;

@@ -492,6 +492,23 @@ struct FrameParser {
         q += (uint64_t)used;
         if (q > lim) return MZD_ERR_TRUNCATED;
         if (q == lim) return MZD_ERR_BAD_PADDING;  // empty bitstream: the reference would spin at sequences.go:133
+        if (nseq == 0) {
+            // Zero sequences in the two-byte form (0x80 0x00).  The reference decodes the section like any other (sequences.go:126-208):
+            // the padding, the three initial states, no sequence -- and then wants the bitstream used up to the bit.  What that comes to
+            // is decided here (the device's sequence stage has no chain to run for the block) and reported by the execution stage in
+            // the stage's place.  (Found by the chunk soak of round 6: such a block passed as its literals.)
+            auto log_of = [&](uint32_t idx) -> int {
+                if (idx == kPredefLL || idx == kPredefML) return 6;
+                if (idx == kPredefOF) return 5;
+                if (idx >= kInheritLL) return -1;  // (the table of an earlier range: settled when the ranges are stitched)
+                return out.fse_tables[idx].acc_log;
+            };
+            const int ll = log_of(bd.ll_table), of = log_of(bd.of_table), ml = log_of(bd.ml_table);
+            const uint8_t top = base[lim - 1];
+            if (ll < 0 || of < 0 || ml < 0) bd.seq_status = 0xFF;  // (decided by parse_blocks_parallel's stitching)
+            else if (top == 0) bd.seq_status = MZD_ERR_BAD_PADDING;  // sequences.go:141-143
+            else bd.seq_status = (int64_t)(lim - q) * 8 - (8 - highbit(top)) - (ll + of + ml) == 0 ? MZD_OK : MZD_ERR_SEQ_BITS;
+        }
         bd.n_seq = nseq;
         bd.seq_off = q;
         bd.seq_size = (uint32_t)(lim - q);
@@ -651,6 +668,7 @@ bool parse_blocks_parallel(const uint8_t *base, uint64_t end, const std::vector<
         for (auto &r : rg) {
             for (auto &b : r.part.blocks) {
                 if (b.type != MZD_BLOCK_COMPRESSED) continue;
+                if (b.seq_status == 0xFF) return false;  // (zero sequences in the long form under an inherited table: the serial walk decides)
                 if ((b.ll_table == kInheritLL && c[0] == MZD_NO_TABLE) || (b.of_table == kInheritOF && c[1] == MZD_NO_TABLE) ||
                     (b.ml_table == kInheritML && c[2] == MZD_NO_TABLE) || (b.huf_table == kInheritHuf && c[3] == MZD_NO_TABLE))
                     return false;

@@ -98,6 +98,8 @@ def run_batch(batch, blob: bytes, prefixes=None, hists_out=None):
                     lits = huf_decode(cells, ht.max_bits, blob[b.lit_off:b.lit_off + b.lit_stream_size[0]], b.lit_regen)
             # sequences
             lit_pos = 0
+            if b.n_seq == 0 and b.seq_status:
+                raise ValueError(f"sequence section of no sequences: status {b.seq_status}")
             if b.n_seq:
                 tabs = []
                 for ti in (b.ll_table, b.of_table, b.ml_table):

@@ -329,3 +329,35 @@ def test_repeat_offsets_from_the_chunk_before_reach_back_more_than_8_mib(oracle)
             bad = np.nonzero(a[:min(len(a), len(b))] != b[:min(len(a), len(b))])[0]
             raise AssertionError((ev, chunk, len(got), len(bad), bad[:6].tolist()))
         ctx.close()
+
+
+def test_zero_sequences_in_the_two_byte_form_on_the_device(oracle):
+    """tests/test_planner.py::test_zero_sequences_in_the_two_byte_form on the device: the frame the chunk soak found and the hand-made
+    ones, planned on the host and on the device, whole (every execution kernel) and in chunks -- the reference's verdict each time,
+    reported in the sequence stage's place (after the block's literal errors, after the blocks before it)."""
+    import os
+    from tests.test_planner import _zero_sequence_frames
+    f = open(os.path.join(os.path.dirname(__file__), "golden", "fuzz_zero_sequences_long_form.zst"), "rb").read()
+    cases = [("the soak's frame", f, 11)] + _zero_sequence_frames()
+    frames = [c[1] for c in cases]
+    want = []
+    for what, frame, rc_want in cases:
+        rc, ref, *_ = oracle.decode_frame(frame, cap=1 << 20)
+        assert rc == rc_want
+        want.append(ref if rc == 0 else None)
+    for ev in (0, 1, 2, 3, 4, 5):
+        ctx = z.Context(0, exec_variant=ev)
+        for device_plan in (False, True):
+            outs, sts = z.decode_frames(frames, ctx, device_plan=device_plan)
+            assert sts == [c[2] for c in cases], (ev, device_plan, sts)
+            assert all(o == w for o, w, s in zip(outs, want, sts) if s == 0)
+        ctx.close()
+    ctx = z.Context(0)
+    for (what, frame, rc_want), w in zip(cases, want):
+        if rc_want == 0:
+            assert stream_decode(frame, ctx, 128 * KIB)[0] == w, what
+        else:
+            with pytest.raises(z.MzdError) as e:
+                stream_decode(frame, ctx, 128 * KIB)
+            assert e.value.code == rc_want, what
+    ctx.close()

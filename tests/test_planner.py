@@ -427,3 +427,40 @@ def test_blocks_parsed_in_ranges_describe_what_the_serial_walk_describes(corpus)
             p.close()
         assert res[0] == res[1]
     assert res[0][0] != 0 or True
+
+
+def _zero_sequence_frames():
+    """frames whose last block declares ZERO sequences in the two-byte form (0x80 0x00) -- modes, tables and a bitstream follow all the
+    same -- with what the reference makes of each (sequences.go:126-208: padding + initial states must use the bitstream up)"""
+    from tests.frame_splice import splice_frame
+    head = (0, b"hello world, hello", 18)
+    lit = bytes([(23 << 3) | 1, 0x41])  # RLE literals: 23 x 'A'
+    mk = lambda tail: splice_frame([head, (2, lit + b"\x80\x00" + tail, len(lit) + 2 + len(tail))])
+    return [("RLE tables, the padding bit alone", mk(b"\x54\x00\x00\x00\x01"), 0),
+            ("RLE tables, one bit left over", mk(b"\x54\x00\x00\x00\x03"), 11),
+            ("RLE tables, a zero byte on top", mk(b"\x54\x00\x00\x00\x00"), 8),
+            ("predefined tables, 17 state bits behind 7 bits of padding", mk(b"\x00\x12\x34\x02"), 0),
+            ("predefined tables, a byte too many", mk(b"\x00\x12\x34\x56\x02"), 11)]
+
+
+def test_zero_sequences_in_the_two_byte_form(oracle):
+    """Found by the chunk soak of round 6 (tests/golden/fuzz_zero_sequences_long_form.zst: a corpus frame with ONE byte flipped): a block
+    whose Number_of_Sequences is zero in its two-byte form used to pass as its literals; the reference decodes the section and
+    returns ErrNotAllBitsUsed.  The planner now says what the reference's DecodeSequences makes of such a block
+    (mzd_block_desc.seq_status) -- the oracle's verdict on every case; the descriptor interpreter honours it."""
+    import os
+    f = open(os.path.join(os.path.dirname(__file__), "golden", "fuzz_zero_sequences_long_form.zst"), "rb").read()
+    for what, frame, want in [("the soak's frame", f, 11)] + _zero_sequence_frames():
+        rc, ref, *_ = oracle.decode_frame(frame, cap=1 << 20)
+        assert rc == want, what
+        p = z.Plan()
+        assert p.add_frame(frame)[0] == 0
+        b = p.finalize()
+        last = b.blocks[b.n_blocks - 1]
+        assert last.n_seq == 0 and last.seq_status == want, (what, last.seq_status)
+        if want == 0:
+            assert run_batch(b, _blob_of(b))[0] == ref, what
+        else:
+            with pytest.raises(ValueError):
+                run_batch(b, _blob_of(b))
+        p.close()

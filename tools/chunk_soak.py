@@ -37,7 +37,12 @@ def declared_window(f):
         return None
     fhd = f[4]
     if fhd & 0x20:
-        return None  # single segment: the window is the content
+        # single segment: the window is the declared content size (frame.go:49-61; 1, 2, 4 or 8 bytes behind the dictionary id)
+        n = (1, 2, 4, 8)[fhd >> 6]
+        p = 5 + (0, 1, 2, 4)[fhd & 3]
+        if len(f) < p + n:
+            return None
+        return int.from_bytes(f[p:p + n], "little") + (256 if n == 2 else 0)
     wd = f[5]
     base = 1 << (10 + (wd >> 3))
     return base + (base >> 3) * (wd & 7)
@@ -69,6 +74,18 @@ def through_stream(f, c, chunk, piece):
 
 bad = done = n_ok = n_err = n_more = n_chunks_gt1 = 0
 t0 = time.time()
+
+
+def keep(f, what):
+    """a frame the stream and the oracle disagree on goes to gpurun_out/ with what was asked of the stream"""
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"chunk_soak_bad_{seed}_{done}.zst"), "wb") as fh:
+        fh.write(f)
+    with open(os.path.join(d, f"chunk_soak_bad_{seed}_{done}.json"), "w") as fh:
+        json.dump(what, fh)
+
+
 while done < n_mut:
     b = bytearray(pool[int(rng.integers(len(pool)))])
     r = rng.random()
@@ -93,12 +110,14 @@ while done < n_mut:
         if rc == 0:
             bad += 1
             print(f"DISAGREE [{name}]: oracle ok, the stream wants more bytes, len", len(f), flush=True)
+            keep(f, {"ctx": name, "chunk": chunk, "piece": piece, "what": "wants more"})
     elif st == 0:
         n_ok += 1
         n_chunks_gt1 += 1 if len(out) > chunk else 0
         if rc != 0 or out != ref:
             bad += 1
             print(f"DISAGREE [{name}]: stream ok ({len(out)} bytes), oracle rc", rc, "len", len(f), "chunk", chunk, flush=True)
+            keep(f, {"ctx": name, "chunk": chunk, "piece": piece, "what": "stream ok", "oracle_rc": rc, "out_len": len(out)})
     else:
         n_err += 1
         if rc == 0:
@@ -109,6 +128,7 @@ while done < n_mut:
             if not ok:
                 bad += 1
                 print(f"DISAGREE [{name}]: oracle ok, stream status", st, "len", len(f), "chunk", chunk, "window", w, flush=True)
+                keep(f, {"ctx": name, "chunk": chunk, "piece": piece, "what": "stream status", "status": st, "window": w})
     if done % 500 == 0:
         print(f"{done} mutations: {n_ok} decoded ({n_chunks_gt1} in more than one chunk), {n_err} errors, {n_more} cut, {bad} bad, {time.time() - t0:.0f} s", flush=True)
 print(f"{done} mutations: {n_ok} decoded ({n_chunks_gt1} in more than one chunk), {n_err} errors, {n_more} cut, {bad} bad, {time.time() - t0:.0f} s")
