@@ -173,6 +173,52 @@ int main(int argc, char **argv)
         free(c);
         acc += total + n;
     }
+    // 6. the cursor (one frame in chunks of whole blocks, ABI 9): intact and mutated frames, the source handed over in exact-size heap
+    // copies of what is left, small and large chunk bounds, the blocks of a chunk parsed serially and in ranges on eight threads
+    uint64_t n_chunks = 0, n_cur_bad = 0;
+    for (int threads = 1; threads <= 8; threads += 7) {
+        for (size_t fi = 0; fi < frames.size(); fi++) {
+            for (int m = 0; m < 1 + n_mut / 4; m++) {
+                std::vector<uint8_t> b = frames[fi];
+                if (m > 0) {
+                    if (rnd() % 5 == 0) b.resize(rnd() % (b.size() + 1));
+                    else
+                        for (int k = 0; k < 2 && b.size() > 4; k++) b[4 + rnd() % (b.size() - 4)] ^= (uint8_t)(1 + rnd() % 255);
+                }
+                mzd_cursor *cur = mzd_cursor_create();
+                mzd_cursor_set_threads(cur, (uint32_t)threads);
+                const uint64_t max_out = (rnd() & 1) ? 131072 : (1ull << 30);
+                size_t pos = 0;
+                for (int guard = 0; guard < 100000; guard++) {
+                    const size_t left = b.size() - pos;
+                    uint8_t *c = (uint8_t *)malloc(left ? left : 1);
+                    if (left) memcpy(c, b.data() + pos, left);
+                    uint64_t used = 0;
+                    const mzd_batch *chunk = nullptr;
+                    int last = 0;
+                    const int32_t hist[3] = {1, 4, 8};
+                    const int rc = mzd_cursor_next(cur, c, left, max_out, 0, hist, &used, &chunk, &last);
+                    if (rc == MZD_OK && used > left) { fprintf(stderr, "cursor consumed beyond its source\n"); return 1; }
+                    if (rc == MZD_OK && chunk) {
+                        acc += walk(chunk);
+                        n_chunks++;
+                        if (m == 0 && chunk->in_size != used) { fprintf(stderr, "cursor: a chunk's input is not what it consumed\n"); return 1; }
+                    }
+                    free(c);
+                    pos += used;
+                    if (rc != MZD_OK) { n_cur_bad++; break; }
+                    if (last) break;
+                    if (!chunk && used == 0) {  // wants more than there is: a cut frame
+                        if (m == 0) { fprintf(stderr, "cursor starved on an intact frame\n"); return 1; }
+                        break;
+                    }
+                }
+                if (m == 0 && pos + 4 != b.size() && pos != b.size()) { fprintf(stderr, "cursor left %zu bytes of an intact frame\n", b.size() - pos); return 1; }
+                mzd_cursor_destroy(cur);
+            }
+        }
+    }
+    printf("cursor: %llu chunks described, %llu frames ended in a status\n", (unsigned long long)n_chunks, (unsigned long long)n_cur_bad);
     printf("san_planner ok: %llu mutated frames planned, %llu rejected with a status, %llu intact concatenations split (acc %llx)\n",
            (unsigned long long)n_ok, (unsigned long long)n_bad, (unsigned long long)n_split_ok, (unsigned long long)acc);
     return 0;

@@ -53,7 +53,27 @@ if len(sys.argv) > 2:
     t1 = time.time()
     assert got == data
     print(f"FrameReader, one frame of {big >> 20} MiB ({len(comp) >> 20} MiB compressed): {(t1 - t0) * 1e3:.1f} ms = {big / (t1 - t0) / 1e6:.0f} MB/s "
-          f"host to host (planning on one host thread + upload + device pass + download)")
+          f"host to host (planning + upload + device pass + download)")
+    # the same frame in CHUNKS of whole blocks (ABI 9: the device keeps the frame's window, not the frame; bytes as the source delivers)
+    for chunk in (16 << 20, 64 << 20):
+        z.FrameReader(io.BytesIO(comp), chunk_bytes=chunk).read()
+        r = z.FrameReader(io.BytesIO(comp), chunk_bytes=chunk)
+        buf = bytearray(chunk)
+        t0 = time.time()
+        first = None
+        n = 0
+        while True:
+            k = r.readinto(buf)
+            if not k:
+                break
+            n += k
+            if first is None:
+                first = time.time() - t0
+        t1 = time.time()
+        assert n == big
+        print(f"FrameReader(chunk_bytes={chunk >> 20} MiB), readinto: {(t1 - t0) * 1e3:.1f} ms = {big / (t1 - t0) / 1e6:.0f} MB/s host to host, first bytes after "
+              f"{first * 1e3:.1f} ms")
+        r.close()
     ctx.timing_reset(True)
     outs, sts = z.decode_frames([comp], ctx)
     ctx.sync()
