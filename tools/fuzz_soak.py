@@ -24,6 +24,13 @@ from tests.oracle_binding import load_oracle
 
 n_mut = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+# hunting a hang: batches up to `first_batch` are generated (the random sequence stays the soak's) but not decoded, and from then on
+# every batch is left in gpurun_out/fuzz_soak_batch.pkl with the context that is about to take it, so that a run cut by `timeout`
+# leaves behind what it was decoding.  usage: fuzz_soak.py <n> <seed> <first_batch>
+first_batch = int(sys.argv[3]) if len(sys.argv) > 3 else None
+if first_batch is not None:
+    import faulthandler
+    faulthandler.dump_traceback_later(100, repeat=True)  # a stall: where the host is (which library call, or the oracle)
 rng = np.random.default_rng(seed)
 orc = load_oracle()
 L = _lib.load()
@@ -105,10 +112,25 @@ while done < n_mut:
             for pos in rng.integers(min(lo, len(b) - 1), len(b), size=int(rng.integers(1, 4))):
                 b[int(pos)] ^= int(rng.integers(1, 256))
         frames.append(bytes(b))
+    if first_batch is not None and n_batches < first_batch:
+        for name, c in ctxs:
+            if c is bail_ctx:
+                rng.integers(1, 6)
+        done += len(frames)
+        continue
     want = [orc.decode_frame(f, cap=4 << 20) for f in frames]
     for name, c in ctxs:
         if c is bail_ctx:
-            assert L.mzd_debug_force_fixup_bail(c._c, int(rng.integers(1, 6))) == 0
+            bail_step = int(rng.integers(1, 6))
+            assert L.mzd_debug_force_fixup_bail(c._c, bail_step) == 0
+        if first_batch is not None:
+            import pickle
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            if name == ctxs[0][0]:  # (the frames once per batch, the context that is about to take them every time)
+                with open(os.path.join(ROOT, "gpurun_out", "fuzz_soak_batch.pkl"), "wb") as fh:
+                    pickle.dump({"batch": n_batches, "frames": frames}, fh)
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_soak_now.json"), "w") as fh:
+                json.dump({"batch": n_batches, "ctx": name, "bail_step": bail_step if c is bail_ctx else 0, "t": time.time() - t0}, fh)
         outs, sts, lp = decode(frames, c)
         for k, bit in (("block mode", _lib.MZD_PASS_BLOCK_MODE), ("k_exec_c", _lib.MZD_PASS_EXEC_C), ("k_exec_b", _lib.MZD_PASS_EXEC_B)):
             n_pass[k] += 1 if lp & bit else 0
