@@ -56,8 +56,9 @@ if len(sys.argv) > 2:
           f"host to host (planning + upload + device pass + download)")
     # the same frame in CHUNKS of whole blocks (ABI 9: the device keeps the frame's window, not the frame; bytes as the source delivers)
     for chunk in (16 << 20, 64 << 20):
-        z.FrameReader(io.BytesIO(comp), chunk_bytes=chunk).read()
         r = z.FrameReader(io.BytesIO(comp), chunk_bytes=chunk)
+        assert r.read() == data  # warm-up: the reader's pinned chunk buffer, the allocations of this size
+        r.Reset(io.BytesIO(comp))
         buf = bytearray(chunk)
         t0 = time.time()
         first = None
@@ -72,7 +73,7 @@ if len(sys.argv) > 2:
         t1 = time.time()
         assert n == big
         print(f"FrameReader(chunk_bytes={chunk >> 20} MiB), readinto: {(t1 - t0) * 1e3:.1f} ms = {big / (t1 - t0) / 1e6:.0f} MB/s host to host, first bytes after "
-              f"{first * 1e3:.1f} ms")
+              f"{first * 1e3:.1f} ms; stream stages (host ms): {getattr(r, 'stream_timing', None)}")
         r.close()
     ctx.timing_reset(True)
     outs, sts = z.decode_frames([comp], ctx)
